@@ -1,0 +1,216 @@
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU
+box).  It imports the reference's own classes (modeling.bert.LFQBert,
+modeling.conv_vqgan.ConvVQModel, modeling.modules.sample), loads seeded synthetic
+weights into them with strict key checking (which also pins the checkpoint key names and
+shapes of SURVEY.md 8b), runs them on CPU in fp32 and stores inputs + outputs as .npz.
+Nothing of the reference's source travels: fixtures hold tensors only.
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+Weights for the tiny cases are stored inside the fixtures; the full-size cases regenerate
+weights from a seed with oracle.make_*_weights and guard them with a sha256 sentinel.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MASKBIT_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import maskbit_oracle as O  # noqa: E402
+
+
+def _import_reference():
+    """The reference imports torchvision eagerly for its (out-of-scope) perceptual losses;
+    torchvision is absent here, so give it an empty stand-in before importing."""
+    for name in ("torchvision", "torchvision.models", "torchvision.models.feature_extraction"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchvision.models"].feature_extraction = sys.modules["torchvision.models.feature_extraction"]
+    sys.modules["torchvision.models.feature_extraction"].create_feature_extractor = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    # our repo also has a top-level ``modeling`` shim; make sure the reference's wins here
+    for k in [k for k in sys.modules if k == "modeling" or k.startswith("modeling.")]:
+        del sys.modules[k]
+    from modeling.bert import LFQBert
+    from modeling.conv_vqgan import ConvVQModel
+    from modeling.modules import sample, get_masking_ratio, combine_factorized_tokens, split_factorized_tokens
+    assert os.path.realpath(sys.modules["modeling"].__file__).startswith(os.path.realpath(REF))
+    return LFQBert, ConvVQModel, sample, get_masking_ratio, combine_factorized_tokens, split_factorized_tokens
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def tok_config(c: O.TokCfg) -> Cfg:
+    return Cfg(quantizer_type="lookup-free", codebook_size=2 ** c.token_size, token_size=c.token_size,
+               commitment_cost=0.25, entropy_loss_weight=0.02, entropy_loss_temperature=0.01, entropy_gamma=1.0,
+               num_channels=c.num_channels, hidden_channels=c.hidden_channels, channel_mult=list(c.channel_mult),
+               num_resolutions=c.num_resolutions, num_res_blocks=c.num_res_blocks, sample_with_conv=c.sample_with_conv)
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def npify(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+TINY_GEN = O.GenCfg(bits=12, splits=2, hidden=128, depth=2, heads=4, mlp=256, seq=256, nclass=10)
+TINY_TOK = O.TokCfg(token_size=12, hidden_channels=32, channel_mult=(1, 2, 2), num_resolutions=3, num_res_blocks=1)
+FULL_GEN12 = O.GenCfg(bits=12, splits=2)
+FULL_TOK12 = O.TokCfg(token_size=12)
+FULL_TOK10 = O.TokCfg(token_size=10)
+
+
+def build_ref_gen(LFQBert, cfg: O.GenCfg, sd):
+    model = LFQBert(img_size=256, hidden_dim=cfg.hidden, codebook_size=2 ** cfg.bits, codebook_splits=cfg.splits,
+                    depth=cfg.depth, heads=cfg.heads, mlp_dim=cfg.mlp, dropout=0.1, nclass=cfg.nclass,
+                    input_stride=16, use_prenorm=False)
+    model.load_state_dict(sd, strict=True)
+    return model.eval().requires_grad_(False)
+
+
+def build_ref_tok(ConvVQModel, cfg: O.TokCfg, sd):
+    model = ConvVQModel(tok_config(cfg), legacy=False)
+    model.load_state_dict(sd, strict=True)
+    return model.eval().requires_grad_(False)
+
+
+def masked_test_tokens(cfg: O.GenCfg, b: int, seed: int) -> torch.Tensor:
+    """Tokens with rows having group-0-only / group-1-only / both / none masked."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(0, cfg.group_codes, (b, cfg.seq, cfg.splits), generator=g)
+    r = torch.rand(b, cfg.seq, cfg.splits, generator=g)
+    frac = torch.linspace(0.0, 1.0, b).view(b, 1, 1)
+    return torch.where(r < frac, torch.full_like(t, cfg.group_codes), t)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    LFQBert, ConvVQModel, ref_sample, ref_ratio, ref_combine, ref_split = _import_reference()
+
+    # ---- 1. tiny generator forward --------------------------------------------------------
+    gsd = O.make_generator_weights(TINY_GEN, seed=11, head_gain=40.0)
+    gen = build_ref_gen(LFQBert, TINY_GEN, gsd)
+    toks = masked_test_tokens(TINY_GEN, 5, seed=5)
+    labels = torch.tensor([0, 3, 9, 7, 2])
+    drop = torch.tensor([False, True, False, False, True])
+    logits = gen(toks.clone(), labels.clone(), drop.clone())
+    np.savez_compressed(os.path.join(OUT, "gen_tiny.npz"), tokens=toks.numpy(), labels=labels.numpy(),
+                        drop=drop.numpy(), logits=logits.numpy(), **{"w." + k: v.numpy() for k, v in gsd.items()})
+    print("gen_tiny logits", tuple(logits.shape), float(logits.abs().max()))
+
+    # ---- 2. tiny tokenizer decode (+ encode) ----------------------------------------------
+    tsd = O.make_tokenizer_weights(TINY_TOK, seed=21, with_encoder=True)
+    tok = build_ref_tok(ConvVQModel, TINY_TOK, tsd)
+    g = torch.Generator().manual_seed(6)
+    dtoks = torch.randint(0, 2 ** TINY_TOK.token_size, (3, 256), generator=g)
+    img = tok.decode_tokens(dtoks.float())
+    x_in = torch.rand(2, 3, 64, 64, generator=g)
+    zq, res = tok.encode(x_in)
+    rec, _ = tok(x_in)
+    np.savez_compressed(os.path.join(OUT, "tok_tiny.npz"), tokens=dtoks.numpy(), image=img.numpy(),
+                        enc_input=x_in.numpy(), enc_zq=zq.numpy(), enc_indices=res["min_encoding_indices"].numpy(),
+                        recon=rec.numpy(), **{"w." + k: v.numpy() for k, v in tsd.items()})
+    print("tok_tiny image", tuple(img.shape), float(img.mean()), float(img.std()))
+
+    # ---- 3. tiny end-to-end sample(): per-step tokens + image, with CFG cosine and without --
+    for name, kw in {
+        "sample_tiny_cfg": dict(num_steps=8, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0,
+                                randomize_temperature=8.2, mask_schedule_strategy="arccos"),
+        "sample_tiny_nocfg": dict(num_steps=6, guidance_scale=0.0, guidance_annealing="none", scale_pow=4.0,
+                                  randomize_temperature=4.5, mask_schedule_strategy="linear"),
+        "sample_tiny_linear_anneal": dict(num_steps=5, guidance_scale=3.0, guidance_annealing="linear", scale_pow=1.0,
+                                          randomize_temperature=2.0, mask_schedule_strategy="cosine",
+                                          use_sampling_annealing=True),
+    }.items():
+        B = 3
+        y = torch.tensor([1, 4, 8])
+        torch.manual_seed(1234)
+        image, steps = ref_sample(gen, tok, num_samples=B, labels=y.clone(), softmax_temperature=1.0, mask_token=64,
+                                  patch_size=16, codebook_size=4096, codebook_splits=2, **kw)
+        u8 = (torch.clamp(image, 0.0, 1.0) * 255.0).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), labels=y.numpy(), seed=1234,
+                            steps=torch.stack(steps).numpy(), image=image.numpy(), image_u8=u8.numpy(),
+                            kw_keys=np.array(list(kw.keys())), kw_vals=np.array([str(v) for v in kw.values()]))
+        print(name, "final mask tokens left:", int((steps[-1] == 64).sum()))
+
+    # ---- 4. schedule tables + helpers ------------------------------------------------------
+    sched = {}
+    for mode in ("arccos", "cosine", "linear", "square", "root"):
+        for N in (16, 64, 128, 256):
+            sched[f"{mode}_{N}"] = np.array([float(torch.floor(ref_ratio((i + 1) / N, mode) * 512)) for i in range(N)])
+            sched[f"ratio_{mode}_{N}"] = np.array([float(ref_ratio((i + 1) / N, mode)) for i in range(N)], dtype=np.float32)
+    g = torch.Generator().manual_seed(2)
+    t = torch.randint(0, 4096, (2, 256), generator=g)
+    sp = ref_split(t, 4096, 2)
+    sched["split_in"] = t.numpy(); sched["split_out"] = sp.numpy(); sched["combine_out"] = ref_combine(sp, 4096, 2).numpy()
+    np.savez_compressed(os.path.join(OUT, "schedule.npz"), **sched)
+
+    # ---- 5. full-size 12-bit generator: logits slices + hashes (weights from seed) ---------
+    gsd_full = O.make_generator_weights(FULL_GEN12, seed=100, head_gain=12.0)
+    genF = build_ref_gen(LFQBert, FULL_GEN12, gsd_full)
+    toksF = masked_test_tokens(FULL_GEN12, 4, seed=9)
+    labelsF = torch.tensor([1, 7, 282, 999])
+    dropF = torch.tensor([False, False, True, False])
+    logitsF = genF(toksF.clone(), labelsF.clone(), dropF.clone())
+    pF = torch.softmax(logitsF, -1)
+    print("gen_full: mean max-prob", float(pF.max(-1).values.mean()))
+    np.savez_compressed(os.path.join(OUT, "gen_full12.npz"), seed=100, head_gain=12.0, tokens=toksF.numpy(),
+                        labels=labelsF.numpy(), drop=dropF.numpy(), logits=logitsF.numpy().astype(np.float32),
+                        w_sha_in_proj0=sha(gsd_full["transformer.layers.0.0.mha.in_proj_weight"]),
+                        w_sha_pred=sha(gsd_full["prediction_layer.weight"]))
+
+    # ---- 6. full-size 12-bit decoder: 2 token maps -> crops + stats ------------------------
+    tsd_full = O.make_tokenizer_weights(FULL_TOK12, seed=200)
+    tsd_full_enc = O.make_tokenizer_weights(FULL_TOK12, seed=200, with_encoder=True)
+    assert all(torch.equal(tsd_full[k], tsd_full_enc[k]) for k in tsd_full)
+    tokF = build_ref_tok(ConvVQModel, FULL_TOK12, tsd_full_enc)
+    g = torch.Generator().manual_seed(10)
+    dtoksF = torch.randint(0, 4096, (2, 256), generator=g)
+    imgF = tokF.decode_tokens(dtoksF.float())
+    crops = {f"crop_{y}_{x}": imgF[:, :, y:y + 16, x:x + 16].numpy() for (y, x) in ((0, 0), (120, 120), (240, 240), (37, 201))}
+    np.savez_compressed(os.path.join(OUT, "tok_full12.npz"), seed=200, tokens=dtoksF.numpy(),
+                        mean=imgF.mean((0, 2, 3)).numpy(), std=imgF.std((0, 2, 3)).numpy(),
+                        image_half=imgF[:, :, ::2, ::2].numpy().astype(np.float16),
+                        w_sha_conv_in=sha(tsd_full["decoder.conv_in.weight"]), **crops)
+    print("tok_full12 image mean/std", imgF.mean().item(), imgF.std().item())
+
+    # ---- 7. BASELINE config 1: 10-bit tokenizer encode+decode one 256x256 image on CPU -----
+    tsd10 = O.make_tokenizer_weights(FULL_TOK10, seed=300, with_encoder=True)
+    tok10 = build_ref_tok(ConvVQModel, FULL_TOK10, tsd10)
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    zq10, res10 = tok10.encode(x)
+    idx10 = res10["min_encoding_indices"]
+    rec10 = tok10.decode_tokens(idx10.reshape(1, -1))
+    np.savez_compressed(os.path.join(OUT, "tok_full10_cfg1.npz"), seed=300, indices=idx10.numpy(),
+                        recon_half=rec10[:, :, ::2, ::2].numpy().astype(np.float16),
+                        recon_crop=rec10[:, :, 100:132, 100:132].numpy(),
+                        w_sha_conv_in=sha(tsd10["encoder.conv_in.weight"]))
+    print("cfg1 indices", tuple(idx10.shape), int(idx10.min()), int(idx10.max()))
+
+    # ---- 8. RNG stream sentinels ----------------------------------------------
+    torch.manual_seed(1234)
+    a = torch.empty(1536, 64).exponential_(1)
+    b = torch.rand(3, 256, 2)
+    np.savez_compressed(os.path.join(OUT, "rng_sentinel.npz"), exp_sha=sha(a), rand_sha=sha(b), torch_version=torch.__version__)
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()
