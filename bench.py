@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of 64-step MaskBit-12bit sampling with CFG + conv-VQGAN decode.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: per GPU, B=64 class-conditional images through
+the whole of sample() -- noise draw (reference RNG protocol), 64 x [2B-sequence LFQBert forward, CFG,
+softmax, categorical draw, Gumbel confidence, re-mask], token combine, conv-VQGAN decode to 256x256,
+uint8 NHWC -- i.e. BASELINE.json configs[2] (C3).  With N>1 (launched by torch.distributed.run, one
+process per GPU) every rank samples its own B=64 shard (weak scaling, no data-path collective) and
+the uint8 images are all-gathered once per batch over RCCL.  Weights are random-init of the real
+architecture (304.8 M-param generator, 29.4 M-param decoder), labels synthetic; no checkpoint or
+dataset is available offline.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     : dominant kernel (the bf16 MFMA GEMM family) algorithmic FLOPs / HIP-event duration
+  cpu_baseline : the CPU oracle (oracle/, a parity-checked port of the reference) timed on the host
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+B_PER_GPU = 64
+NUM_STEPS = 64
+GEN = dict(img_size=256, hidden_dim=1024, codebook_size=4096, codebook_splits=2, depth=24, heads=16, mlp_dim=4096,
+           dropout=0.1, use_prenorm=False, input_stride=16)
+SAMPLER = dict(guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2,
+               mask_schedule_strategy="arccos", softmax_temperature=1.0)      # configs/generator/maskbit_generator_12bit.yaml
+F_SEQ = 162.33e9                        # algorithmic FLOPs per 257-token sequence forward
+F_DEC = 185.97e9                        # per decoded image
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def tok_config():
+    return Cfg(quantizer_type="lookup-free", codebook_size=4096, token_size=12, num_channels=3, hidden_channels=128,
+               channel_mult=[1, 1, 2, 2, 4], num_resolutions=5, num_res_blocks=2, sample_with_conv=True)
+
+
+def seeded_fill(model: torch.nn.Module, seed: int) -> None:
+    """Random-init weights of the real shapes, seeded; norm gains ~1, everything else N(0, small)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1 and ("norm" in name or "first_layer.0" in name or "last_layer.2" in name) and name.endswith("weight"):
+                p.copy_(1.0 + 0.02 * torch.randn(p.shape, generator=g))
+            elif p.dim() == 4:
+                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                p.copy_(torch.randn(p.shape, generator=g) / fan_in ** 0.5)
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+        if hasattr(model, "prediction_layer"):
+            model.prediction_layer.weight.mul_(12.0)       # peaky head: mean max-prob ~0.85 (SURVEY 7 "hard parts")
+
+
+def cpu_baseline():
+    """Time the CPU oracle on a bounded sample of the same workload:
+    2 complete CFG steps at B=8 (16 sequences) after 1 warm-up step, and one decode of 8 images."""
+    from oracle import maskbit_oracle as O
+    gcfg, tcfg = O.GenCfg(bits=12, splits=2), O.TokCfg(token_size=12)
+    gsd = O.make_generator_weights(gcfg, seed=100, head_gain=12.0)
+    tsd = O.make_tokenizer_weights(tcfg, seed=200)
+    B = 8
+    labels = (torch.arange(B) * 37) % 1000
+    times = []
+    fwd = lambda t, y, d: O.lfq_bert_forward(gsd, gcfg, t, y, d)
+
+    def timed_fwd(t, y, d):
+        t0 = time.perf_counter()
+        out = fwd(t, y, d)
+        times.append(time.perf_counter() - t0)
+        return out
+
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    preds = O.sample_loop(timed_fwd, B, labels, num_steps=3, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0,
+                          randomize_temperature=8.2, mask_schedule_strategy="arccos", mask_token=64, codebook_splits=2)
+    loop_s = time.perf_counter() - t0
+    step_s = (loop_s - times[0] - (loop_s - sum(times)) / 3) / 2          # 2 timed steps: forward + that step's sampling tail
+    codes = O.combine_groups(preds[-1], 12, 2)
+    t0 = time.perf_counter()
+    O.decode_tokens(tsd, tcfg, codes)
+    dec_s = time.perf_counter() - t0
+    ips = 1.0 / (NUM_STEPS * step_s / B + dec_s / B)
+    return {"value": ips, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 port, parity-pinned to the reference): mean of 2 full CFG steps at B={B} "
+                      f"({step_s:.2f} s/step) + decode of {B} images ({dec_s:.2f} s), extrapolated to 64 steps",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU per step (default: the C3 batch, 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from maskbit_amd import ConvVQModel, LFQBert, _lib
+    from maskbit_amd.parallel import gather_images
+    from maskbit_amd.sampling import build_plan, draw_noise, run_loop
+
+    B = args.batch
+    gen = LFQBert(**GEN)
+    tok = ConvVQModel(tok_config())
+    seeded_fill(gen, 100)
+    seeded_fill(tok, 200)
+    gen = gen.eval().requires_grad_(False).to(dev)
+    tok = tok.eval().requires_grad_(False).to(dev)
+    torch.manual_seed(1234 + rank)
+    plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
+                      SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])
+
+    def one_batch(i: int):
+        labels = ((torch.arange(B) + (rank * B + i * world * B)) * 37 % 1000).to(dev)
+        exp_noise, conf_noise = draw_noise(B, 256, 2, 64, NUM_STEPS, SAMPLER["randomize_temperature"], dev)
+        _, u8, _, _ = run_loop(gen, tok, labels, plan, exp_noise, conf_noise, want_steps=False, want_image=False, want_u8=True)
+        return gather_images(u8) if world > 1 else u8
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_batch(i)
+    fence()
+    if not args.no_prof:
+        _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_batch(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = {}
+    if not args.no_prof:
+        prof = _lib.prof_read()
+        _lib.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape[0] == B * world and out.dtype == torch.uint8
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        value = total_images / elapsed
+        M = 2 * B * 257
+        gemm_flops = {"gemm_qkv": 2.0 * M * 3072 * 1024, "gemm_attn_out": 2.0 * M * 1024 * 1024,
+                      "gemm_ffn_up": 2.0 * M * 4096 * 1024, "gemm_ffn_down": 2.0 * M * 1024 * 4096}
+        kernels = {k: {"calls": c, "avg_us": ms / c * 1e3, "total_ms": ms} for k, (c, ms) in prof.items()}
+        roofline = None
+        if prof:
+            dom = max(gemm_flops, key=lambda k: prof.get(k, (0, 0.0))[1])
+            calls, ms = prof[dom]
+            achieved = gemm_flops[dom] / (ms / calls * 1e-3) / 1e12
+            fam_flops = sum(gemm_flops[k] * prof[k][0] for k in gemm_flops if k in prof)
+            fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
+            roofline = {"bound": "mfma", "kernel": f"gemm_tn_kernel ({dom}: M={M}, N={4096 if dom == 'gemm_ffn_up' else (3072 if dom == 'gemm_qkv' else 1024)}, "
+                                                   f"K={4096 if dom == 'gemm_ffn_down' else 1024})",
+                        "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                        "traffic": None, "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
+                        "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
+                        "end_to_end_frac": value / world * (2 * NUM_STEPS * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        line = {
+            "metric": "images/sec (256x256, 64-step MaskBit-12bit, CFG)", "value": value, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] (C3): MaskBit-Generator 12-bit, 64 steps, CFG 7.1 cosine, arccos schedule, "
+                                   f"batch {B}/GPU, conv_vqgan decode to 256x256 uint8" + (", RCCL all-gather of images" if world > 1 else ""),
+                       "global_batch": B * world, "parallelism": f"dp{world} (batch shards, one process per GPU)"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+/* libmaskbit_hip.so -- C ABI of the MI355X-native MaskBit sampling engine.
+ *
+ * The reference (markweberdev/maskbit) has no FFI / plugin layer: its hot path sits behind a
+ * Python call surface.  This header is therefore the *new* boundary beneath the Python classes
+ * that mirror that surface (maskbit_amd.LFQBert / ConvVQModel / sample); every entry point cites
+ * the reference code it replaces (paths relative to the reference root).  Plain pointers and
+ * sizes only -- no torch types.  All pointers are DEVICE pointers unless noted; `stream` is a
+ * hipStream_t passed as void*.  Calls are stream-ordered, never synchronise the device and never
+ * touch the default stream.  Return value: 0 on success, negative on error (message through
+ * mb_last_error(), thread-local).  A handle is bound to the device that was current at create
+ * time and is not thread-safe (the reference is single-threaded Python on one device,
+ * scripts/eval_maskbit.py:65).
+ */
+#ifndef MASKBIT_HIP_H
+#define MASKBIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MB_ABI_VERSION 1
+
+typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
+typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
+typedef void* mb_stream;      /* hipStream_t                                              */
+
+/* LFQBert constructor arguments (modeling/bert.py:345-358). */
+typedef struct {
+  int bits;    /* K = log2(codebook_size)          */
+  int splits;  /* m = codebook_splits              */
+  int hidden;  /* hidden_dim (multiple of 64)      */
+  int heads;   /* heads; hidden/heads in {32,64}   */
+  int depth;   /* transformer layers               */
+  int mlp;     /* mlp_dim (multiple of 64)         */
+  int seq;     /* (img_size/input_stride)^2 = 256  */
+  int nclass;  /* 1000; row nclass = "dropped"     */
+} mb_gen_cfg;
+
+/* ConvDecoder configuration (modeling/modules/autoencoder.py:358-397, configs/tokenizer yaml files). */
+typedef struct {
+  int token_size;      /* K bits per token = conv_in input channels */
+  int hidden_channels; /* 128                                       */
+  int num_resolutions; /* 5                                         */
+  int num_res_blocks;  /* 2                                         */
+  int num_channels;    /* 3                                         */
+  int channel_mult[8]; /* [1,1,2,2,4]                               */
+  int latent_size;     /* token grid side: 16 (=> 256x256 output)   */
+} mb_dec_cfg;
+
+/* Per-step plan of modeling.modules.sample (modeling/modules/sampling.py:81-124), evaluated on the
+ * host exactly as the reference does (float32 torch scalars) and handed over as HOST arrays. */
+typedef struct {
+  int num_steps;
+  int use_guidance;            /* guidance_scale != 0 => 2B sequences per step (sampling.py:83-88) */
+  const float* scale;          /* [num_steps] guidance_scale * a_i (sampling.py:91-98)            */
+  const float* temperature;    /* [num_steps] softmax temperature (sampling.py:103-105)           */
+  const int* mask_len;         /* [num_steps] floor(mask_ratio * n*m) (sampling.py:120-123)       */
+} mb_sample_plan;
+
+int mb_abi_version(void);
+const char* mb_last_error(void);
+
+/* ---- generator: LFQBert.forward, modeling/bert.py:456-508 --------------------------------- */
+int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out);
+void mb_gen_destroy(mb_gen* g);
+/* One call per checkpoint entry (key names of SURVEY.md 8b / BaseModel.load_pretrained,
+ * modeling/modules/base_model.py:87-141).  `data` is a device fp32 tensor in the checkpoint's
+ * own layout; GEMM weights are repacked to bf16 here.  Unknown names return -2. */
+int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream);
+/* tokens int64 [nb,seq,m] (value C = masked), labels int64 [nb], drop uint8 [nb] (1 => label
+ * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */
+int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop,
+                   float* logits, int nb, mb_stream stream);
+
+/* ---- one sampling step after the forward: sampling.py:90-131 ------------------------------ *
+ * logits_u NULL => no guidance.  `scale` = guidance_scale * a_i (sampling.py:91-98), `temperature`
+ * the softmax temperature of this step.  exp_noise [B*n*m, C] is the Exp(1) draw of
+ * torch.multinomial; conf_noise [B,n,m] is gumbel*randomize_temperature*(1-progress).
+ * k_mask_len = floor(ratio * n*m) (masking.py:41-65, sampling.py:120-123); the clamp to
+ * [1, num_masked(sample 0) - 1] happens on the device.  tokens_in / tokens_out [B,n,m] must not
+ * alias; pred_out (may be NULL) receives the step's predicted tokens (l_full_tokens entry). */
+int mb_sample_step(const float* logits_c, const float* logits_u, float scale, float temperature,
+                   const float* exp_noise, const float* conf_noise, int k_mask_len,
+                   const int64_t* tokens_in, int64_t* tokens_out, int64_t* pred_out,
+                   int B, int n, int m, int C, mb_stream stream);
+
+/* ---- decoder: ConvVQModel.decode_tokens, modeling/conv_vqgan.py:98-112 --------------------- */
+int mb_dec_create(const mb_dec_cfg* cfg, int max_batch, mb_dec** out);
+void mb_dec_destroy(mb_dec* d);
+int mb_dec_load(mb_dec* d, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream);
+/* tokens int64 [B, n] (K-bit codes) -> img_nchw fp32 [B,3,H,W] unclamped (may be NULL) and/or
+ * img_nhwc_u8 uint8 [B,H,W,3] = trunc(clamp(x,0,1)*255) (scripts/eval_maskbit.py:134-135; may be NULL). */
+int mb_dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_nhwc_u8, int B, mb_stream stream);
+
+/* ---- whole loop: modeling.modules.sample, sampling.py:55-136 ------------------------------- *
+ * Runs num_steps x (forward [+CFG], step) then combine (factorization.py:7-24) + decode.
+ * exp_noise [steps, B*n*m, C] and conf_noise [steps, B, n, m] (= gumbel * randomize_temperature *
+ * (1-progress)) are drawn by the caller with the reference's RNG protocol.  step_tokens int64
+ * [steps,B,n,m] may be NULL.  tokens_out int64 [B,n] receives the combined K-bit codes (may be
+ * NULL).  d may be NULL (then both image pointers must be NULL). */
+int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* labels, int B,
+              const float* exp_noise, const float* conf_noise, int64_t* step_tokens, int64_t* tokens_out,
+              float* img_nchw, uint8_t* img_nhwc_u8, mb_stream stream);
+
+/* ---- introspection used by bench.py (not part of the reference surface) -------------------- */
+/* Name + accumulated device time (HIP events on the launch stream) of the engine's kernels. */
+int mb_prof_enable(int on);
+int mb_prof_read(char* buf, int buflen); /* host buffer; writes "name calls total_ms\n" lines */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKBIT_HIP_H */

@@ -1,0 +1,127 @@
+"""MaskBit generator (LFQBert) backed by the gfx950 engine.
+
+Call surface of the reference's ``modeling.bert.LFQBert`` (bert.py:344-508): same constructor
+keywords, same checkpoint keys, ``model(img_tokens, class_labels, drop_label_mask)
+-> logits [b, seq, m, C]`` float32.  The forward itself is ``mb_gen_forward`` in
+libmaskbit_hip.so: fused bit-token embed + LayerNorm, 24 x (bf16 MFMA QKV GEMM, LDS-resident
+attention, out-proj GEMM + residual, LayerNorm, FFN GEMMs with fused erf-GELU / residual), head.
+Only the post-norm variant (``use_prenorm=False``, every shipped config) is implemented.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from .base_model import BaseModel, ParamSpec
+
+
+def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int) -> List[ParamSpec]:
+    s: List[ParamSpec] = [
+        ("pos_emb", (1, seq + 1, d), "normal"),
+        ("class_emb.weight", (nclass + 1, d), "normal"),
+        ("input_proj.weight", (d, bits), "normal"), ("input_proj.bias", (d,), "zeros"),
+        ("first_layer.0.weight", (d,), "ones"), ("first_layer.0.bias", (d,), "zeros"),
+    ]
+    for l in range(depth):
+        a, m = f"transformer.layers.{l}.0", f"transformer.layers.{l}.1"
+        s += [(a + ".mha.in_proj_weight", (3 * d, d), "normal"), (a + ".mha.in_proj_bias", (3 * d,), "zeros"),
+              (a + ".mha.out_proj.weight", (d, d), "normal"), (a + ".mha.out_proj.bias", (d,), "zeros"),
+              (a + ".norm.weight", (d,), "ones"), (a + ".norm.bias", (d,), "zeros"),
+              (m + ".net.0.weight", (f, d), "normal"), (m + ".net.0.bias", (f,), "zeros"),
+              (m + ".net.2.weight", (d, f), "normal"), (m + ".net.2.bias", (d,), "zeros"),
+              (m + ".norm.weight", (d,), "ones"), (m + ".norm.bias", (d,), "zeros")]
+    s += [("last_layer.0.weight", (d, d), "normal"), ("last_layer.0.bias", (d,), "zeros"),
+          ("last_layer.2.weight", (d,), "ones"), ("last_layer.2.bias", (d,), "zeros"),
+          ("prediction_layer.weight", (out, d), "normal"), ("prediction_layer.bias", (out,), "zeros")]
+    return s
+
+
+class LFQBert(BaseModel):
+    def __init__(self, img_size=256, hidden_dim=768, codebook_size=1024, codebook_splits=1, depth=24, heads=8,
+                 mlp_dim=3072, dropout=0.1, nclass=1000, input_stride: int = 16, use_prenorm: bool = False):
+        super().__init__()
+        if use_prenorm:
+            raise NotImplementedError("LFQBert(use_prenorm=True) is not implemented by the HIP engine "
+                                      "(no shipped MaskBit config uses it; SURVEY.md 8f next-3)")
+        self.nclass = nclass
+        self.drop_label = nclass
+        self.seq_len = (img_size // input_stride) ** 2
+        self.splits = codebook_splits
+        self.bits = int(math.log2(codebook_size))
+        if self.bits % self.splits:
+            raise ValueError(f"log2(codebook_size)={self.bits} is not divisible by codebook_splits={self.splits}")
+        group_bits = self.bits // self.splits
+        self.effective_codebook_size = 2 ** group_bits
+        self.mask_token = self.effective_codebook_size
+        self.hidden_dim, self.depth, self.heads, self.mlp_dim = hidden_dim, depth, heads, mlp_dim
+        self.dropout = dropout            # inference only: dropout is the identity in eval mode
+        self.use_prenorm = False
+        self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
+        self._build(_generator_specs(hidden_dim, mlp_dim, depth, self.seq_len, self.bits, nclass,
+                                     self.splits * self.effective_codebook_size))
+
+    def get_group_splits(self) -> int:
+        return self.splits
+
+    # ---- engine hooks ---------------------------------------------------------------------
+    def _engine_create(self, capacity: int):
+        cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass)
+        h = C.c_void_p()
+        _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
+        return h
+
+    def _engine_destroy(self, h) -> None:
+        _lib.load().mb_gen_destroy(h)
+
+    def _engine_load(self, h, key: str, t: torch.Tensor, stream: int) -> None:
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _lib.check(_lib.load().mb_gen_load(h, key.encode(), t.data_ptr(), shape, t.dim(), stream), f"mb_gen_load({key})")
+
+    def engine(self, min_seqs: int):
+        """Device engine able to hold ``min_seqs`` sequences (CFG needs 2 x batch)."""
+        have = self._engine_key[1] if self._engine_key else 0
+        return self._ensure_engine(max(min_seqs, have, 16))
+
+    def _check_labels(self, labels: torch.Tensor) -> None:
+        """Host-resident labels are range-checked here (an out-of-range class would index past class_emb, where the
+        reference raises an IndexError); device-resident labels are clamped inside the kernel instead of forcing a sync."""
+        if labels.device.type == "cpu" and labels.numel() and (int(labels.min()) < 0 or int(labels.max()) > self.nclass):
+            raise IndexError(f"class label outside [0, {self.nclass}]")
+
+    # ---- forward ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, img_tokens: torch.Tensor, class_labels: torch.Tensor,
+                drop_label_mask: Optional[torch.Tensor] = None, return_attn: bool = False) -> torch.Tensor:
+        if return_attn:
+            raise NotImplementedError("return_attn=True (attention maps) is not produced by the fused HIP attention kernel")
+        dev = self._require_cuda("forward")
+        if img_tokens.dim() != 3 or img_tokens.shape[1] != self.seq_len or img_tokens.shape[2] != self.splits:
+            raise ValueError(f"img_tokens must be [b, {self.seq_len}, {self.splits}], got {tuple(img_tokens.shape)}")
+        b = img_tokens.shape[0]
+        if class_labels.numel() != b:
+            raise ValueError(f"class_labels must hold {b} labels, got {tuple(class_labels.shape)}")
+        self._check_labels(class_labels)
+        toks = img_tokens.to(device=dev, dtype=torch.int64).contiguous()
+        labs = class_labels.to(device=dev, dtype=torch.int64).reshape(b).contiguous()     # never mutated (cf. bert.py:482-484)
+        drop = None
+        if drop_label_mask is not None:
+            drop = drop_label_mask.to(device=dev).reshape(b).to(torch.uint8).contiguous()
+        logits = torch.empty((b, self.seq_len, self.splits, self.effective_codebook_size), dtype=torch.float32, device=dev)
+        h = self.engine(b)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mb_gen_forward(h, toks.data_ptr(), labs.data_ptr(), drop.data_ptr() if drop is not None else None,
+                                                  logits.data_ptr(), b, torch.cuda.current_stream().cuda_stream), "mb_gen_forward")
+        return logits
+
+
+class Bert(BaseModel):
+    """The embedding-table generator (reference bert.py:184-340).  No shipped MaskBit config selects it
+    (all use ``model_cls: lfq_bert``); it is importable for ``scripts/eval_maskbit.py`` but not built yet."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("modeling.bert.Bert (model_cls='bert') is not implemented by the HIP engine yet (SURVEY.md 8f next-3)")

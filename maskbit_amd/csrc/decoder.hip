@@ -1,0 +1,485 @@
+// conv-VQGAN decoder (ConvDecoder.forward, modeling/modules/autoencoder.py:399-423) as NHWC h16
+// implicit-GEMM convolutions on MFMA.
+//
+// Layout: every activation is [B, H, W, C] h16 (channels contiguous = the MFMA k order), weights
+// are repacked once to [tap][Cout_pad][Cin_pad] h16.  One workgroup computes an 8x16-pixel output
+// tile for 128 (or 16) output channels; for each 64-channel input chunk the (8+2)x(16+2) halo tile
+// is staged ONCE into LDS and re-used by all 9 taps (a tap is just a shifted LDS row index), while
+// the per-tap weight tiles stream in by LDS-DMA, double-buffered, exactly like the GEMM's W tile.
+// Fusions:  GroupNorm-apply + SiLU happen on the way into LDS (per-(image,channel) scale/shift
+// from the stats pass), nearest-2x upsampling is an index shift (>>1) of the source pixel, bias /
+// residual add live in the epilogue, and the last conv writes fp32 NCHW and/or clamp*255 uint8 NHWC.
+// GroupNorm statistics (32 groups, eps 1e-6, autoencoder.py:39-43) are a deterministic two-level
+// reduction (no float atomics), so outputs are bit-stable run to run.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mb_decoder.h"
+#include "mb_kernels.h"
+
+namespace mb {
+
+constexpr int TH = 8, TW = 16;           // output pixel tile
+constexpr int CK = 64;                   // input-channel chunk = one 128-byte LDS row
+
+struct ConvArgs {
+  const h16* in;        // [B, Hin, Win, Cin] (Hin = H/2 when UP)
+  const float2* gn;      // [B, Cin] (scale, shift) or null
+  const h16* w;         // [taps][Cout_pad][Cin]
+  const float* bias;     // [Cout_pad] or null
+  const h16* residual;  // [B, H, W, Cout] or null
+  h16* out;             // [B, H, W, Cout]
+  float* img_nchw;       // final conv only
+  uint8_t* img_u8;       // final conv only
+  int B, H, W, Cin, Cout, Cout_pad;
+};
+
+__device__ __forceinline__ float silu(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+
+template <int NI, int WN, int KS, bool UP, bool FINAL>
+__global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
+  constexpr int WM = 4 / WN, MJ = TH / WM, BN = WN * NI * 16;
+  constexpr int PAD = KS / 2, HW_ = TW + 2 * PAD, HALO = (TH + 2 * PAD) * HW_, NTAP = KS * KS;
+  constexpr int WT_BYTES = BN * 128;
+  __shared__ __attribute__((aligned(16))) char smem[HALO * 128 + 2 * WT_BYTES];
+  char* halo = smem;
+  char* wt = smem + HALO * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int ntn = a.Cout_pad / BN, ntx = a.W / TW, nty = a.H / TH;
+  int bid = blockIdx.x;
+  const int tn = bid % ntn; bid /= ntn;
+  const int tx = bid % ntx; bid /= ntx;
+  const int ty = bid % nty; const int b = bid / nty;
+  const int n0 = tn * BN, y0 = ty * TH, x0 = tx * TW;
+  const int Cin = a.Cin;
+  const int Hin = UP ? a.H / 2 : a.H, Win = UP ? a.W / 2 : a.W;
+
+  // ---- weight-tile DMA: BN rows of 128 B; a wave instruction covers 8 rows
+  constexpr int WROWS_PER_WAVE = BN / 4;            // 32 or 4
+  constexpr int WINST = (WROWS_PER_WAVE + 7) / 8;   // 4 or 1
+  const h16* wsrc[WINST];
+#pragma unroll
+  for (int j = 0; j < WINST; ++j) {
+    int row = wave * WROWS_PER_WAVE + j * 8 + (lane >> 3);
+    if (WROWS_PER_WAVE < 8) row = min(row, BN - 1);
+    wsrc[j] = a.w + (size_t)(n0 + row) * Cin + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  auto stage_w = [&](int t, int buf) {
+    const int chunk = t / NTAP, tap = t - chunk * NTAP;
+    const size_t off = (size_t)tap * a.Cout_pad * Cin + chunk * CK;
+    if (WROWS_PER_WAVE >= 8) {
+#pragma unroll
+      for (int j = 0; j < WINST; ++j)
+        MB_GLDS16(wsrc[j] + off, wt + buf * WT_BYTES + (wave * WROWS_PER_WAVE + j * 8) * 128);
+    } else if (wave < 2) {                           // BN = 16: two 8-row instructions in total
+      const int row = wave * 8 + (lane >> 3);
+      const h16* src = a.w + (size_t)(n0 + row) * Cin + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+      MB_GLDS16(src + off, wt + buf * WT_BYTES + wave * 8 * 128);
+    }
+  };
+
+  // ---- halo staging through registers (GN-apply + SiLU + zero padding)
+  const int myslot = tid & 7;
+  auto stage_halo = [&](int chunk) {
+    const int c0 = chunk * CK + myslot * 8;
+    float sc[8], sh[8];
+    if (a.gn) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float2 v = a.gn[(size_t)b * Cin + c0 + e]; sc[e] = v.x; sh[e] = v.y; }
+    }
+    for (int hp = tid >> 3; hp < HALO; hp += 32) {
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int Y = y0 - PAD + hy, X = x0 - PAD + hx;
+      h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
+        const int sy = UP ? (Y >> 1) : Y, sx = UP ? (X >> 1) : X;
+        v = *(const h16x8*)(a.in + (((size_t)b * Hin + sy) * Win + sx) * Cin + c0);
+        if (a.gn) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = to_h(silu(fmaf((float)v[e], sc[e], sh[e])));
+        }
+      }
+      *(h16x8*)(halo + hp * 128 + ((myslot ^ ((hp >> 1) & 7)) * 16)) = v;
+    }
+  };
+
+  int wfoff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) wfoff[kk] = l15 * 128 + (((kk * 4 + g) ^ (l15 >> 1)) * 16);
+
+  f32x4 acc[NI][MJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int T = (Cin / CK) * NTAP;
+  stage_w(0, 0);
+  for (int t = 0; t < T; ++t) {
+    const int chunk = t / NTAP, tap = t - chunk * NTAP;
+    if (tap == 0) {
+      __syncthreads();                      // all waves are done with the previous chunk's halo
+      stage_halo(chunk);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                        // weight tile t landed, halo visible
+    if (t + 1 < T) stage_w(t + 1, (t + 1) & 1);
+    const int dy = tap / KS, dx = tap - dy * KS;
+    const char* wb = wt + (t & 1) * WT_BYTES + wn * NI * 16 * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      h16x8 wf[NI], xf[MJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = *(const h16x8*)(wb + i * 16 * 128 + wfoff[kk]);
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        const int hp = (wm * MJ + j + dy) * HW_ + l15 + dx;
+        xf[j] = *(const h16x8*)(halo + hp * 128 + (((kk * 4 + g) ^ ((hp >> 1) & 7)) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+          acc[i][j] = MB_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: lane holds out[pixel (y = wm*MJ+j, x = l15)][cout = ..+g*4 .. +3]
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int Y = y0 + wm * MJ + j, X = x0 + l15;
+    const size_t pix = ((size_t)b * a.H + Y) * a.W + X;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = n0 + wn * NI * 16 + i * 16 + g * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (a.bias) { const float4 bv = *(const float4*)(a.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+      if (FINAL) {
+        if (g == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (r < a.Cout) {
+              if (a.img_nchw) a.img_nchw[(((size_t)b * a.Cout + r) * a.H + Y) * a.W + X] = v[r];
+              if (a.img_u8) a.img_u8[pix * a.Cout + r] = (uint8_t)(fminf(fmaxf(v[r], 0.f), 1.f) * 255.0f);
+            }
+          }
+        }
+      } else if (n < a.Cout) {
+        if (a.residual) {
+          const h16x4 rv = *(const h16x4*)(a.residual + pix * a.Cout + n);
+          v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+        }
+        *(h16x4*)(a.out + pix * a.Cout + n) = h16x4{to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
+      }
+    }
+  }
+}
+
+// ---- GroupNorm statistics: partial (sum, sumsq) per (image, pixel chunk, group) -----------------
+__global__ __launch_bounds__(256) void gn_partial_kernel(const h16* __restrict__ x, float* __restrict__ part, int HW,
+                                                         int C, int nchunk) {
+  __shared__ float red[2][256 * 8];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int nslot = C / 8, npl = 256 / nslot;       // 8-channel slots per pixel, pixel lanes
+  const int slot = tid % nslot, pl = tid / nslot;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  for (int p = p0 + pl; p < p1; p += npl) {
+    const h16x8 v = *(const h16x8*)(x + ((size_t)b * HW + p) * C + slot * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] = fmaf(f, f, q[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][pl * C + slot * 8 + e] = s[e]; red[1][pl * C + slot * 8 + e] = q[e]; }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {               // fixed-order sum over pixel lanes
+    float ts = 0.f, tq = 0.f;
+    for (int l = 0; l < npl; ++l) { ts += red[0][l * C + c]; tq += red[1][l * C + c]; }
+    red[0][c] = ts; red[1][c] = tq;                  // row 0 of the scratch is only read by thread c here
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int cpg = C / 32;
+    float ts = 0.f, tq = 0.f;
+    for (int e = 0; e < cpg; ++e) { ts += red[0][tid * cpg + e]; tq += red[1][tid * cpg + e]; }
+    float* o = part + (((size_t)b * nchunk + chunk) * 32 + tid) * 2;
+    o[0] = ts; o[1] = tq;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float2* __restrict__ out, int HW, int C, int nchunk) {
+  const int b = blockIdx.x;
+  const int cpg = C / 32;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int grp = c / cpg;
+    float ts = 0.f, tq = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* o = part + (((size_t)b * nchunk + k) * 32 + grp) * 2;
+      ts += o[0]; tq += o[1];
+    }
+    const float n = (float)HW * (float)cpg;
+    const float mean = ts / n;
+    const float var = fmaxf(tq / n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + 1e-6f);
+    const float sc = rstd * gamma[c];
+    out[(size_t)b * C + c] = make_float2(sc, beta[c] - mean * sc);
+  }
+}
+
+// ---- tokens -> +-1 latent, NHWC padded to 64 channels (lookup_free.py:96-111, conv_vqgan.py:107-110)
+__global__ void latent_kernel(const int64_t* __restrict__ tokens, h16* __restrict__ z, size_t npix, int K) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * CK; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / CK; const int c = (int)(i - p * CK);
+    float v = 0.f;
+    if (c < K) v = ((tokens[p] >> c) & 1) ? 1.f : -1.f;
+    z[i] = to_h(v);
+  }
+}
+
+// ---- OIHW fp32 -> [tap][Cout_pad][Cin_pad] h16 ---------------------------------------------------
+__global__ void repack_conv_kernel(const float* __restrict__ w, h16* __restrict__ out, int Cout, int Cin, int ks,
+                                   int Cout_pad, int Cin_pad) {
+  const size_t total = (size_t)ks * ks * Cout_pad * Cin_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin_pad); size_t r = i / Cin_pad;
+    const int co = (int)(r % Cout_pad); const int tap = (int)(r / Cout_pad);
+    float v = 0.f;
+    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ks * ks + tap];
+    out[i] = to_h(v);
+  }
+}
+
+// ================================================================================================
+struct Conv {
+  std::string name; int cin = 0, cout = 0, ks = 3; bool has_bias = false, up = false;
+  int cin_pad = 0, cout_pad = 0;
+  h16* w = nullptr; float* b = nullptr;
+};
+struct Norm { std::string name; int c = 0; float *g = nullptr, *b = nullptr; };
+struct ResBlock { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; };
+struct Stage { std::vector<ResBlock> blocks; Conv up; bool has_up = false; };
+
+}  // namespace mb
+
+struct mb_dec {
+  mb_dec_cfg c{};
+  int max_batch = 0, out_res = 0;
+  mb::Conv conv_in, conv_out;
+  mb::Norm norm_out;
+  std::vector<mb::ResBlock> mid;
+  std::vector<mb::Stage> up;
+  h16* buf[3] = {nullptr, nullptr, nullptr};
+  h16* z = nullptr;
+  float* gn_part = nullptr;
+  float2* gn_ss = nullptr;
+  std::vector<void*> owned;
+};
+
+namespace mb {
+
+namespace {
+constexpr int GN_MAXCHUNK = 64;
+
+template <typename T>
+bool dalloc(mb_dec* d, T** p, size_t n, std::string& err) {
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) { err = std::string("hipMalloc failed: ") + hipGetErrorString(e); return false; }
+  d->owned.push_back((void*)*p);
+  return true;
+}
+
+bool init_conv(mb_dec* d, Conv& c, const std::string& name, int cin, int cout, int ks, bool bias, bool up, bool final_,
+               std::string& err) {
+  c.name = name; c.cin = cin; c.cout = cout; c.ks = ks; c.has_bias = bias; c.up = up;
+  c.cin_pad = (cin + CK - 1) / CK * CK;
+  c.cout_pad = final_ ? 16 : (cout + 127) / 128 * 128;
+  if (!dalloc(d, &c.w, (size_t)ks * ks * c.cout_pad * c.cin_pad, err)) return false;
+  if (bias) {
+    if (!dalloc(d, &c.b, (size_t)c.cout_pad, err)) return false;
+    (void)hipMemset(c.b, 0, c.cout_pad * sizeof(float));
+  }
+  return true;
+}
+bool init_norm(mb_dec* d, Norm& n, const std::string& name, int c, std::string& err) {
+  n.name = name; n.c = c;
+  return dalloc(d, &n.g, (size_t)c, err) && dalloc(d, &n.b, (size_t)c, err);
+}
+bool init_block(mb_dec* d, ResBlock& rb, const std::string& p, int cin, int cout, std::string& err) {
+  rb.has_sc = cin != cout;
+  bool ok = init_norm(d, rb.n1, p + ".norm1", cin, err) && init_conv(d, rb.c1, p + ".conv1", cin, cout, 3, false, false, false, err) &&
+            init_norm(d, rb.n2, p + ".norm2", cout, err) && init_conv(d, rb.c2, p + ".conv2", cout, cout, 3, false, false, false, err);
+  if (ok && rb.has_sc) ok = init_conv(d, rb.sc, p + ".nin_shortcut", cout, cout, 1, false, false, false, err);
+  return ok;
+}
+
+void launch_conv(hipStream_t s, const Conv& c, const h16* in, const float2* gn, const h16* residual, h16* out,
+                 float* img, uint8_t* u8, int B, int H, int W, bool final_) {
+  ConvArgs a{in, gn, c.w, c.has_bias ? c.b : nullptr, residual, out, img, u8, B, H, W, c.cin_pad, c.cout, c.cout_pad};
+  const int bn = final_ ? 16 : 128;
+  dim3 grid((unsigned)((size_t)B * (H / TH) * (W / TW) * (c.cout_pad / bn))), block(256);
+  if (final_) hipLaunchKernelGGL((conv_kernel<1, 1, 3, false, true>), grid, block, 0, s, a);
+  else if (c.ks == 1) hipLaunchKernelGGL((conv_kernel<4, 2, 1, false, false>), grid, block, 0, s, a);
+  else if (c.up) hipLaunchKernelGGL((conv_kernel<4, 2, 3, true, false>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv_kernel<4, 2, 3, false, false>), grid, block, 0, s, a);
+}
+
+void launch_gn(hipStream_t s, mb_dec* d, const Norm& n, const h16* x, int B, int HW) {
+  int nchunk = HW / 256; if (nchunk < 1) nchunk = 1; if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, d->gn_part, HW, n.c, nchunk);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, d->gn_part, n.g, n.b, d->gn_ss, HW, n.c, nchunk);
+}
+
+// x (buffer index xi) -> returns the buffer index holding the block output
+int run_block(hipStream_t s, mb_dec* d, const ResBlock& rb, int xi, int B, int H, int W) {
+  const int t1 = (xi + 1) % 3, t2 = (xi + 2) % 3;
+  launch_gn(s, d, rb.n1, d->buf[xi], B, H * W);
+  launch_conv(s, rb.c1, d->buf[xi], d->gn_ss, nullptr, d->buf[t1], nullptr, nullptr, B, H, W, false);
+  launch_gn(s, d, rb.n2, d->buf[t1], B, H * W);
+  if (!rb.has_sc) {
+    launch_conv(s, rb.c2, d->buf[t1], d->gn_ss, d->buf[xi], d->buf[t2], nullptr, nullptr, B, H, W, false);
+    return t2;
+  }
+  // shortcut quirk (autoencoder.py:72-73,93-96): out = h + nin_shortcut(h); the block input is dropped
+  launch_conv(s, rb.c2, d->buf[t1], d->gn_ss, nullptr, d->buf[t2], nullptr, nullptr, B, H, W, false);
+  launch_conv(s, rb.sc, d->buf[t2], nullptr, d->buf[t2], d->buf[t1], nullptr, nullptr, B, H, W, false);
+  return t1;
+}
+
+bool find_conv(Conv& c, const std::string& n, Conv** hit, bool* is_bias) {
+  if (n == c.name + ".weight") { *hit = &c; *is_bias = false; return true; }
+  if (n == c.name + ".bias" && c.has_bias) { *hit = &c; *is_bias = true; return true; }
+  return false;
+}
+bool find_norm(Norm& nm, const std::string& n, float** dst) {
+  if (n == nm.name + ".weight") { *dst = nm.g; return true; }
+  if (n == nm.name + ".bias") { *dst = nm.b; return true; }
+  return false;
+}
+}  // namespace
+
+mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
+  const int R = cfg.num_resolutions;
+  if (R < 1 || R > 7) { err = "num_resolutions out of range"; return nullptr; }
+  if (cfg.hidden_channels % 64) { err = "hidden_channels must be a multiple of 64 for the HIP decoder"; return nullptr; }
+  if (cfg.token_size > CK || cfg.token_size < 1) { err = "token_size must be in [1, 64]"; return nullptr; }
+  if (cfg.latent_size % 16) { err = "latent_size must be a multiple of 16"; return nullptr; }
+  if (cfg.num_channels > 4) { err = "num_channels > 4 unsupported"; return nullptr; }
+  mb_dec* d = new mb_dec();
+  d->c = cfg; d->max_batch = max_batch; d->out_res = cfg.latent_size << (R - 1);
+  const int hc = cfg.hidden_channels;
+  std::vector<int> mult(cfg.channel_mult, cfg.channel_mult + R);
+  mult.push_back(cfg.channel_mult[R - 1]);
+  const int top = hc * cfg.channel_mult[R - 1];
+  bool ok = init_conv(d, d->conv_in, "decoder.conv_in", cfg.token_size, top, 3, true, false, false, err);
+  d->mid.resize(cfg.num_res_blocks);
+  for (int r = 0; ok && r < cfg.num_res_blocks; ++r)
+    ok = init_block(d, d->mid[r], "decoder.mid.res_blocks." + std::to_string(r), top, top, err);
+  d->up.resize(R);
+  int last = top;
+  size_t max_elems = 0;
+  int res = cfg.latent_size;
+  max_elems = (size_t)res * res * top;
+  for (int s = 0; ok && s < R; ++s) {                    // up.0 = coarsest level (autoencoder.py:384-392)
+    const int lvl = R - 1 - s;
+    const int cin = hc * mult[lvl + 1], cout = hc * mult[lvl];
+    Stage& st = d->up[s];
+    st.blocks.resize(cfg.num_res_blocks);
+    int c = cin;
+    for (int r = 0; ok && r < cfg.num_res_blocks; ++r) {
+      ok = init_block(d, st.blocks[r], "decoder.up." + std::to_string(s) + ".res_blocks." + std::to_string(r), c, cout, err);
+      c = cout;
+    }
+    max_elems = std::max(max_elems, (size_t)res * res * std::max(cin, cout));
+    st.has_up = lvl > 0;
+    if (ok && st.has_up) {
+      ok = init_conv(d, st.up, "decoder.up." + std::to_string(s) + ".upsample_conv", cout, cout, 3, true, true, false, err);
+      res *= 2;
+      max_elems = std::max(max_elems, (size_t)res * res * cout);
+    }
+    last = cout;
+  }
+  ok = ok && init_norm(d, d->norm_out, "decoder.norm_out", last, err) &&
+       init_conv(d, d->conv_out, "decoder.conv_out", last, cfg.num_channels, 3, true, false, true, err);
+  for (int i = 0; ok && i < 3; ++i) ok = dalloc(d, &d->buf[i], (size_t)max_batch * max_elems, err);
+  ok = ok && dalloc(d, &d->z, (size_t)max_batch * cfg.latent_size * cfg.latent_size * CK, err) &&
+       dalloc(d, &d->gn_part, (size_t)max_batch * GN_MAXCHUNK * 64, err) && dalloc(d, &d->gn_ss, (size_t)max_batch * 4096, err);
+  if (!ok) { dec_destroy(d); return nullptr; }
+  return d;
+}
+
+void dec_destroy(mb_dec* d) {
+  if (!d) return;
+  for (void* p : d->owned) (void)hipFree(p);
+  delete d;
+}
+
+int dec_load(mb_dec* d, const char* name, const float* data, const int64_t* shape, int ndim, hipStream_t s, std::string& err) {
+  const std::string n(name);
+  if (n.rfind("encoder.", 0) == 0 || n.rfind("quantize.", 0) == 0) return 0;   // encode half / derived buffers: not on this path
+  size_t numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+  std::vector<Conv*> convs{&d->conv_in, &d->conv_out};
+  std::vector<Norm*> norms{&d->norm_out};
+  auto add_block = [&](ResBlock& rb) {
+    convs.push_back(&rb.c1); convs.push_back(&rb.c2); if (rb.has_sc) convs.push_back(&rb.sc);
+    norms.push_back(&rb.n1); norms.push_back(&rb.n2);
+  };
+  for (auto& rb : d->mid) add_block(rb);
+  for (auto& st : d->up) { for (auto& rb : st.blocks) add_block(rb); if (st.has_up) convs.push_back(&st.up); }
+  for (Conv* c : convs) {
+    Conv* hit = nullptr; bool is_bias = false;
+    if (!find_conv(*c, n, &hit, &is_bias)) continue;
+    if (is_bias) {
+      if (numel != (size_t)c->cout) { err = n + ": wrong bias size"; return -4; }
+      if (hipMemcpyAsync(c->b, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) { err = "copy failed"; return -10; }
+    } else {
+      if (numel != (size_t)c->cout * c->cin * c->ks * c->ks) { err = n + ": wrong weight size"; return -4; }
+      hipLaunchKernelGGL(repack_conv_kernel, dim3(512), dim3(256), 0, s, data, c->w, c->cout, c->cin, c->ks, c->cout_pad, c->cin_pad);
+    }
+    return 0;
+  }
+  for (Norm* nm : norms) {
+    float* dst = nullptr;
+    if (!find_norm(*nm, n, &dst)) continue;
+    if (numel != (size_t)nm->c) { err = n + ": wrong norm size"; return -4; }
+    if (hipMemcpyAsync(dst, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) { err = "copy failed"; return -10; }
+    return 0;
+  }
+  err = "unknown checkpoint entry '" + n + "'";
+  return -2;
+}
+
+int dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_nhwc_u8, int B, hipStream_t s, std::string& err) {
+  if (B <= 0 || B > d->max_batch) { err = "batch outside [1, max_batch]"; return -1; }
+  const mb_dec_cfg& c = d->c;
+  int res = c.latent_size;
+  const size_t npix = (size_t)B * res * res;
+  hipLaunchKernelGGL(latent_kernel, dim3((unsigned)std::min<size_t>(2048, (npix * CK + 255) / 256)), dim3(256), 0, s,
+                     tokens, d->z, npix, c.token_size);
+  launch_conv(s, d->conv_in, d->z, nullptr, nullptr, d->buf[0], nullptr, nullptr, B, res, res, false);
+  int xi = 0;
+  for (auto& rb : d->mid) xi = run_block(s, d, rb, xi, B, res, res);
+  for (auto& st : d->up) {
+    for (auto& rb : st.blocks) xi = run_block(s, d, rb, xi, B, res, res);
+    if (st.has_up) {
+      res *= 2;
+      const int t = (xi + 1) % 3;
+      launch_conv(s, st.up, d->buf[xi], nullptr, nullptr, d->buf[t], nullptr, nullptr, B, res, res, false);
+      xi = t;
+    }
+  }
+  launch_gn(s, d, d->norm_out, d->buf[xi], B, res * res);
+  launch_conv(s, d->conv_out, d->buf[xi], d->gn_ss, nullptr, nullptr, img_nchw, img_nhwc_u8, B, res, res, true);
+  return 0;
+}
+
+}  // namespace mb

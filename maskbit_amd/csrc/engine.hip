@@ -1,0 +1,393 @@
+// C ABI of libmaskbit_hip.so (include/maskbit_hip.h): handle objects, checkpoint ingest with h16
+// repack, the generator forward schedule, the fused sampling step and the whole sampling loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/maskbit_hip.h"
+#include "mb_decoder.h"
+#include "mb_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(-10, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+
+// ---- optional per-kernel device timing with HIP events on the launch stream ------------------
+struct Prof {
+  bool on = false;
+  struct Rec { hipEvent_t a, b; int kind; };
+  std::vector<Rec> recs;
+  std::vector<std::string> names;
+  std::map<std::string, int> index;
+  std::map<int, std::pair<long, double>> acc;   // kind -> (calls, ms)
+  int kind(const char* n) {
+    auto it = index.find(n);
+    if (it != index.end()) return it->second;
+    names.push_back(n);
+    return index[n] = (int)names.size() - 1;
+  }
+  void drain() {
+    for (auto& r : recs) {
+      float ms = 0.f;
+      if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        acc[r.kind].first += 1; acc[r.kind].second += ms;
+      }
+      (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    recs.clear();
+  }
+} g_prof;
+
+struct ProfScope {
+  hipStream_t s; bool live; hipEvent_t a, b; int kind;
+  ProfScope(const char* name, hipStream_t st) : s(st), live(g_prof.on) {
+    if (!live) return;
+    kind = g_prof.kind(name);
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (!live) return;
+    (void)hipEventRecord(b, s);
+    g_prof.recs.push_back({a, b, kind});
+  }
+};
+
+template <typename T>
+int dev_alloc(T** p, size_t n) {
+  HIP_TRY(hipMalloc((void**)p, n * sizeof(T)));
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// generator
+// ================================================================================================
+struct mb_gen {
+  mb_gen_cfg c{};
+  int max_seqs = 0, N = 0, C = 0, gbits = 0, device = 0;
+  struct Layer {
+    h16 *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+  };
+  std::vector<Layer> layers;
+  float *w_in = nullptr, *b_in = nullptr, *class_emb = nullptr, *pos = nullptr, *ln0g = nullptr, *ln0b = nullptr;
+  h16 *wl = nullptr, *wp = nullptr;
+  float *bl = nullptr, *lnhg = nullptr, *lnhb = nullptr, *bp = nullptr;
+  // workspace
+  float *x_f32 = nullptr, *y_f32 = nullptr;
+  h16 *x_h16 = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;
+  // loop state for mb_sample
+  int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
+  uint8_t* drop_cfg = nullptr;
+  float* logits = nullptr;
+  std::vector<void*> owned;
+  int loaded = 0;
+};
+
+namespace {
+
+template <typename T>
+int galloc(mb_gen* g, T** p, size_t n) {
+  int rc = dev_alloc(p, n);
+  if (rc == 0) g->owned.push_back((void*)*p);
+  return rc;
+}
+
+int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits,
+                     int nb, hipStream_t s) {
+  using namespace mb;
+  const mb_gen_cfg& c = g->c;
+  const int d = c.hidden, f = c.mlp, N = g->N, M = nb * N;
+  {
+    ProfScope p("embed_ln", s);
+    EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
+                g->x_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass};
+    embed_ln(s, e);
+  }
+  for (int l = 0; l < c.depth; ++l) {
+    const mb_gen::Layer& L = g->layers[l];
+    { ProfScope p("gemm_qkv", s);
+      gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d, 0}); }
+    { ProfScope p("attention", s); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+    { ProfScope p("gemm_attn_out", s);
+      gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->x_f32, g->y_f32, nullptr, M, d, d, 0}); }
+    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_f32, g->x_h16, M, d); }
+    { ProfScope p("gemm_ffn_up", s);
+      gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d, 0}); }
+    { ProfScope p("gemm_ffn_down", s);
+      gemm_tn(s, EPI_RES_F32, GemmArgs{g->h, L.w2, L.b2, g->x_f32, g->y_f32, nullptr, M, d, f, 0}); }
+    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_f32, g->x_h16, M, d); }
+  }
+  { ProfScope p("gemm_head", s);
+    gemm_tn(s, EPI_GELU_F32, GemmArgs{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d, 0}); }
+  { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, M, d); }
+  { ProfScope p("gemm_head", s);
+    gemm_tn(s, EPI_LOGITS_F32, GemmArgs{g->x_h16, g->wp, g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d, N}); }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mb_abi_version(void) { return MB_ABI_VERSION; }
+const char* mb_last_error(void) { return g_err.c_str(); }
+
+int mb_prof_enable(int on) {
+  if (!on) g_prof.drain();
+  g_prof.on = on != 0;
+  if (on) { g_prof.acc.clear(); }
+  return 0;
+}
+int mb_prof_read(char* buf, int buflen) {
+  g_prof.drain();
+  std::string out;
+  char line[256];
+  for (auto& kv : g_prof.acc) {
+    snprintf(line, sizeof line, "%s %ld %.6f\n", g_prof.names[kv.first].c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if ((int)out.size() + 1 > buflen) return fail(-3, "mb_prof_read: buffer too small (%zu needed)", out.size() + 1);
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int)out.size();
+}
+
+int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
+  if (!cfg || !out || max_seqs <= 0) return fail(-1, "mb_gen_create: bad arguments");
+  const mb_gen_cfg& c = *cfg;
+  if (c.splits <= 0 || c.bits % c.splits) return fail(-1, "bits (%d) must be divisible by splits (%d)", c.bits, c.splits);
+  if (c.bits > 24) return fail(-1, "bits > 24 is not supported");
+  if (c.hidden % 64 || c.mlp % 64) return fail(-1, "hidden (%d) and mlp (%d) must be multiples of 64", c.hidden, c.mlp);
+  if (c.hidden > 2048) return fail(-1, "hidden > 2048 is not supported");
+  const int dh = c.heads > 0 ? c.hidden / c.heads : 0;
+  if (c.heads <= 0 || c.hidden % c.heads || (dh != 32 && dh != 64)) return fail(-1, "hidden/heads must be 32 or 64 (got %d)", dh);
+  if (c.seq + 1 > 288) return fail(-1, "seq+1 = %d tokens exceeds the 288-key attention tile", c.seq + 1);
+  const int C = 1 << (c.bits / c.splits);
+  if (C > 512 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d", C);
+  mb_gen* g = new mb_gen();
+  g->c = c; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
+  (void)hipGetDevice(&g->device);
+  const size_t d = c.hidden, f = c.mlp, M = (size_t)max_seqs * g->N;
+  int rc = 0;
+  g->layers.resize(c.depth);
+  for (auto& L : g->layers) {
+    rc |= galloc(g, &L.wqkv, 3 * d * d); rc |= galloc(g, &L.bqkv, 3 * d);
+    rc |= galloc(g, &L.wo, d * d); rc |= galloc(g, &L.bo, d);
+    rc |= galloc(g, &L.w1, f * d); rc |= galloc(g, &L.b1, f);
+    rc |= galloc(g, &L.w2, d * f); rc |= galloc(g, &L.b2, d);
+    rc |= galloc(g, &L.ln1g, d); rc |= galloc(g, &L.ln1b, d); rc |= galloc(g, &L.ln2g, d); rc |= galloc(g, &L.ln2b, d);
+  }
+  rc |= galloc(g, &g->w_in, d * c.bits); rc |= galloc(g, &g->b_in, d);
+  rc |= galloc(g, &g->class_emb, (size_t)(c.nclass + 1) * d); rc |= galloc(g, &g->pos, (size_t)g->N * d);
+  rc |= galloc(g, &g->ln0g, d); rc |= galloc(g, &g->ln0b, d);
+  rc |= galloc(g, &g->wl, d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
+  rc |= galloc(g, &g->wp, (size_t)c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
+  rc |= galloc(g, &g->x_f32, M * d); rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->x_h16, M * d);
+  rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
+  const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
+  rc |= galloc(g, &g->tok_a, B * P); rc |= galloc(g, &g->tok_b, B * P); rc |= galloc(g, &g->tok_cfg, B * P);
+  rc |= galloc(g, &g->pred, B * P); rc |= galloc(g, &g->codes, B * c.seq);
+  rc |= galloc(g, &g->lab_cfg, B); rc |= galloc(g, &g->drop_cfg, B); rc |= galloc(g, &g->logits, B * P * C);
+  if (rc) { mb_gen_destroy(g); return rc; }
+  *out = g;
+  return 0;
+}
+
+void mb_gen_destroy(mb_gen* g) {
+  if (!g) return;
+  for (void* p : g->owned) (void)hipFree(p);
+  delete g;
+}
+
+int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream) {
+  if (!g || !name || !data) return fail(-1, "mb_gen_load: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const mb_gen_cfg& c = g->c;
+  const size_t d = c.hidden, f = c.mlp;
+  size_t numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+  float* dst_f = nullptr; h16* dst_h = nullptr; size_t want = 0;
+  int l = -1, sub = -1; char rest[96] = {0};
+  std::string n(name);
+  if (sscanf(name, "transformer.layers.%d.%d.%95s", &l, &sub, rest) == 3) {
+    if (l < 0 || l >= c.depth) return fail(-2, "layer index out of range in '%s'", name);
+    mb_gen::Layer& L = g->layers[l];
+    std::string r(rest);
+    if (sub == 0) {
+      if (r == "mha.in_proj_weight") { dst_h = L.wqkv; want = 3 * d * d; }
+      else if (r == "mha.in_proj_bias") { dst_f = L.bqkv; want = 3 * d; }
+      else if (r == "mha.out_proj.weight") { dst_h = L.wo; want = d * d; }
+      else if (r == "mha.out_proj.bias") { dst_f = L.bo; want = d; }
+      else if (r == "norm.weight") { dst_f = L.ln1g; want = d; }
+      else if (r == "norm.bias") { dst_f = L.ln1b; want = d; }
+    } else if (sub == 1) {
+      if (r == "net.0.weight") { dst_h = L.w1; want = f * d; }
+      else if (r == "net.0.bias") { dst_f = L.b1; want = f; }
+      else if (r == "net.2.weight") { dst_h = L.w2; want = d * f; }
+      else if (r == "net.2.bias") { dst_f = L.b2; want = d; }
+      else if (r == "norm.weight") { dst_f = L.ln2g; want = d; }
+      else if (r == "norm.bias") { dst_f = L.ln2b; want = d; }
+    }
+  } else if (n == "pos_emb") { dst_f = g->pos; want = (size_t)g->N * d; }
+  else if (n == "class_emb.weight") { dst_f = g->class_emb; want = (size_t)(c.nclass + 1) * d; }
+  else if (n == "input_proj.weight") { dst_f = g->w_in; want = d * c.bits; }
+  else if (n == "input_proj.bias") { dst_f = g->b_in; want = d; }
+  else if (n == "first_layer.0.weight") { dst_f = g->ln0g; want = d; }
+  else if (n == "first_layer.0.bias") { dst_f = g->ln0b; want = d; }
+  else if (n == "last_layer.0.weight") { dst_h = g->wl; want = d * d; }
+  else if (n == "last_layer.0.bias") { dst_f = g->bl; want = d; }
+  else if (n == "last_layer.2.weight") { dst_f = g->lnhg; want = d; }
+  else if (n == "last_layer.2.bias") { dst_f = g->lnhb; want = d; }
+  else if (n == "prediction_layer.weight") { dst_h = g->wp; want = (size_t)c.splits * g->C * d; }
+  else if (n == "prediction_layer.bias") { dst_f = g->bp; want = (size_t)c.splits * g->C; }
+  else if (n == "bits_to_indices") return 0;   // derived buffer (bert.py:383-384): recomputed on the device
+  if (!dst_f && !dst_h) return fail(-2, "mb_gen_load: unknown checkpoint entry '%s'", name);
+  if (numel != want) return fail(-4, "mb_gen_load: '%s' has %zu elements, expected %zu", name, numel, want);
+  if (dst_f == g->w_in) mb::transpose_f32(s, data, g->w_in, (int)d, c.bits);       // [d,K] -> [K,d] for the embed kernel
+  else if (dst_h) mb::cast_f32_to_h16(s, data, dst_h, numel);
+  else HIP_TRY(hipMemcpyAsync(dst_f, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+  g->loaded++;
+  return 0;
+}
+
+int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits,
+                   int nb, mb_stream stream) {
+  if (!g || !tokens || !labels || !logits) return fail(-1, "mb_gen_forward: null argument");
+  if (nb <= 0 || nb > g->max_seqs) return fail(-1, "mb_gen_forward: nb=%d outside [1, %d]", nb, g->max_seqs);
+  return gen_forward_impl(g, tokens, labels, drop, logits, nb, (hipStream_t)stream);
+}
+
+int mb_sample_step(const float* logits_c, const float* logits_u, float scale, float temperature,
+                   const float* exp_noise, const float* conf_noise, int k_mask_len, const int64_t* tokens_in,
+                   int64_t* tokens_out, int64_t* pred_out, int B, int n, int m, int C, mb_stream stream) {
+  if (!logits_c || !exp_noise || !conf_noise || !tokens_in || !tokens_out) return fail(-1, "mb_sample_step: null argument");
+  if (tokens_in == tokens_out) return fail(-1, "mb_sample_step: tokens_in and tokens_out must not alias");
+  if (B <= 0 || n <= 0 || m <= 0 || C <= 0) return fail(-1, "mb_sample_step: bad sizes");
+  mb::StepArgs a{logits_c, logits_u, scale, temperature, exp_noise, conf_noise, k_mask_len, tokens_out, pred_out, B, n * m, C};
+  ProfScope p("sample_step", (hipStream_t)stream);
+  if (mb::sample_step((hipStream_t)stream, a, tokens_in)) return fail(-1, "mb_sample_step: C=%d or n*m=%d too large", C, n * m);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// decoder handle (kernels in decoder.hip)
+// ================================================================================================
+extern "C" {
+
+int mb_dec_create(const mb_dec_cfg* cfg, int max_batch, mb_dec** out) {
+  if (!cfg || !out || max_batch <= 0) return fail(-1, "mb_dec_create: bad arguments");
+  std::string err;
+  mb_dec* d = mb::dec_create(*cfg, max_batch, err);
+  if (!d) return fail(-1, "mb_dec_create: %s", err.c_str());
+  *out = d;
+  return 0;
+}
+void mb_dec_destroy(mb_dec* d) { mb::dec_destroy(d); }
+int mb_dec_load(mb_dec* d, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream) {
+  if (!d || !name || !data) return fail(-1, "mb_dec_load: bad arguments");
+  std::string err;
+  int rc = mb::dec_load(d, name, data, shape, ndim, (hipStream_t)stream, err);
+  if (rc) return fail(rc, "mb_dec_load: %s", err.c_str());
+  return 0;
+}
+int mb_dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_nhwc_u8, int B, mb_stream stream) {
+  if (!d || !tokens) return fail(-1, "mb_dec_decode: null argument");
+  std::string err;
+  ProfScope p("decode", (hipStream_t)stream);
+  int rc = mb::dec_decode(d, tokens, img_nchw, img_nhwc_u8, B, (hipStream_t)stream, err);
+  if (rc) return fail(rc, "mb_dec_decode: %s", err.c_str());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ================================================================================================
+// whole loop (sampling.py:55-136)
+// ================================================================================================
+int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* labels, int B, const float* exp_noise,
+              const float* conf_noise, int64_t* step_tokens, int64_t* tokens_out, float* img_nchw,
+              uint8_t* img_nhwc_u8, mb_stream stream) {
+  if (!g || !plan || !labels || !exp_noise || !conf_noise) return fail(-1, "mb_sample: null argument");
+  if (!plan->scale || !plan->temperature || !plan->mask_len || plan->num_steps <= 0) return fail(-1, "mb_sample: incomplete plan");
+  const int nbf = plan->use_guidance ? 2 * B : B;
+  if (B <= 0 || nbf > g->max_seqs) return fail(-1, "mb_sample: B=%d needs %d sequences, engine holds %d", B, nbf, g->max_seqs);
+  if (!d && (img_nchw || img_nhwc_u8)) return fail(-1, "mb_sample: image requested without a decoder");
+  hipStream_t s = (hipStream_t)stream;
+  const mb_gen_cfg& c = g->c;
+  const int n = c.seq, m = c.splits, C = g->C;
+  const size_t P = (size_t)n * m;
+  // state init (sampling.py:65-71): every position masked; CFG batch = [cond | label-dropped]
+  mb::fill_i64(s, g->tok_a, (int64_t)C, (size_t)B * P);
+  if (plan->use_guidance) {
+    HIP_TRY(hipMemcpyAsync(g->lab_cfg, labels, B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->lab_cfg + B, labels, B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(g->drop_cfg, 0, B, s));
+    HIP_TRY(hipMemsetAsync(g->drop_cfg + B, 1, B, s));
+  }
+  int64_t* cur = g->tok_a;
+  int64_t* nxt = g->tok_b;
+  int64_t* last_pred = g->pred;
+  for (int i = 0; i < plan->num_steps; ++i) {
+    const float* lc = g->logits;
+    const float* lu = nullptr;
+    int rc;
+    if (plan->use_guidance) {
+      HIP_TRY(hipMemcpyAsync(g->tok_cfg, cur, B * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(g->tok_cfg + B * P, cur, B * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+      rc = gen_forward_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, g->logits, 2 * B, s);
+      lu = g->logits + (size_t)B * P * C;
+    } else {
+      rc = gen_forward_impl(g, cur, labels, nullptr, g->logits, B, s);
+    }
+    if (rc) return rc;
+    int64_t* pred = step_tokens ? step_tokens + (size_t)i * B * P : g->pred;
+    rc = mb_sample_step(lc, lu, plan->scale[i], plan->temperature[i], exp_noise + (size_t)i * B * P * C,
+                        conf_noise + (size_t)i * B * P, plan->mask_len[i], cur, nxt, pred, B, n, m, C, stream);
+    if (rc) return rc;
+    last_pred = pred;
+    int64_t* t = cur; cur = nxt; nxt = t;
+  }
+  // combine_factorized_tokens (factorization.py:7-24) on the LAST step's predictions, kept as integers
+  int64_t* codes = tokens_out ? tokens_out : g->codes;
+  mb::combine_groups(s, last_pred, codes, (size_t)B * n, m, g->gbits);
+  if (d) {
+    int rc = mb_dec_decode(d, codes, img_nchw, img_nhwc_u8, B, stream);
+    if (rc) return rc;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// h16 MFMA GEMM for the LFQBert trunk: out[M,N] = A[M,K] . W[N,K]^T + bias, fused epilogues.
+//
+// Replaces the nn.Linear / packed in_proj calls of modeling/bert.py:27-33 (FFN), :84,137 (MHA
+// projections), :411-417 (head).  Both operands are K-contiguous ("TN"), which is exactly the MFMA
+// fragment order, so tiles go HBM -> LDS by 16-byte LDS-DMA with no register round trip.
+//
+// Tile: 128(M) x 128(N) x 64(K), 256 threads = 4 waves as 2x2, each wave 64x64 = 4x4 MFMA
+// 16x16x32 tiles.  The MFMA A operand is the WEIGHT tile and the B operand the ACTIVATION tile, so
+// that a lane ends up holding 4 consecutive output features of one token row
+// (D[n=(lane>>4)*4+r][m=lane&15]) -> 8/16-byte row-major stores and float4 bias/residual loads.
+// LDS rows are 128 B (64 h16); the 16-byte slot index is XOR-swizzled with (row>>1)&7 -- applied
+// on the per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment
+// read -- which makes every ds_read_b128 lane group hit 16 distinct slots.
+// Double-buffered: the DMA for K-tile t+1 is in flight while tile t is multiplied.
+#include "mb_kernels.h"
+
+namespace mb {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][X|W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const int L = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
+  const int K = a.K;
+
+  // ---- staging: wave w owns rows [32w, 32w+32) of both tiles; 4 DMA instructions of 8 rows each
+  const h16* xsrc[4];
+  const h16* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = wave * 32 + j * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    const int mr = min(m0 + row, a.M - 1), nr = min(n0 + row, a.N - 1);
+    xsrc[j] = a.A + (size_t)mr * K + slot * 8;
+    wsrc[j] = a.W + (size_t)nr * K + slot * 8;
+  }
+  auto stage = [&](int t, int buf) {
+    char* xb = smem + buf * 2 * TILE_BYTES + wave * 32 * 128;
+    char* wb = xb + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      MB_GLDS16(xsrc[j] + t * BK, xb + j * 8 * 128);
+      MB_GLDS16(wsrc[j] + t * BK, wb + j * 8 * 128);
+    }
+  };
+
+  // ---- fragment read offsets (independent of the 16-row tile index: (row>>1)&7 == (lane&15)>>1)
+  int foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+    foff[kk] = (lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ ((lane & 15) >> 1)) * 16);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  stage(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // tile t landed for every wave; buf (t+1)&1 is free
+    if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
+    const char* xb = smem + (t & 1) * 2 * TILE_BYTES + wm * 64 * 128;
+    const char* wb = smem + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + wn * 64 * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      h16x8 wf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *(const h16x8*)(wb + i * 16 * 128 + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = *(const h16x8*)(xb + j * 16 * 128 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = MB_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: lane holds out[m][n..n+3], m = ..+(lane&15), n = ..+(lane>>4)*4
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+    if (m >= a.M) continue;
+    size_t orow = (size_t)m;
+    if (EPI == EPI_LOGITS_F32) {
+      const int sq = m / a.period, pos = m - sq * a.period;
+      if (pos == a.period - 1) continue;           // class-token row is not a prediction (bert.py:503)
+      orow = (size_t)sq * (a.period - 1) + pos;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      if (n >= a.N) continue;
+      const float4 b = *(const float4*)(a.bias + n);
+      float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
+      if (EPI == EPI_RES_F32) {
+        const float4 r = *(const float4*)(a.residual + (size_t)m * a.N + n);
+        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+      }
+      if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
+        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+      }
+      if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
+        h16x4 o = {to_h(v0), to_h(v1), to_h(v2), to_h(v3)};
+        *(h16x4*)(a.out_h16 + orow * a.N + n) = o;
+      } else {
+        *(float4*)(a.out_f32 + orow * a.N + n) = make_float4(v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
+void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a) {
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  dim3 grid(tiles), block(256);
+  switch (epi) {
+    case EPI_H16: hipLaunchKernelGGL(gemm_tn_kernel<EPI_H16>, grid, block, 0, s, a); break;
+    case EPI_GELU_H16: hipLaunchKernelGGL(gemm_tn_kernel<EPI_GELU_H16>, grid, block, 0, s, a); break;
+    case EPI_RES_F32: hipLaunchKernelGGL(gemm_tn_kernel<EPI_RES_F32>, grid, block, 0, s, a); break;
+    case EPI_GELU_F32: hipLaunchKernelGGL(gemm_tn_kernel<EPI_GELU_F32>, grid, block, 0, s, a); break;
+    case EPI_LOGITS_F32: hipLaunchKernelGGL(gemm_tn_kernel<EPI_LOGITS_F32>, grid, block, 0, s, a); break;
+  }
+}
+
+__global__ void cast_kernel(const float* __restrict__ src, h16* __restrict__ dst, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 v = *(const float4*)(src + i);
+    *(h16x4*)(dst + i) = h16x4{to_h(v.x), to_h(v.y), to_h(v.z), to_h(v.w)};
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t j = n & ~(size_t)3; j < n; ++j) dst[j] = to_h(src[j]);
+}
+void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n) {
+  const int blocks = (int)min((size_t)2048, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(cast_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+}
+
+}  // namespace mb

@@ -1,0 +1,68 @@
+// Shared device/host helpers for the MaskBit gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// 16-bit storage type of activations and packed weights.  IEEE fp16 by default: the sampler feeds its
+// own output back for 64 steps and classifier-free guidance multiplies logit errors by up to ~8x,
+// so the 8-bit mantissa of h16 costs ~1e-2 token mismatch against the fp32 reference where fp16's
+// 11 bits give ~1e-3 at the same MFMA rate (measured; DESIGN.md "Precision").  Build with
+// -DMB_HALF_BF16=1 to get the h16 variant for A/B runs.  Accumulation is always fp32.
+#ifndef MB_HALF_BF16
+#define MB_HALF_BF16 0
+#endif
+#if MB_HALF_BF16
+typedef __bf16 h16;
+#define MB_MFMA_16x16x32(a, b, c) MB_MFMA_16x16x32(a, b, c)
+#define MB_H16_MAX 3.3e38f
+#else
+typedef _Float16 h16;
+#define MB_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MB_H16_MAX 65504.0f
+#endif
+typedef __attribute__((ext_vector_type(2))) h16 h16x2;
+typedef __attribute__((ext_vector_type(4))) h16 h16x4;
+typedef __attribute__((ext_vector_type(8))) h16 h16x8;
+
+// fp32 -> storage half with saturation instead of +-inf (fp16 only; a no-op clamp for h16)
+__device__ __forceinline__ h16 to_h(float x) { return (h16)__builtin_amdgcn_fmed3f(x, -MB_H16_MAX, MB_H16_MAX); }
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MB_WAVE 64
+
+// Global -> LDS DMA of 16 B per lane: LDS destination is wave-uniform base + lane*16.
+#define MB_GLDS16(gptr, ldsptr)                                                                 \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),       \
+                                   (void __attribute__((address_space(3)))*)(ldsptr), 16, 0, 0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// erf with |abs err| < 2e-7 (Abramowitz-Stegun 7.1.26); used by the erf-GELU epilogue.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+
+// XCD-aware bijective remap: hardware places block b on XCD b%8; give every XCD a contiguous
+// chunk of the logical tile list so neighbouring tiles (sharing an operand panel) share an L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

@@ -1,0 +1,70 @@
+// Internal launcher declarations shared between the kernel translation units and engine.hip.
+#pragma once
+#include "mb_common.h"
+
+namespace mb {
+
+// ---- GEMM  out[M,N] = A[M,K] * W[N,K]^T + bias (+ epilogue) ------------------------------------
+enum GemmEpi {
+  EPI_H16 = 0,         // h16 out = acc + bias                      (QKV projection)
+  EPI_GELU_H16 = 1,    // h16 out = gelu_erf(acc + bias)            (FFN up projection)
+  EPI_RES_F32 = 2,      // f32 out  = acc + bias + residual           (attention out-proj, FFN down)
+  EPI_GELU_F32 = 3,     // f32 out  = gelu_erf(acc + bias)            (last_layer.0)
+  EPI_LOGITS_F32 = 4,   // f32 out, rows with (m % period)==period-1 dropped, rest compacted (head)
+};
+struct GemmArgs {
+  const h16* A;        // [M,K] row-major
+  const h16* W;        // [N,K] row-major (torch Linear layout)
+  const float* bias;    // [N]
+  const float* residual;// [M,N] fp32 or null
+  float* out_f32;
+  h16* out_h16;
+  int M, N, K;
+  int period;           // EPI_LOGITS_F32 only: tokens per sequence incl. the class row
+};
+void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a);
+
+// ---- LayerNorm over rows of y[M,d] -> x_f32 (optional) and x_h16 (optional) ---------------------
+void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
+                    float* x_f32, h16* x_h16, int M, int d);
+
+// ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------
+struct EmbedArgs {
+  const int64_t* tokens;   // [nb, seq, m]
+  const int64_t* labels;   // [nb]
+  const uint8_t* drop;     // [nb] or null
+  const float* w_in;       // [K, d]  (input_proj.weight transposed at load)
+  const float* b_in;       // [d]
+  const float* class_emb;  // [nclass+1, d]
+  const float* pos;        // [seq+1, d]
+  const float* gamma; const float* beta;
+  float* x_f32; h16* x_h16;   // [nb*(seq+1), d]
+  int nb, seq, m, gbits, d, nclass;
+};
+void embed_ln(hipStream_t s, const EmbedArgs& a);
+void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);
+
+// ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads);
+
+// ---- fused sampling step (sampling.py:90-131) ----------------------------------------------------
+struct StepArgs {
+  const float* logits_c; const float* logits_u;   // [B, n*m, C]
+  float scale, temperature;
+  const float* exp_noise;    // [B*n*m, C]
+  const float* conf_noise;   // [B, n*m]
+  int k_mask_len;
+  int64_t* tokens;           // [B, n*m] out (must not alias tokens_in)
+  int64_t* pred;             // [B, n*m] out (may be null)
+  int B, P /* n*m */, C;
+};
+int sample_step(hipStream_t s, const StepArgs& a, const int64_t* tokens_in);
+
+// ---- small integer helpers of the loop (sampling.py:65, factorization.py:7-24) -------------------
+void fill_i64(hipStream_t s, int64_t* dst, int64_t value, size_t n);
+void combine_groups(hipStream_t s, const int64_t* tokens /*[rows,m]*/, int64_t* codes /*[rows]*/, size_t rows, int m, int gbits);
+
+// ---- fp32 -> h16 repack ------------------------------------------------------------------------
+void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n);
+
+}  // namespace mb

@@ -1,0 +1,178 @@
+// Row-wise kernels of the LFQBert trunk: one 64-lane wavefront per token row, no LDS.
+//   embed_ln      : bit tokens -> {-1,0,+1} vector -> input_proj + class token + pos_emb -> LayerNorm
+//                   (modeling/bert.py:440-454 preprocess_tokens, :482-496)
+//   layernorm_rows: the post-norm LayerNorm(eps=1e-12) after each residual add (bert.py:69-70,137-139)
+// Both write the fp32 residual stream and its h16 copy (the next GEMM's A operand) in one pass.
+#include "mb_kernels.h"
+
+namespace mb {
+
+constexpr int MAXS = 32;  // scalar fallback path: d <= 64 * MAXS = 2048
+// NV > 0: vector path, d == 256*NV, row lives in NV float4 registers per lane (fully unrolled).
+// NV == 0: generic scalar path for odd widths (tiny test configs).
+
+// Two-pass mean / variance of a row held in registers, then affine + store.
+template <int NV>
+__device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          float eps, float* xo, h16* xb) {
+  constexpr bool VEC = NV > 0;
+  constexpr int nv = NV;
+  float s = 0.f;
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < nv; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+  }
+  else     { for (int q = 0; q < ns; ++q) s += sc[q]; }
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < nv; ++q) {
+      const float a = v[q].x - mean, b = v[q].y - mean, c = v[q].z - mean, e = v[q].w - mean;
+      ss += (a * a + b * b) + (c * c + e * e);
+    }
+  } else {
+    for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; if (c < d) { const float a = sc[q] - mean; ss += a * a; } }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < nv; ++q) {
+      const int c = q * 256 + lane * 4;
+      const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+      float4 o;
+      o.x = (v[q].x - mean) * rstd * g.x + b.x; o.y = (v[q].y - mean) * rstd * g.y + b.y;
+      o.z = (v[q].z - mean) * rstd * g.z + b.z; o.w = (v[q].w - mean) * rstd * g.w + b.w;
+      if (xo) *(float4*)(xo + c) = o;
+      if (xb) *(h16x4*)(xb + c) = h16x4{to_h(o.x), to_h(o.y), to_h(o.z), to_h(o.w)};
+    }
+  } else {
+    for (int q = 0; q < ns; ++q) {
+      const int c = lane + q * 64;
+      if (c < d) {
+        const float o = (sc[q] - mean) * rstd * gamma[c] + beta[c];
+        if (xo) xo[c] = o;
+        if (xb) xb[c] = to_h(o);
+      }
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, float* x_f32,
+                                                      h16* x_h16, int M, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* yr = y + (size_t)row * d;
+  constexpr bool VEC = NV > 0;
+  float4 v[VEC ? NV : 1]; float sc[VEC ? 1 : MAXS];
+  const int ns = (d + 63) / 64;
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = *(const float4*)(yr + q * 256 + lane * 4);
+  }
+  else     { for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; sc[q] = c < d ? yr[c] : 0.f; } }
+  ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
+                 x_h16 ? x_h16 + (size_t)row * d : nullptr);
+}
+
+void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
+                    float* x_f32, h16* x_h16, int M, int d) {
+  dim3 grid((M + 3) / 4), block(256);
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, M, d);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, M, d);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, M, d);
+}
+
+// One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,
+// bert.py:489).  A token contributes sum_j sign_j * W[:, g*gbits + j] where sign is +-1 from bit j
+// of group g's index (LSB first) and 0 when the group carries the mask token (index == 2^gbits).
+// w_in is held TRANSPOSED ([K][d], repacked at load) so that the K loads of a lane are independent
+// float4 reads of 4 neighbouring features; the sign vector is two wave-uniform bit masks.
+constexpr int MAXBITS = 24;
+
+template <int NV>
+__global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int N = a.seq + 1;
+  if (row >= a.nb * N) return;
+  const int sq = row / N, t = row - sq * N;
+  const int d = a.d, K = a.m * a.gbits;
+  uint32_t plus = 0, live = 0;       // bit j of `plus` set -> +1; bit j of `live` clear -> 0
+  const float* cls = nullptr;
+  if (t < a.seq) {
+    for (int g = 0; g < a.m; ++g) {
+      const int64_t idx = a.tokens[((size_t)sq * a.seq + t) * a.m + g];
+      const uint32_t gm = (1u << a.gbits) - 1u;
+      if (idx != ((int64_t)1 << a.gbits)) { live |= gm << (g * a.gbits); plus |= ((uint32_t)idx & gm) << (g * a.gbits); }
+    }
+  } else {
+    int64_t lab = a.labels[sq];
+    if (a.drop && a.drop[sq]) lab = a.nclass;                       // bert.py:482-484 (not in place)
+    lab = lab < 0 ? 0 : (lab > a.nclass ? a.nclass : lab);          // never read outside class_emb (host validates)
+    cls = a.class_emb + (size_t)lab * d;
+  }
+  const float* pos = a.pos + (size_t)t * d;
+  constexpr bool VEC = NV > 0;
+  float4 v[VEC ? NV : 1]; float sc[VEC ? 1 : MAXS];
+  const int ns = (d + 63) / 64;
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c = q * 256 + lane * 4;
+      float4 e = cls ? *(const float4*)(cls + c) : *(const float4*)(a.b_in + c);
+      if (!cls) {
+#pragma unroll
+        for (int j = 0; j < MAXBITS; ++j) {
+          if (j < K) {
+            const float4 w = *(const float4*)(a.w_in + (size_t)j * d + c);
+            const float sj = ((live >> j) & 1u) ? (((plus >> j) & 1u) ? 1.f : -1.f) : 0.f;
+            e.x = fmaf(sj, w.x, e.x); e.y = fmaf(sj, w.y, e.y); e.z = fmaf(sj, w.z, e.z); e.w = fmaf(sj, w.w, e.w);
+          }
+        }
+      }
+      const float4 p = *(const float4*)(pos + c);
+      v[q] = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
+  } else {
+    for (int q = 0; q < ns; ++q) {
+      const int c = lane + q * 64;
+      float e = 0.f;
+      if (c < d) {
+        if (cls) e = cls[c];
+        else {
+          e = a.b_in[c];
+          for (int j = 0; j < K; ++j) {
+            const float sj = ((live >> j) & 1u) ? (((plus >> j) & 1u) ? 1.f : -1.f) : 0.f;
+            e = fmaf(sj, a.w_in[(size_t)j * d + c], e);
+          }
+        }
+        e += pos[c];
+      }
+      sc[q] = e;
+    }
+  }
+  ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d);
+}
+
+void embed_ln(hipStream_t s, const EmbedArgs& a) {
+  const int rows = a.nb * (a.seq + 1);
+  dim3 grid((rows + 3) / 4), block(256);
+  if (a.d == 1024) hipLaunchKernelGGL(embed_ln_kernel<4>, grid, block, 0, s, a);
+  else if (a.d == 768) hipLaunchKernelGGL(embed_ln_kernel<3>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(embed_ln_kernel<0>, grid, block, 0, s, a);
+}
+
+__global__ void transpose_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * cols) { const int r = i / cols, c = i - r * cols; dst[(size_t)c * rows + r] = src[i]; }
+}
+void transpose_f32(hipStream_t s, const float* src, float* dst, int rows, int cols) {
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, src, dst, rows, cols);
+}
+
+}  // namespace mb

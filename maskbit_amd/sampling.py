@@ -1,0 +1,155 @@
+"""``sample()``: the MaskBit N-step masked bit-token sampler + decode, on the gfx950 engine.
+
+Drop-in for the reference's ``modeling.modules.sample`` (sampling.py:13-136): same signature,
+same return value ``(image [B,3,H,W] float32 unclamped on model.device, [pred tokens per step])``,
+same random-number protocol -- per step one ``exponential_`` of shape [B*n*m, C] from the model
+device's generator (what ``Categorical.sample`` -> ``torch.multinomial(n=1)`` draws) and one
+``Gumbel(0,1).sample([B,n,m])`` from the CPU default generator -- so a fixed seed draws the same
+noise the reference would on the same device.  The schedule (guidance scale, temperature, mask
+length per step) is evaluated here on the host with the reference's float32 torch-scalar
+arithmetic and handed to ``mb_sample`` as a plan; the loop body itself (2B-sequence forward, CFG
+combine, softmax, draw, confidence, k-th-smallest re-mask, combine, decode) never leaves the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Text, Tuple
+
+import torch
+
+from . import _lib
+from .bert import LFQBert
+from .conv_vqgan import ConvVQModel
+from .masking import get_masking_ratio
+
+
+def build_plan(num_steps: int, num_maskable: int, guidance_scale: float, guidance_annealing: str, scale_pow: float,
+               softmax_temperature: float, use_sampling_annealing: bool, mask_schedule_strategy: str):
+    """Host-side per-step constants (sampling.py:82, 90-98, 103-104, 120-123)."""
+    get_masking_ratio(1.0, mask_schedule_strategy)          # raises ValueError on a bad strategy before any GPU work
+    scale, temp, mask_len = [], [], []
+    for i in range(num_steps):
+        progress = (i + 1) / num_steps
+        if guidance_annealing == "none":
+            a = guidance_scale * 1.0
+        elif guidance_annealing == "linear":
+            a = guidance_scale * (i / num_steps)
+        elif guidance_annealing == "cosine":
+            sp = torch.ones(1) * scale_pow                                      # float32, as in the reference
+            a = float(guidance_scale * ((1 - torch.cos(((i / num_steps) ** sp) * torch.pi)) * 1 / 2))
+        else:
+            raise ValueError(f"guidance_annealing must be 'none', 'linear' or 'cosine', got {guidance_annealing!r}")
+        scale.append(float(torch.tensor(a, dtype=torch.float32)))
+        temp.append(0.5 + 0.8 * (1 - progress) if use_sampling_annealing else softmax_temperature)
+        mask_len.append(int(torch.floor(get_masking_ratio(progress, mask_schedule_strategy) * num_maskable)))
+    return scale, temp, mask_len
+
+
+def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, randomize_temperature: float,
+               device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Noise for a whole run, drawn in the reference's per-generator order.
+    Returns exp_noise [steps, B*n*m, C] (device) and conf_noise [steps, B, n, m] (device) where
+    conf_noise = gumbel * randomize_temperature * (1 - progress) (sampling.py:117)."""
+    exp_noise = torch.empty((num_steps, num_samples * n * m, C_), dtype=torch.float32, device=device)
+    for i in range(num_steps):
+        exp_noise[i].exponential_(1)
+    gumbel = torch.distributions.Gumbel(loc=0.0, scale=1.0)                     # python-float params => CPU draws
+    conf = []
+    for i in range(num_steps):
+        progress = (i + 1) / num_steps
+        conf.append(gumbel.sample((num_samples, n, m)) * randomize_temperature * (1 - progress))
+    return exp_noise, torch.stack(conf).to(device, non_blocking=False)
+
+
+def run_loop(model: LFQBert, vqgan_model: Optional[ConvVQModel], labels: torch.Tensor, plan, exp_noise: torch.Tensor,
+             conf_noise: torch.Tensor, want_steps: bool = True, want_image: bool = True, want_u8: bool = False):
+    """One ``mb_sample`` call.  -> (image or None, uint8 NHWC or None, step tokens [steps,B,n,m] or None, codes [B,n])."""
+    dev = model._require_cuda("sample")
+    scale, temp, mask_len = plan
+    steps = len(scale)
+    B = labels.shape[0]
+    n, m = model.seq_len, model.splits
+    use_cfg = any(s != 0.0 for s in scale) or getattr(plan, "force_guidance", False)
+    labels = labels.to(device=dev, dtype=torch.int64).contiguous()
+    step_tokens = torch.empty((steps, B, n, m), dtype=torch.int64, device=dev) if want_steps else None
+    codes = torch.empty((B, n), dtype=torch.int64, device=dev)
+    img = u8 = None
+    hdec = None
+    if vqgan_model is not None and (want_image or want_u8):
+        side = int(round(n ** 0.5))
+        res = side << (vqgan_model.num_resolutions - 1)
+        if want_image:
+            img = torch.empty((B, vqgan_model.num_channels, res, res), dtype=torch.float32, device=dev)
+        if want_u8:
+            u8 = torch.empty((B, res, res, vqgan_model.num_channels), dtype=torch.uint8, device=dev)
+        hdec = vqgan_model.engine(B, side)
+    hgen = model.engine(2 * B if use_cfg else B)
+    c_scale = (C.c_float * steps)(*scale)
+    c_temp = (C.c_float * steps)(*temp)
+    c_len = (C.c_int * steps)(*mask_len)
+    cplan = _lib.SamplePlan(steps, 1 if use_cfg else 0, c_scale, c_temp, c_len)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mb_sample(hgen, hdec, C.byref(cplan), labels.data_ptr(), B, exp_noise.data_ptr(),
+                                         conf_noise.data_ptr(), ptr(step_tokens), codes.data_ptr(), ptr(img), ptr(u8),
+                                         torch.cuda.current_stream().cuda_stream), "mb_sample")
+    return img, u8, step_tokens, codes
+
+
+@torch.no_grad()
+def sample(
+    model,
+    vqgan_model,
+    num_samples: int = 10,
+    labels: Optional[torch.Tensor] = None,
+    softmax_temperature: float = 1.0,
+    randomize_temperature: float = 4.5,
+    mask_schedule_strategy: Text = "linear",
+    num_steps: int = 12,
+    guidance_scale: float = 3.0,
+    mask_token: int = 1024,
+    patch_size: int = 16,
+    guidance_annealing: Text = "none",
+    use_sampling_annealing: bool = False,
+    scale_pow: float = 4.0,
+    codebook_size: int = 1024,
+    codebook_splits: int = 1,
+    use_tqdm: bool = False,
+) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """Generate ``num_samples`` class-conditional images.  See the module docstring; arguments as in the
+    reference (sampling.py:32-54).  ``use_tqdm`` is accepted and ignored (the loop runs on the device)."""
+    if not isinstance(model, LFQBert):
+        raise TypeError(f"sample() needs a maskbit_amd LFQBert generator, got {type(model).__name__}")
+    if not isinstance(vqgan_model, ConvVQModel):
+        raise TypeError(f"sample() needs a maskbit_amd ConvVQModel tokenizer, got {type(vqgan_model).__name__}")
+    device = model.device
+    model.eval()
+    vqgan_model.eval()
+    n, m = int(patch_size ** 2), int(codebook_splits)
+    if n != model.seq_len or m != model.splits:
+        raise ValueError(f"patch_size/codebook_splits ({patch_size}, {m}) do not match the generator ({model.seq_len} tokens, {model.splits} groups)")
+    if mask_token != model.mask_token:
+        raise ValueError(f"mask_token={mask_token} but the generator masks with {model.mask_token} (= 2**(bits/splits))")
+    if 2 ** model.bits != codebook_size:
+        raise ValueError(f"codebook_size={codebook_size} does not match the generator's 2**{model.bits}")
+    if labels is None:
+        # goldfish, chicken, tiger cat, hourglass, ship, dog, race car, airliner, teddy bear, random (sampling.py:60-63)
+        labels = torch.LongTensor([1, 7, 282, 604, 724, 179, 751, 404, 850, int(torch.randint(0, 999, size=(1,)))] * (num_samples // 10))
+    model._check_labels(labels)
+    labels = labels.to(device)
+    if labels.numel() != num_samples:
+        raise ValueError(f"{labels.numel()} labels for num_samples={num_samples}")
+    plan = build_plan(num_steps, n * m, guidance_scale, guidance_annealing, scale_pow, softmax_temperature,
+                      use_sampling_annealing, mask_schedule_strategy)
+    if guidance_scale != 0.0 and not any(s != 0.0 for s in plan[0]):
+        plan = _ForcedPlan(plan)                      # CFG forward still runs when every a_i happens to be 0
+    exp_noise, conf_noise = draw_noise(num_samples, n, m, model.effective_codebook_size, num_steps, randomize_temperature, device)
+    img, _, step_tokens, _ = run_loop(model, vqgan_model, labels, plan, exp_noise, conf_noise)
+    return img, list(step_tokens.unbind(0))
+
+
+class _ForcedPlan(tuple):
+    force_guidance = True
+
+    def __new__(cls, plan):
+        return super().__new__(cls, plan)

@@ -70,7 +70,7 @@ def npify(d):
 
 
 TINY_GEN = O.GenCfg(bits=12, splits=2, hidden=128, depth=2, heads=4, mlp=256, seq=256, nclass=10)
-TINY_TOK = O.TokCfg(token_size=12, hidden_channels=32, channel_mult=(1, 2, 2), num_resolutions=3, num_res_blocks=1)
+TINY_TOK = O.TokCfg(token_size=12, hidden_channels=64, channel_mult=(1, 1, 2), num_resolutions=3, num_res_blocks=1)
 FULL_GEN12 = O.GenCfg(bits=12, splits=2)
 FULL_TOK12 = O.TokCfg(token_size=12)
 FULL_TOK10 = O.TokCfg(token_size=10)
@@ -126,7 +126,8 @@ def main():
     rec, _ = tok(x_in)
     np.savez_compressed(os.path.join(OUT, "tok_tiny.npz"), tokens=dtoks.numpy(), image=img.numpy(),
                         enc_input=x_in.numpy(), enc_zq=zq.numpy(), enc_indices=res["min_encoding_indices"].numpy(),
-                        recon=rec.numpy(), **{"w." + k: v.numpy() for k, v in tsd.items()})
+                        recon=rec.numpy(), seed=21, w_sha_conv_in=sha(tsd["decoder.conv_in.weight"]),
+                        w_sha_enc_conv_in=sha(tsd["encoder.conv_in.weight"]))
     print("tok_tiny image", tuple(img.shape), float(img.mean()), float(img.std()))
 
     # ---- 3. tiny end-to-end sample(): per-step tokens + image, with CFG cosine and without --

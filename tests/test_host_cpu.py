@@ -1,0 +1,143 @@
+"""CPU-only tests of the host side: C-ABI library exports, reference-compatible module surface,
+checkpoint key compatibility, schedule/plan arithmetic, loud failure without a GPU."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_weights
+from oracle import maskbit_oracle as O
+
+TINY_GEN = O.GenCfg(bits=12, splits=2, hidden=128, depth=2, heads=4, mlp=256, seq=256, nclass=10)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/maskbit_hip.h <-> libmaskbit_hip.so <-> ctypes signatures stay in sync."""
+    from maskbit_amd import _lib
+    header = open(os.path.join(ROOT, "include", "maskbit_hip.h")).read()
+    declared = set(re.findall(r"\b(mb_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mb_abi_version() == 1
+    assert isinstance(lib.mb_last_error(), bytes)
+
+
+def test_struct_layouts_match_header():
+    from maskbit_amd import _lib
+    assert ctypes.sizeof(_lib.GenCfg) == 8 * 4
+    assert ctypes.sizeof(_lib.DecCfg) == (5 + 8 + 1) * 4
+    assert ctypes.sizeof(_lib.SamplePlan) == 8 + 3 * 8
+
+
+def test_generator_state_dict_matches_reference_keys():
+    """The oracle's weights were loaded with strict=True into the REAL reference when the goldens were
+    made; loading the same dict strictly here pins our key names and shapes to the reference's."""
+    from maskbit_amd import LFQBert
+    sd = golden_weights(load_golden("gen_tiny.npz"))
+    m = LFQBert(hidden_dim=128, codebook_size=4096, codebook_splits=2, depth=2, heads=4, mlp_dim=256, nclass=10)
+    m.load_state_dict(sd, strict=True)
+    full = LFQBert(img_size=256, hidden_dim=1024, codebook_size=4096, codebook_splits=2, depth=24, heads=16, mlp_dim=4096)
+    assert len(full.state_dict()) == 301
+    assert sum(p.numel() for p in full.parameters()) == 304_795_776
+    assert full.mask_token == 64 and full.effective_codebook_size == 64 and full.seq_len == 256
+
+
+def test_tokenizer_state_dict_matches_reference_keys():
+    from maskbit_amd import ConvVQModel
+    from hip_helpers import tok_config
+    cfg = O.TokCfg(token_size=12)
+    sd = O.make_tokenizer_weights(cfg, seed=200, with_encoder=True)
+    m = ConvVQModel(tok_config(cfg))
+    m.load_state_dict(sd, strict=True)
+    assert len(m.state_dict()) == 177
+    assert torch.equal(m.quantize.codebook, sd["quantize.codebook"])
+
+
+def test_sample_signature_matches_reference():
+    from maskbit_amd import sample
+    sig = inspect.signature(sample)
+    names = list(sig.parameters)
+    assert names == ["model", "vqgan_model", "num_samples", "labels", "softmax_temperature", "randomize_temperature",
+                     "mask_schedule_strategy", "num_steps", "guidance_scale", "mask_token", "patch_size",
+                     "guidance_annealing", "use_sampling_annealing", "scale_pow", "codebook_size", "codebook_splits", "use_tqdm"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["num_samples"], d["randomize_temperature"], d["mask_schedule_strategy"], d["num_steps"], d["guidance_scale"],
+            d["mask_token"], d["scale_pow"], d["codebook_size"], d["codebook_splits"]) == (10, 4.5, "linear", 12, 3.0, 1024, 4.0, 1024, 1)
+
+
+def test_import_paths_of_the_reference_drivers():
+    from modeling.bert import Bert, LFQBert          # scripts/eval_maskbit.py:11-13
+    from modeling.conv_vqgan import ConvVQModel
+    from modeling.modules import sample, BaseModel
+    import maskbit_amd
+    assert LFQBert is maskbit_amd.LFQBert and ConvVQModel is maskbit_amd.ConvVQModel and sample is maskbit_amd.sample
+    with pytest.raises(NotImplementedError):
+        Bert()
+
+
+def test_no_cpu_fallback():
+    from maskbit_amd import LFQBert, ConvVQModel, sample
+    from hip_helpers import tok_config
+    m = LFQBert(hidden_dim=128, codebook_size=4096, codebook_splits=2, depth=1, heads=4, mlp_dim=256, nclass=10)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 256, 2, dtype=torch.long), torch.zeros(1, dtype=torch.long))
+    t = ConvVQModel(tok_config(O.TokCfg(token_size=12, hidden_channels=64, channel_mult=(1, 1, 2), num_resolutions=3, num_res_blocks=1)))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        t.decode_tokens(torch.zeros(1, 256))
+    with pytest.raises(RuntimeError):
+        sample(m, t, num_samples=1, labels=torch.zeros(1, dtype=torch.long), mask_token=64, codebook_size=4096, codebook_splits=2)
+    src = open(os.path.join(ROOT, "maskbit_amd", "sampling.py")).read() + open(os.path.join(ROOT, "maskbit_amd", "bert.py")).read()
+    assert "oracle" not in src.replace("test infrastructure", "")
+
+
+def test_plan_matches_oracle_schedule():
+    from maskbit_amd.sampling import build_plan
+    from maskbit_amd.masking import get_masking_ratio
+    for (N, ann, sp, strat) in [(64, "cosine", 3.0, "arccos"), (16, "none", 4.0, "linear"), (8, "linear", 1.0, "cosine"), (256, "cosine", 3.0, "arccos")]:
+        scale, temp, mlen = build_plan(N, 512, 7.1, ann, sp, 1.0, False, strat)
+        assert mlen == [int(v) for v in O.mask_len_schedule(N, 512, strat)]
+        for i in range(N):
+            ref = 7.1 * O.guidance_factor(i, N, ann, sp)
+            assert scale[i] == float(torch.as_tensor(ref, dtype=torch.float32).reshape(-1)[0])
+        assert temp == [1.0] * N
+    _, temp, _ = build_plan(4, 512, 3.0, "none", 1.0, 1.0, True, "arccos")
+    assert temp == [0.5 + 0.8 * (1 - (i + 1) / 4) for i in range(4)]
+    with pytest.raises(ValueError):
+        build_plan(4, 512, 3.0, "none", 1.0, 1.0, False, "bogus")
+    z = load_golden("schedule.npz")
+    for mode in ("arccos", "cosine", "linear", "square", "root"):
+        mine = np.array([float(get_masking_ratio((i + 1) / 64, mode)) for i in range(64)], dtype=np.float32)
+        assert np.array_equal(mine, z[f"ratio_{mode}_64"])
+
+
+def test_factorization_matches_reference_vectors():
+    from maskbit_amd import combine_factorized_tokens, split_factorized_tokens
+    z = load_golden("schedule.npz")
+    t = torch.from_numpy(z["split_in"])
+    sp = split_factorized_tokens(t, 4096, 2)
+    assert torch.equal(sp, torch.from_numpy(z["split_out"]))
+    comb = combine_factorized_tokens(sp, 4096, 2)
+    assert comb.dtype == torch.float32 and torch.equal(comb, torch.from_numpy(z["combine_out"]))
+
+
+def test_load_pretrained_roundtrip(tmp_path):
+    from maskbit_amd import LFQBert
+    sd = golden_weights(load_golden("gen_tiny.npz"))
+    legacy = {k.replace("input_proj", "token_emb"): v for k, v in sd.items()}      # eval_maskbit.py:52-53 rename
+    torch.save(legacy, tmp_path / "gen.bin")
+    m = LFQBert(hidden_dim=128, codebook_size=4096, codebook_splits=2, depth=2, heads=4, mlp_dim=256, nclass=10)
+    m.train()
+    m.load_pretrained(str(tmp_path / "gen.bin"), rename_keys={"token_emb": "input_proj"})
+    assert not m.training and torch.equal(m.input_proj.weight, sd["input_proj.weight"])
+    m.save_pretrained(str(tmp_path / "out"))
+    again = torch.load(tmp_path / "out" / "pytorch_model.bin")
+    assert set(again) == set(sd)
+    with pytest.raises(ValueError):
+        m.load_pretrained(str(tmp_path / "missing.bin"))
+    assert m.device == torch.device("cpu") and m.dtype == torch.float32

@@ -10,7 +10,15 @@ from conftest import load_golden, golden_weights
 from oracle import maskbit_oracle as O
 
 TINY_GEN = O.GenCfg(bits=12, splits=2, hidden=128, depth=2, heads=4, mlp=256, seq=256, nclass=10)
-TINY_TOK = O.TokCfg(token_size=12, hidden_channels=32, channel_mult=(1, 2, 2), num_resolutions=3, num_res_blocks=1)
+TINY_TOK = O.TokCfg(token_size=12, hidden_channels=64, channel_mult=(1, 1, 2), num_resolutions=3, num_res_blocks=1)
+
+
+def tiny_tok_weights():
+    z = load_golden("tok_tiny.npz")
+    sd = O.make_tokenizer_weights(TINY_TOK, seed=int(z["seed"]), with_encoder=True)
+    assert sha(sd["decoder.conv_in.weight"]) == str(z["w_sha_conv_in"])
+    assert sha(sd["encoder.conv_in.weight"]) == str(z["w_sha_enc_conv_in"])
+    return sd
 
 
 def sha(t):
@@ -48,7 +56,7 @@ def test_generator_does_not_mutate_labels():
 
 def test_decode_and_encode_tiny():
     z = load_golden("tok_tiny.npz")
-    sd = golden_weights(z)
+    sd = tiny_tok_weights()
     img = O.decode_tokens(sd, TINY_TOK, torch.from_numpy(z["tokens"]).float())
     assert (img - torch.from_numpy(z["image"])).abs().max().item() < 1e-4
     zq, idx = O.encode_image(sd, TINY_TOK, torch.from_numpy(z["enc_input"]))
@@ -63,7 +71,7 @@ def test_sample_loop_bit_exact(name):
     """Same seed, same RNG draw order -> the per-step tokens of the reference, bit for bit."""
     z = load_golden(name + ".npz")
     gsd = golden_weights(load_golden("gen_tiny.npz"))
-    tsd = golden_weights(load_golden("tok_tiny.npz"))
+    tsd = tiny_tok_weights()
     kw = {}
     for k, v in zip(z["kw_keys"], z["kw_vals"]):
         v = str(v)
