@@ -197,7 +197,7 @@ def main():
         line = {
             "metric": "images/sec (256x256, 64-step MaskBit-12bit, CFG)", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] (C3): MaskBit-Generator 12-bit, 64 steps, CFG 7.1 cosine, arccos schedule, "
                                    f"batch {B}/GPU, conv_vqgan decode to 256x256 uint8" + (", RCCL all-gather of images" if world > 1 else ""),
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, one process per GPU)"},

@@ -45,6 +45,8 @@ SIGNATURES = {
     "mb_dec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SamplePlan), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mb_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                          C.c_int, C.c_int, C.c_void_p]),
     "mb_prof_enable": (C.c_int, [C.c_int]),
     "mb_prof_read": (C.c_int, [C.c_char_p, C.c_int]),
 }

@@ -179,6 +179,21 @@ int mb_prof_read(char* buf, int buflen) {
   return (int)out.size();
 }
 
+// Diagnostic entry: one GEMM of the trunk family on caller buffers (tests and tools/gemm_bench.py).
+int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
+            int M, int N, int K, int period, int variant, mb_stream stream) {
+  if (!A || !W || !bias || epi < 0 || epi > 4) return fail(-1, "mb_gemm: bad arguments");
+  if (K % 64) return fail(-1, "mb_gemm: K must be a multiple of 64");
+  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period};
+  ProfScope p("gemm_diag", (hipStream_t)stream);
+  mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int mb_debug_read(long long* host, int n) { return mb::gemm_debug_read(host, n); }
+
 int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (!cfg || !out || max_seqs <= 0) return fail(-1, "mb_gen_create: bad arguments");
   const mb_gen_cfg& c = *cfg;

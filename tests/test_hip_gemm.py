@@ -1,0 +1,76 @@
+"""GPU tests of the trunk GEMM family (both kernels, every tile height, every epilogue) against a
+plain PyTorch fp32 matmul of the same fp16 operands.  Tolerance: fp32 accumulation-order noise plus
+(for fp16 outputs) one fp16 rounding of the result."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _run(epi, A, W, bias, res, variant, period=0):
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    rows = M if epi != 4 else (M // period) * (period - 1)
+    out32 = torch.full((rows, N), float("nan"), device=DEV, dtype=torch.float32) if epi in (2, 3, 4) else None
+    out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16) if epi in (0, 1) else None
+    _lib.check(lib.mb_gemm(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None,
+                           out32.data_ptr() if out32 is not None else None, out16.data_ptr() if out16 is not None else None,
+                           M, N, K, period, variant, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return out32 if out32 is not None else out16
+
+
+def _ref(epi, A, W, bias, res, period=0):
+    y = A.float() @ W.float().t() + bias
+    if epi == 2:
+        y = y + res
+    if epi in (1, 3):
+        y = torch.nn.functional.gelu(y)
+    if epi == 4:
+        y = y.reshape(A.shape[0] // period, period, -1)[:, :period - 1].reshape(-1, y.shape[-1])
+    return y
+
+
+@pytest.mark.parametrize("variant", [-1, 4, 5, 6, 7, 8, 14, 18, 106, 108, 0])
+@pytest.mark.parametrize("epi,N,K", [(0, 768, 256), (1, 512, 128), (2, 256, 512), (3, 256, 64)])
+def test_gemm_variants_match_torch(variant, epi, N, K):
+    torch.manual_seed(variant * 10 + epi)
+    M = 5 * 257 + 3                                         # ragged: not a multiple of any tile height
+    A = torch.randn(M, K, device=DEV).half()
+    W = (torch.randn(N, K, device=DEV) * 0.1).half()        # asymmetric operands: catches transposed fragments
+    bias = torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV) if epi == 2 else None
+    out = _run(epi, A, W, bias, res, variant)
+    ref = _ref(epi, A, W, bias, res)
+    assert not torch.isnan(out.float()).any()               # every output element written exactly once
+    tol = 2e-3 * float(ref.abs().max()) if epi in (0, 1) else 2e-4 * float(ref.abs().max())
+    assert float((out.float() - ref).abs().max()) < tol
+
+
+def test_gemm_identity_detects_layout_bugs():
+    """A = I (padded) with an asymmetric W returns W^T rows exactly: row/col swaps or fragment permutations show up."""
+    K = N = 256
+    M = 1024
+    A = torch.zeros(M, K, device=DEV, dtype=torch.float16)
+    A[torch.arange(K), torch.arange(K)] = 1.0
+    A[K:2 * K] = A[:K] * 2
+    W = (torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) % 251 - 125).half()
+    bias = torch.zeros(N, device=DEV)
+    for variant in (-1, 4, 8, 106, 108):
+        out = _run(3 if False else 2, A, W, bias, torch.zeros(M, N, device=DEV), variant)
+        assert torch.equal(out[:K], W.float().t()) and torch.equal(out[K:2 * K], 2 * W.float().t())
+        assert float(out[2 * K:].abs().max()) == 0.0
+
+
+def test_gemm_logits_epilogue_drops_class_rows():
+    torch.manual_seed(3)
+    period, nb, K, N = 257, 3, 128, 128
+    A = torch.randn(nb * period, K, device=DEV).half()
+    W = (torch.randn(N, K, device=DEV) * 0.1).half()
+    bias = torch.randn(N, device=DEV)
+    out = _run(4, A, W, bias, None, 0, period)
+    ref = _ref(4, A, W, bias, None, period)
+    assert out.shape == (nb * 256, N) and float((out - ref).abs().max()) < 2e-4 * float(ref.abs().max())
