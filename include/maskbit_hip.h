@@ -108,7 +108,8 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
 /* Name + accumulated device time (HIP events on the launch stream) of the engine's kernels. */
 /* One GEMM of the trunk family, out[M,N] = A[M,K] . W[N,K]^T + bias with epilogue `epi` (0 fp16 out,
  * 1 gelu->fp16, 2 +residual->fp32, 3 gelu->fp32, 4 logits fp32 with every `period`-th row dropped);
- * A, W, out_h16 are fp16 device buffers.  variant: 0 auto, -1 small-tile kernel, 4..8 large kernel MT. */
+ * A, W, out_h16 are fp16 device buffers.  variant: 0 auto, -1 the 128x128 kernel, 6 / 8 the half-tile kernel with
+ * 192 / 256-row tiles, 257 its sequence-aligned tiles (M % 257 == 0). */
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
             void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
 int mb_prof_enable(int on);

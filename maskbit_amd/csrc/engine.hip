@@ -192,8 +192,6 @@ int mb_gemm(int epi, const void* A, const void* W, const float* bias, const floa
   return 0;
 }
 
-int mb_debug_read(long long* host, int n) { return mb::gemm_debug_read(host, n); }
-
 int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (!cfg || !out || max_seqs <= 0) return fail(-1, "mb_gen_create: bad arguments");
   const mb_gen_cfg& c = *cfg;

@@ -19,7 +19,7 @@ namespace mb {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
 
-template <int EPI, bool DMA_ONLY = false>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][X|W]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
     const char* xb = smem + (t & 1) * 2 * TILE_BYTES + wm * 64 * 128;
     const char* wb = smem + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + wn * 64 * 128;
-    if (!DMA_ONLY)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       h16x8 wf[4], xf[4];
@@ -122,12 +121,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
 }
 
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
-  // variant: 0 auto; -1 the 128x128 kernel; 4..8 (+10) gemm_big with that MT; 106 / 108 the half-tile kernel with that MT
-  if ((variant == 0 || (variant >= 106 && variant <= 128)) && gemm_ht_supported(epi, a)) { gemm_ht(s, epi, a, variant ? variant - 100 : 0); return; }
-  if (variant > 0 && variant < 100 && gemm_big_supported(epi, a)) { gemm_big(s, epi, a, variant); return; }
-  if (variant == -2) {   // experiment: DMA traffic only
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_tn_kernel<EPI_RES_F32, true>), dim3(tiles), dim3(256), 0, s, a);
+  // variant: 0 auto; -1 this 128x128 kernel; 6 / 8 the half-tile kernel with that MT; 257 its sequence-aligned tiles;
+  // 16/26 (MT 6) and 18/28 (MT 8): DMA-only / compute-only ablations of the half-tile kernel (timing experiments)
+  if (variant >= 0 && gemm_ht_supported(epi, a)) {
+    if (variant == 257 && a.M % 257) variant = 0;
+    gemm_ht(s, epi, a, variant);
     return;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);

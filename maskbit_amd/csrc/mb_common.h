@@ -32,9 +32,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define MB_WAVE 64
 
 // Global -> LDS DMA of 16 B per lane: LDS destination is wave-uniform base + lane*16.
-#define MB_GLDS16(gptr, ldsptr)                                                                 \
+#define MB_GLDS16_AUX(gptr, ldsptr, aux)                                                        \
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),       \
-                                   (void __attribute__((address_space(3)))*)(ldsptr), 16, 0, 0)
+                                   (void __attribute__((address_space(3)))*)(ldsptr), 16, 0, aux)
+#define MB_GLDS16(gptr, ldsptr) MB_GLDS16_AUX(gptr, ldsptr, 0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

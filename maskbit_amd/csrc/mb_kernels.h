@@ -23,11 +23,8 @@ struct GemmArgs {
   int period;           // EPI_LOGITS_F32 only: tokens per sequence incl. the class row
 };
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
-bool gemm_big_supported(GemmEpi epi, const GemmArgs& a);
-int gemm_debug_read(long long* host, int n);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
-void gemm_big(hipStream_t s, GemmEpi epi, const GemmArgs& a, int force_mt);
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional) and x_h16 (optional) ---------------------
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,

@@ -34,7 +34,7 @@ def _ref(epi, A, W, bias, res, period=0):
     return y
 
 
-@pytest.mark.parametrize("variant", [-1, 4, 5, 6, 7, 8, 14, 18, 106, 108, 0])
+@pytest.mark.parametrize("variant", [-1, 6, 8, 0])
 @pytest.mark.parametrize("epi,N,K", [(0, 768, 256), (1, 512, 128), (2, 256, 512), (3, 256, 64)])
 def test_gemm_variants_match_torch(variant, epi, N, K):
     torch.manual_seed(variant * 10 + epi)
@@ -50,6 +50,24 @@ def test_gemm_variants_match_torch(variant, epi, N, K):
     assert float((out.float() - ref).abs().max()) < tol
 
 
+@pytest.mark.parametrize("epi,N,K", [(0, 768, 256), (1, 512, 128), (2, 256, 512), (3, 256, 64)])
+def test_gemm_sequence_aligned_tiles(epi, N, K):
+    """M = nb*257: one tile per sequence (256 token rows + the class-token row as a 17th one-row m-tile)."""
+    torch.manual_seed(100 + epi)
+    M = 6 * 257
+    A = torch.randn(M, K, device=DEV).half()
+    W = (torch.randn(N, K, device=DEV) * 0.1).half()
+    bias = torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV) if epi == 2 else None
+    ref = _ref(epi, A, W, bias, res)
+    tol = 2e-3 * float(ref.abs().max()) if epi in (0, 1) else 2e-4 * float(ref.abs().max())
+    for variant in (257, 0):
+        out = _run(epi, A, W, bias, res, variant)
+        assert not torch.isnan(out.float()).any()
+        err = (out.float() - ref).abs()
+        assert float(err.max()) < tol, f"variant {variant}: worst row {int(err.max(1).values.argmax())} (class rows are 256 mod 257)"
+
+
 def test_gemm_identity_detects_layout_bugs():
     """A = I (padded) with an asymmetric W returns W^T rows exactly: row/col swaps or fragment permutations show up."""
     K = N = 256
@@ -59,7 +77,7 @@ def test_gemm_identity_detects_layout_bugs():
     A[K:2 * K] = A[:K] * 2
     W = (torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) % 251 - 125).half()
     bias = torch.zeros(N, device=DEV)
-    for variant in (-1, 4, 8, 106, 108):
+    for variant in (-1, 6, 8):
         out = _run(3 if False else 2, A, W, bias, torch.zeros(M, N, device=DEV), variant)
         assert torch.equal(out[:K], W.float().t()) and torch.equal(out[K:2 * K], 2 * W.float().t())
         assert float(out[2 * K:].abs().max()) == 0.0

@@ -42,7 +42,7 @@ def main():  # noqa
         ref = reference(epi, A[:4096], W, bias, res[:4096] if res is not None else None)
         ref_tail = reference(epi, A[-600:], W, bias, res[-600:] if res is not None else None)
         flops = 2.0 * M * N * K
-        for variant in ([-1, 0] if quick else [-1, 6, 7, 8, 106, 108, 0]):
+        for variant in ([-1, 0] if quick else [-1, 6, 8, 257, 0]):
             out = run(epi, A, W, bias, res, M, N, K, variant)
             torch.cuda.synchronize()
             err = float((out[:4096].float() - ref).abs().max()); err2 = float((out[-600:].float() - ref_tail).abs().max())
