@@ -4,131 +4,177 @@
 // softmax(Q K^T / sqrt(dh)) V over N = seq+1 = 257 tokens, heads = contiguous dh-wide slices of the
 // packed in_proj output qkv[row, 0:d | d:2d | 2d:3d].
 //
-// N = 257 fits on chip, so there is no online softmax: K (row-major, XOR-swizzled 16-B slots) and
-// V^T (transposed while staging) for the whole head sit in LDS (~73 KiB at dh = 64 -> 2 WGs/CU);
-// each wave owns 16-query tiles.  Scores are computed TRANSPOSED, S^T = K Q^T
-// (mfma A = K tile, B = Q tile), so a lane holds one query column (q = lane&15) and 4 keys per
-// 16-key tile: the row max / row sum are in-lane reductions plus two xor-shuffles, and the
-// probabilities are already in MFMA B-operand order for O^T = V^T P^T (k index = key, with the
-// 32-key k-block taking keys {tile 2j: g*4..g*4+3, tile 2j+1: g*4..g*4+3} for lane group g -- the
-// V^T fragment is read with the same permutation, so P never moves between lanes).  The output
-// lane owns O[q = lane&15][4 consecutive dh] -> 8-byte row-major stores.
+// N = 257 fits on chip, so there is no online softmax: K and V for the whole head are copied
+// row-major into LDS by 16-byte LDS-DMA (72 KiB at dh = 64 -> 2 WGs/CU) while each wave fetches the Q
+// fragments of all its 16-query tiles into registers.  Scores are computed TRANSPOSED, S^T = K Q^T
+// (mfma A = K tile, B = Q tile): a lane holds one query column (q = lane&15) and 4 keys per 16-key
+// tile, so row max / row sum are in-lane reductions plus two xor-shuffles and the probabilities are
+// already in MFMA B-operand order for O^T = V^T P^T.  The V^T A-operand comes from the hardware
+// transpose read ds_read_b64_tr_b16 straight out of the row-major V image: per 16-lane group, lane i
+// points at V[key0 + i/4][d0 + 4*(i%4) ..+3] and lane c receives V[key0 + 0..3][d0 + c] (probed on
+// gfx950: tools/micro/tr_read.hip).  The 32-key k-block takes keys {tile 2j: g*4..g*4+3, tile 2j+1:
+// g*4..g*4+3} for lane group g on both operands, so P never moves between lanes.  The output lane
+// owns O[q = lane&15][4 consecutive dh] -> 8-byte row-major stores.
+// LDS rows are 2*dh bytes; 16-byte slots are XOR-swizzled (K: conflict-free ds_read_b128; V: with an
+// even mask, so the two slots of a 32-byte tr-read segment stay adjacent) on the DMA source address
+// and on the reads.  The tr reads are inline asm (no builtin), software-pipelined one k-block ahead
+// with counted lgkmcnt waits.
 #include "mb_kernels.h"
 
 namespace mb {
 
 constexpr int ATT_NKT = 18;              // key tiles of 16 -> up to 288 keys
 constexpr int ATT_NP = ATT_NKT * 16;     // padded key count
-constexpr int ATT_KP = 296;              // V^T row pitch in elements: (KP/2) % 64 == 20 -> conflict-free b64 reads
+constexpr int ATT_MAXQT = 5;             // q-tiles per wave: ceil(18 / 4)
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out,
-                                                          int N, int d, int heads, float scale) {
-  constexpr int KROW = DH * 2;           // bytes per K row
-  constexpr int SL = DH / 8;             // 16-byte slots per K row
+                                                          int N, int d, int heads, float scale_log2e) {
+  constexpr int ROW = DH * 2;            // bytes per K / V row
+  constexpr int SL = DH / 8;             // 16-byte slots per row (8 or 4)
   constexpr int KS = DH / 32;            // k-steps of the QK^T MFMA
   constexpr int NT = DH / 16;            // output dh tiles
-  __shared__ __attribute__((aligned(16))) char smem[ATT_NP * KROW + DH * ATT_KP * 2];
+  constexpr int RPI = 64 / SL;           // rows covered by one 1 KiB DMA instruction (8 or 16)
+  constexpr int NINST = ATT_NP / RPI;    // DMA instructions per operand (36 or 18)
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_NP * ROW];
   char* Ks = smem;
-  uint32_t* Vt32 = (uint32_t*)(smem + ATT_NP * KROW);
-  const char* Vt = smem + ATT_NP * KROW;
+  char* Vs = smem + ATT_NP * ROW;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sq = blockIdx.x / heads, h = blockIdx.x - sq * heads;
   const size_t rs = (size_t)3 * d;                                   // qkv row stride (elements)
   const h16* base = qkv + (size_t)sq * N * rs + h * DH;
 
-  auto kswz = [](int row, int s) { return SL == 8 ? (s ^ ((row >> 1) & 7)) : (s ^ ((row >> 2) & 3)); };
+  auto kswz = [](int row) { return SL == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
+  auto vswz = [](int row) { return SL == 8 ? (((row >> 1) & 3) << 1) : (((row >> 1) & 1) << 1); };
 
-  // ---- stage K: [key][dh] row-major, zero-filled beyond N
-  for (int c = tid; c < ATT_NP * SL; c += 256) {
-    const int row = c / SL, p = c - row * SL;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < N) v = *(const uint4*)(base + (size_t)row * rs + d + kswz(row, p) * 8);
-    *(uint4*)(Ks + row * KROW + p * 16) = v;
+  // ---- stage K and V by LDS-DMA: instruction j covers rows [j*RPI, (j+1)*RPI); rows >= N re-read row N-1
+  for (int j = wave; j < NINST; j += 4) {
+    const int row = j * RPI + lane / SL, p = lane % SL;
+    const h16* src = base + (size_t)min(row, N - 1) * rs;
+    MB_GLDS16(src + d + (p ^ kswz(row)) * 8, Ks + j * 1024);
+    MB_GLDS16(src + 2 * d + (p ^ vswz(row)) * 8, Vs + j * 1024);
   }
-  // ---- stage V^T: Vt[dh][key]; each item = (key pair j, 8-wide dh slice) -> 8 packed 32-bit writes
-  constexpr int NPAIR = ATT_NP / 2;
-  for (int it = tid; it < NPAIR * SL; it += 256) {
-    const int sl = it / NPAIR, j = it - sl * NPAIR;
-    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
-    if (2 * j < N) r0 = *(const uint4*)(base + (size_t)(2 * j) * rs + 2 * d + sl * 8);
-    if (2 * j + 1 < N) r1 = *(const uint4*)(base + (size_t)(2 * j + 1) * rs + 2 * d + sl * 8);
-    const uint32_t a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = sl * 8 + 2 * e;
-      Vt32[(c * ATT_KP) / 2 + j] = (a[e] & 0xffffu) | (b[e] << 16);
-      Vt32[((c + 1) * ATT_KP) / 2 + j] = (a[e] >> 16) | (b[e] & 0xffff0000u);
-    }
-  }
-  __syncthreads();
-
+  // ---- Q fragments of every q-tile this wave owns (in flight together with the DMA)
   const int l15 = lane & 15, g = lane >> 4;
   const int nqt = (N + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    // ---- Q fragments straight from global (each element is used once per workgroup)
-    const int qrow = min(qt * 16 + l15, N - 1);
-    h16x8 qf[KS];
+  h16x8 qf[ATT_MAXQT][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qrow * rs + (ks * 4 + g) * 8);
+  for (int i = 0; i < ATT_MAXQT; ++i) {
+    const int qrow = min((wave + 4 * i) * 16 + l15, N - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[i][ks] = *(const h16x8*)(base + (size_t)qrow * rs + (ks * 4 + g) * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
+  // per-lane constant parts of the fragment addresses
+  const int koff = l15 * ROW;                                       // K fragment: row kt*16 + l15
+  const int vrow = g * 4 + (l15 >> 2), vchunk = (l15 & 3) * 8;      // V tr-read: row key0 + g*4 + i/4, 8-byte chunk i%4
+  const unsigned vbase = (unsigned)(uintptr_t)Vs;
+  // address of the tr-read for key tile `kt` and dh tile `nt`
+  auto vaddr = [&](int kt, int nt) {
+    const int r = kt * 16 + vrow;
+    return vbase + r * ROW + ((((nt * 32 + vchunk) >> 4) ^ vswz(r)) << 4) + (vchunk & 8);
+  };
+
+#pragma unroll
+  for (int i = 0; i < ATT_MAXQT; ++i) {
+    const int qt = wave + 4 * i;
+    if (qt >= nqt) break;
     // ---- S^T tiles: s[kt][r] = S[q = l15][key = kt*16 + g*4 + r]
     f32x4 s[ATT_NKT];
 #pragma unroll
     for (int kt = 0; kt < ATT_NKT; ++kt) {
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int row = kt * 16 + l15;
+      if (kt == ATT_NKT - 1 && kt * 16 >= N) continue;      // the padding tile holds no key at N = 257
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const h16x8 kf = *(const h16x8*)(Ks + row * KROW + kswz(row, ks * 4 + g) * 16);
-        s[kt] = MB_MFMA_16x16x32(kf, qf[ks], s[kt]);
+        const h16x8 kf = *(const h16x8*)(Ks + kt * 16 * ROW + koff + (((ks * 4 + g) ^ kswz(row)) * 16));
+        s[kt] = MB_MFMA_16x16x32(kf, qf[i][ks], s[kt]);
       }
       if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound the fragment prefetch depth (VGPR budget)
     }
-    // ---- softmax over keys (fp32)
+    // ---- softmax over keys (fp32); only the last two key tiles can hold keys >= N
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < ATT_NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        s[kt][r] = key < N ? s[kt][r] : -INFINITY;
+        if (kt >= ATT_NKT - 2) s[kt][r] = (kt * 16 + g * 4 + r < N) ? s[kt][r] : -INFINITY;
         mx = fmaxf(mx, s[kt][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * scale_log2e;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < ATT_NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf((s[kt][r] - mx) * scale);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale_log2e, -mxs));   // exp((s - max)/sqrt(dh)); arg <= 0: bare v_exp_f32
         s[kt][r] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    float inv = 1.0f / sum;
+    asm volatile("" : "+v"(inv));          // every cross-lane op of the softmax has retired before the asm LDS reads start
 
-    // ---- O^T = V^T P^T
+    // ---- O^T = V^T P^T ; V^T fragments by transpose reads, one k-block ahead
     f32x4 o[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Two named register sets alternate (never copied: an asm load's destination must not be touched by
+    // compiler-generated moves before the counted wait that covers it).
+    uint2 va[NT][2], vb[NT][2];
+    auto issue = [&](uint2 (&dst)[NT][2], int kb) {
 #pragma unroll
-    for (int kb = 0; kb < ATT_NKT / 2; ++kb) {
+      for (int nt = 0; nt < NT; ++nt) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[nt][0]) : "v"(vaddr(2 * kb, nt)) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[nt][1]) : "v"(vaddr(2 * kb + 1, nt)) : "memory");
+      }
+    };
+    auto consume = [&](uint2 (&cur)[NT][2], int kb, bool more_in_flight) {
+      // `more_in_flight`: the 2*NT reads of the next k-block were issued after `cur`'s and may stay outstanding
+      if constexpr (NT == 4) {
+        if (more_in_flight)
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[1][0]), "+v"(cur[1][1]),
+                       "+v"(cur[2][0]), "+v"(cur[2][1]), "+v"(cur[3][0]), "+v"(cur[3][1])::"memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[1][0]), "+v"(cur[1][1]),
+                       "+v"(cur[2][0]), "+v"(cur[2][1]), "+v"(cur[3][0]), "+v"(cur[3][1])::"memory");
+      } else {
+        if (more_in_flight)
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[1][0]), "+v"(cur[1][1])::"memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[1][0]), "+v"(cur[1][1])::"memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const f32x4 p0 = s[2 * kb], p1 = s[2 * kb + 1];
       const h16x8 pf = {to_h(p0[0]), to_h(p0[1]), to_h(p0[2]), to_h(p0[3]),
                          to_h(p1[0]), to_h(p1[1]), to_h(p1[2]), to_h(p1[3])};
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const char* vr = Vt + (size_t)(nt * 16 + l15) * (ATT_KP * 2) + (kb * 32 + g * 4) * 2;
-        const h16x4 v0 = *(const h16x4*)vr;
-        const h16x4 v1 = *(const h16x4*)(vr + 32);
-        const h16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o[nt] = MB_MFMA_16x16x32(vf, pf, o[nt]);
+        const u32x4 raw = {cur[nt][0].x, cur[nt][0].y, cur[nt][1].x, cur[nt][1].y};
+        o[nt] = MB_MFMA_16x16x32(__builtin_bit_cast(h16x8, raw), pf, o[nt]);
       }
-      if (kb % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int NKB = ATT_NKT / 2;
+    issue(va, 0);
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb += 2) {
+      if (kb + 1 < NKB) issue(vb, kb + 1);
+      consume(va, kb, kb + 1 < NKB);
+      if (kb + 1 < NKB) {
+        if (kb + 2 < NKB) issue(va, kb + 2);
+        consume(vb, kb + 1, kb + 2 < NKB);
+      }
     }
     // ---- o[nt][r] = O[q = l15][dh = nt*16 + g*4 + r]
     const int q = qt * 16 + l15;
@@ -144,10 +190,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const h16* __restrict
 
 void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads) {
   const int dh = d / heads;
-  const float scale = 1.0f / sqrtf((float)dh);
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   dim3 grid(nb * heads), block(256);
-  if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, scale);
-  else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, scale);
+  if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, scale_log2e);
+  else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, scale_log2e);
 }
 
 }  // namespace mb
