@@ -36,7 +36,7 @@ struct ConvArgs {
   int B, H, W, Cin, Cout, Cout_pad;
 };
 
-__device__ __forceinline__ float silu(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int NI, int WN, int KS, bool UP, bool FINAL>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {

@@ -21,6 +21,15 @@
 // half-tile of K-tile t+1 or t+2 -- so data is in flight for 3..6 phases (>= 2000 clk) before use.
 // Visibility: each wave waits for its own DMA share before the barrier that precedes the first
 // reader's phase ("GEMM hazards").
+//
+// Persistent: a workgroup walks tiles b, b+G, b+2G, ... (G = grid = #CUs).  When a tile's K loop ends, the
+// DMA of the NEXT tile's first two K-tiles is issued first, then the epilogue arithmetic runs in place on the
+// accumulators (bias, residual, GELU) while that DMA is in flight, then `vmcnt(0)` + barrier, and only then
+// the output stores are issued -- they drain behind the next tile's first two K-tiles (the first counted
+// wait that covers them is in K-tile 1).  Output bursts of all CUs are otherwise fully exposed: measured
+// 9 / 17 / 34 us per tile (fp16 / GELU / fp32+residual epilogue) next to a 26 us K = 1024 main loop.
+#include <algorithm>
+
 #include "mb_kernels.h"
 
 namespace mb {
@@ -34,6 +43,9 @@ namespace mb {
 template <int MT, int EPI, int XP = 0, bool SEQ = false>   // XP (experiments): 1 = DMA only, 2 = no DMA in the main loop
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
+  // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
+  // inside the K loop): those GEMMs run one tile per workgroup, everything else walks the tile list persistently.
+  constexpr bool PERSIST = EPI != EPI_RES_F32;
   constexpr int AUX = 0;   // DMA cache policy: default beats nt (-14 %) and sc1 (-6 %) here, sc0 is equal (measured)
   constexpr int BM = 32 * MT, MH = MT / 2;
   constexpr int AH_ROWS = BM / 2;
@@ -49,82 +61,74 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int grp = wave >> 2;
   const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
+  const int K = a.K, nk = K / 64;
+  const int ntiles = tiles_m * tiles_n;
 
-  const int L = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int sr = L / (8 * tiles_n);
-  const int rows_sr = min(8, tiles_m - sr * 8);
-  const int rem = L - sr * 8 * tiles_n;
-  const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
-  const int m0 = tm * TILE_ROWS, n0 = tn * 256;
-  const int K = a.K;
-
-  // ---- DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
-  uint32_t offA[2][2], offB[2][2];      // element offsets into A / W
-  int dstA[2], dstB[2];                 // byte offset of the instruction inside its half-tile buffer
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int ja = min(wave + 8 * j, A_INSTR - 1);     // surplus slot re-loads the last chunk (uniform vmcnt)
-    const int hra = ja * 8 + (lane >> 3);
-    const int wms = hra / (8 * MT), r = hra - wms * (8 * MT);
-    const int slot_a = (lane & 7) ^ ((hra >> 1) & 7);
-    dstA[j] = ja * 1024;
-    const int jb = wave + 8 * j;
-    const int hrb = jb * 8 + (lane >> 3);
-    const int wns = hrb >> 5, c = hrb & 31;
-    const int slot_b = (lane & 7) ^ ((hrb >> 1) & 7);
-    dstB[j] = jb * 1024;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int gm = min(m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
-      offA[h][j] = (uint32_t)gm * (uint32_t)K + slot_a * 8;
-      const int gn = min(n0 + wns * 64 + h * 32 + c, a.N - 1);
-      offB[h][j] = (uint32_t)gn * (uint32_t)K + slot_b * 8;
-    }
-  }
-  // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
-  const uint32_t offX = (uint32_t)min(m0 + 256, a.M - 1) * (uint32_t)K + ((lane & 7) ^ (((lane >> 3) >> 1) & 7)) * 8;
-  auto dma_x = [&](int t) {
-    if (SEQ && wave == 7) MB_GLDS16_AUX(a.A + offX + t * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
+  // ---- per-tile DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
+  struct Plan {
+    uint32_t offA[2][2], offB[2][2], offX;   // element offsets into A / W
+    int m0, n0;
   };
-  auto dma_a = [&](int t, int h) {
+  int dstA[2], dstB[2];                       // byte offset of the instruction inside its half-tile buffer
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { dstA[j] = min(wave + 8 * j, A_INSTR - 1) * 1024; dstB[j] = (wave + 8 * j) * 1024; }
+  auto make_plan = [&](int vb, Plan& p) {
+    int lane_o = lane;                                 // opaque copy: keeps the plan's lane arithmetic from being hoisted
+    asm volatile("" : "+v"(lane_o));                   // out of the tile loop and held in VGPRs across the K loop
+    const int L = xcd_remap(vb, ntiles);              // XCD-contiguous chunks; inside, 8 x tiles_n super-rows
+    const int sr = L / (8 * tiles_n);
+    const int rows_sr = min(8, tiles_m - sr * 8);
+    const int rem = L - sr * 8 * tiles_n;
+    const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
+    p.m0 = tm * TILE_ROWS; p.n0 = tn * 256;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ja = min(wave + 8 * j, A_INSTR - 1);   // surplus slot re-loads the last chunk (uniform vmcnt)
+      const int hra = ja * 8 + (lane_o >> 3);
+      const int wms = hra / (8 * MT), r = hra - wms * (8 * MT);
+      const int slot_a = (lane_o & 7) ^ ((hra >> 1) & 7);
+      const int hrb = (wave + 8 * j) * 8 + (lane_o >> 3);
+      const int wns = hrb >> 5, c = hrb & 31;
+      const int slot_b = (lane_o & 7) ^ ((hrb >> 1) & 7);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gm = min(p.m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
+        p.offA[h][j] = (uint32_t)gm * (uint32_t)K + slot_a * 8;
+        const int gn = min(p.n0 + wns * 64 + h * 32 + c, a.N - 1);
+        p.offB[h][j] = (uint32_t)gn * (uint32_t)K + slot_b * 8;
+      }
+    }
+    // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
+    p.offX = (uint32_t)min(p.m0 + 256, a.M - 1) * (uint32_t)K + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
+  };
+  auto dma_x = [&](const Plan& p, int t) {
+    if (SEQ && wave == 7) MB_GLDS16_AUX(a.A + p.offX + t * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
+  };
+  auto dma_a = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + h * AH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.A + offA[h][j] + t * 64, buf + dstA[j], AUX);
+    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.A + p.offA[h][j] + t * 64, buf + dstA[j], AUX);
   };
-  auto dma_b = [&](int t, int h) {
+  auto dma_b = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.W + offB[h][j] + t * 64, buf + dstB[j], AUX);
+    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.W + p.offB[h][j] + t * 64, buf + dstB[j], AUX);
+  };
+  // all of K-tiles 0 and 1 of a tile (both LDS parities must be free)
+  auto prologue = [&](const Plan& p) {
+    dma_x(p, 0); dma_a(p, 0, 0); dma_b(p, 0, 0); dma_b(p, 0, 1); dma_a(p, 0, 1);
+    if (nk > 1) { dma_a(p, 1, 0); dma_b(p, 1, 1); dma_a(p, 1, 1); dma_b(p, 1, 0); dma_x(p, 1); }
   };
 
   // ---- fragment read offsets inside a half-tile (rows 128 B, slot swizzled with (row>>1)&7)
-  int foff[2];
+  int foff[2], xoffe[2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) foff[ks] = l15 * 128 + (((ks * 4 + g) ^ (l15 >> 1)) * 16);
+  for (int ks = 0; ks < 2; ++ks) {
+    foff[ks] = l15 * 128 + (((ks * 4 + g) ^ (l15 >> 1)) * 16);
+    xoffe[ks] = 2 * AH_BYTES + 2 * BH_BYTES + (l15 & 7) * 128 + (((ks * 4 + g) ^ ((l15 & 7) >> 1)) * 16);
+  }
   const int xbase = wm * (8 * MT) * 128;              // this wave's rows inside an A half-tile
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
-
-  f32x4 acc[4][MT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  h16x8 xa[MH][2], wb[2][2];
-  f32x4 acce[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // SEQ: class row x this wave row's 2 n-tiles
-  int xoffe[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) xoffe[ks] = 2 * AH_BYTES + 2 * BH_BYTES + (l15 & 7) * 128 + (((ks * 4 + g) ^ ((l15 & 7) >> 1)) * 16);
-
-  const int nk = K / 64;
-  // ---- prologue: all of K-tile 0, plus the two half-tiles of K-tile 1 that no phase of tile 0 stages
-  dma_x(0); dma_a(0, 0); dma_b(0, 0); dma_b(0, 1); dma_a(0, 1);
-  if (nk > 1) {
-    dma_a(1, 0); dma_b(1, 1); dma_x(1);
-    if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind
 
 #define MB_LOAD_A(H)                                                                            \
   if (XP != 1) _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
@@ -145,85 +149,184 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();
 
-  for (int t = 0; t < nk; ++t) {
-    const char* par = smem + (t & 1) * PAR_BYTES;
-    const bool n1 = XP != 2 && t + 1 < nk, n2 = XP != 2 && t + 2 < nk;
-    // ---- phase 0: quadrant (A0, B0); refill A1 of the other parity with K-tile t+1
-    MB_LOAD_A(0) MB_LOAD_B(0)
-    h16x8 xe[2];
-    if (SEQ && wm == 0) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
-    if (n1) dma_a(t + 1, 1);
-    MB_SYNC_L()
-    if (SEQ && wm == 0) {
+  Plan cur;
+  int vb = blockIdx.x;
+  make_plan(vb, cur);
+  prologue(cur);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // K-tiles 0 and 1 of the first tile are in LDS for everyone
+
+  while (true) {
+    f32x4 acc[4][MT];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[n][ks], xe[ks], acce[n]);
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acce[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // SEQ: class row x this wave row's 2 n-tiles
+    h16x8 xa[MH][2], wb[2][2];
+
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
+    for (int t = 0; t < nk; ++t) {
+      const char* par = smem + (t & 1) * PAR_BYTES;
+      // K-tile t+1 is staged by phases 0/1 (except K-tile 1: part of the prologue), K-tile t+2 by phases 2/3
+      const bool n1 = XP != 2 && t >= 1 && t + 1 < nk, n2 = XP != 2 && t + 2 < nk;
+      // ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0]; refill A1 of the other parity
+      MB_LOAD_A(0) MB_LOAD_B(0)
+      h16x8 xe[2];
+      if (SEQ && wm == 0) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
+      if (n1) dma_a(cur, t + 1, 1);
+      MB_SYNC_L()
+      if (SEQ && wm == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[n][ks], xe[ks], acce[n]);
+      }
+      MB_MMA(0, 0)
+      // ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill B0 of the other parity
+      MB_LOAD_B(1)
+      if (SEQ && wm == 1) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
+      if (n1) dma_b(cur, t + 1, 0);
+      MB_SYNC_L()
+      if (SEQ && wm == 1) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[n][ks], xe[ks], acce[n]);
+      }
+      MB_MMA(0, 1)
+      // ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2
+      MB_LOAD_A(1)
+      if (n2) dma_a(cur, t + 2, 0);
+      MB_SYNC_L() MB_MMA(1, 1)
+      // ---- phase 3: (A1, B0); refill B1 (and X) of this parity with K-tile t+2; K-tile t+1 must have landed.
+      // In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output
+      // stores stay in flight until the wait of K-tile 1.
+      MB_LOAD_B(0)
+      if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); }
+      if (t >= 1 || XP == 2) {
+        if (n2) {
+          if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      MB_SYNC_L() MB_MMA(1, 0)
     }
-    MB_MMA(0, 0)
-    // ---- phase 1: (A0, B1); refill B0 of the other parity with K-tile t+1
-    MB_LOAD_B(1)
-    if (SEQ && wm == 1) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
-    if (n1) dma_b(t + 1, 0);
-    MB_SYNC_L()
-    if (SEQ && wm == 1) {
+    if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the two groups
+
+    // ---- next tile: start its first two K-tiles NOW (all LDS is free), so they fly during the epilogue math
+    const int nvb = vb + gridDim.x;
+    const bool has_next = PERSIST && nvb < ntiles;
+    Plan nxt;
+    if (has_next) { make_plan(nvb, nxt); prologue(nxt); }
+
+    // ---- epilogue: acc[nt][mt] holds out[m][n..n+3] (m = ..+l15, n = ..+g*4); wave rows: half h = mt / MH, tile i = mt % MH.
+    // Row r = MT is the class-token row of a sequence-aligned tile (valid in lanes l15 == 0 only).
+    // Pass 1 (arithmetic, in place): + bias (+ residual, fetched one m-tile ahead of its use) (+ GELU).
+    // Pass 2 (after the DMA wait): stores; fp16 results of two neighbouring n-tiles are exchanged between lane
+    // rows g and g^1 with v_permlane16_swap so that a lane stores 8 consecutive columns (16 B; the tail is issue-bound).
+    const float* __restrict__ resp = a.residual;
+    float* __restrict__ out32 = a.out_f32;
+    h16* __restrict__ out16 = a.out_h16;
+    const int m0 = cur.m0, n0 = cur.n0;
+    constexpr int NROWS = SEQ ? MT + 1 : MT;
+    int l15e = l15, ge = g;                              // opaque copies (see make_plan): no per-row address tables
+    asm volatile("" : "+v"(l15e), "+v"(ge));             // carried in VGPRs through the main loop
+    auto row_of = [&](int r) { return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256; };
+    auto col_of = [&](int r, int nt) {
+      return r < MT ? n0 + wn * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + ge * 4 : n0 + wn * 64 + wm * 32 + nt * 16 + ge * 4;
+    };
+    auto row_ok = [&](int r) { return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : l15e == 0; };
+    {
+      float4 bias4[4];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int nt = 0; nt < 4; ++nt) bias4[nt] = *(const float4*)(a.bias + col_of(0, nt));
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[n][ks], xe[ks], acce[n]);
+      for (int r = 0; r < NROWS; ++r) {
+        const int nn = r < MT ? 4 : 2;
+#pragma unroll
+        for (int nt = 0; nt < nn; ++nt) {
+          f32x4& c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
+          const float4 b = r < MT ? bias4[nt] : bias4[wm * 2 + (nt & 1)];
+          c[0] += b.x; c[1] += b.y; c[2] += b.z; c[3] += b.w;
+          if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = gelu_erf(c[e]);
+          }
+        }
+      }
     }
-    MB_MMA(0, 1)
-    // ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2
-    MB_LOAD_A(1)
-    if (n2) dma_a(t + 2, 0);
-    MB_SYNC_L() MB_MMA(1, 1)
-    // ---- phase 3: (A1, B0); refill B1 of this parity with K-tile t+2; all of K-tile t+1 must have landed
-    MB_LOAD_B(0)
-    if (n2) {
-      dma_b(t + 2, 1); dma_x(t + 2);
-      if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MB_SYNC_L() MB_MMA(1, 0)
+    // the next tile's first K-tiles must be in LDS before anyone reads them; nothing of THIS tile is stored yet
+    if (has_next) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    float4 resv[2][4];                 // fp32+residual epilogue: residual rows are fetched one row ahead of their use
+    auto fetch_res = [&](int r, float4 (&dst)[4]) {
+      if (EPI == EPI_RES_F32) {
+        const uint32_t rb = (uint32_t)min(row_of(r), a.M - 1) * (uint32_t)a.N;      // clamped: always a legal address
+#pragma unroll
+        for (int nt = 0; nt < (r < MT ? 4 : 2); ++nt) dst[nt] = *(const float4*)((const char*)resp + (size_t)((rb + (uint32_t)col_of(r, nt)) * 4u));
+      }
+    };
+    fetch_res(0, resv[0]);
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r) {
+      if (r + 1 < NROWS) fetch_res(r + 1, resv[(r + 1) & 1]);
+      const bool ok = row_ok(r);
+      const int nn = r < MT ? 4 : 2;
+      if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
+#pragma unroll
+        for (int pr = 0; pr < nn / 2; ++pr) {
+          const f32x4 ca = r < MT ? acc[2 * pr][r < MT ? r : 0] : acce[0];
+          const f32x4 cb = r < MT ? acc[2 * pr + 1][r < MT ? r : 0] : acce[1];
+          const h16x2 ta0 = {to_h(ca[0]), to_h(ca[1])}, ta1 = {to_h(ca[2]), to_h(ca[3])};
+          const h16x2 tb0 = {to_h(cb[0]), to_h(cb[1])}, tb1 = {to_h(cb[2]), to_h(cb[3])};
+          // swap: lane rows with odd g of the first operand <-> even g of the second (16-lane rows)
+          const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta0), __builtin_bit_cast(uint32_t, tb0), false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta1), __builtin_bit_cast(uint32_t, tb1), false, false);
+          // even g: 8 columns of n-tile 2pr starting at (g/2)*8;  odd g: the same 8 columns of n-tile 2pr+1
+          if (ok) {
+            const int n = col_of(r, 2 * pr + (ge & 1)) - (ge & 1) * 4;
+            *(uint4*)((char*)out16 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)n) * 2u)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+        }
+      } else if (ok) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (nt < nn) {
+            f32x4 c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
+            if (EPI == EPI_RES_F32) {
+              const float4 rr = resv[r & 1][nt];
+              c[0] += rr.x; c[1] += rr.y; c[2] += rr.z; c[3] += rr.w;
+            }
+            *(float4*)((char*)out32 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)col_of(r, nt)) * 4u)) = make_float4(c[0], c[1], c[2], c[3]);
+          }
+      }
+    }
+    if (!has_next) break;
+    cur = nxt;
+    vb = nvb;
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();          // balance the barrier count of the two groups
 #undef MB_LOAD_A
 #undef MB_LOAD_B
 #undef MB_SYNC_L
 #undef MB_MMA
+}
 
-  // ---- epilogue: acc[nt][mt] holds out[m][n..n+3]; wave rows: half h = mt / MH, tile i = mt % MH
-  auto emit = [&](int m, int n, const f32x4& v) {
-    const float4 b = *(const float4*)(a.bias + n);
-    float v0 = v[0] + b.x, v1 = v[1] + b.y, v2 = v[2] + b.z, v3 = v[3] + b.w;
-    if (EPI == EPI_RES_F32) {
-      const float4 r = *(const float4*)(a.residual + (size_t)m * a.N + n);
-      v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
-    }
-    if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
-      v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
-    }
-    if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
-      *(h16x4*)(a.out_h16 + (size_t)m * a.N + n) = h16x4{to_h(v0), to_h(v1), to_h(v2), to_h(v3)};
-    } else {
-      *(float4*)(a.out_f32 + (size_t)m * a.N + n) = make_float4(v0, v1, v2, v3);
-    }
-  };
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + wm * (16 * MT) + (mt / MH) * (8 * MT) + (mt % MH) * 16 + l15;
-    if (m >= (SEQ ? m0 + 256 : a.M)) continue;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) emit(m, n0 + wn * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + g * 4, acc[nt][mt]);
+static int num_cu_cached() {
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (num_cu <= 0) num_cu = 256;
   }
-  if (SEQ && l15 == 0) {                       // class-token row: wave row wm owns the B-half wm of its 64 columns
-#pragma unroll
-    for (int n = 0; n < 2; ++n) emit(m0 + 256, n0 + wn * 64 + wm * 32 + n * 16 + g * 4, acce[n]);
-  }
+  return num_cu;
 }
 
 template <int MT, int EPI, int XP = 0, bool SEQ = false>
-static void launch_ht(hipStream_t s, const GemmArgs& a) {
+static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) {
   constexpr int BM = 32 * MT;
   constexpr int LDS = 2 * (BM * 128 + 2 * 128 * 128 + (SEQ ? 1024 : 0));
   static bool configured = false;
@@ -232,28 +335,26 @@ static void launch_ht(hipStream_t s, const GemmArgs& a) {
     configured = true;
   }
   const int tiles_m = SEQ ? a.M / 257 : (a.M + BM - 1) / BM, tiles_n = a.N / 256;
-  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ>), dim3(tiles_m * tiles_n), dim3(512), LDS, s, a, tiles_m, tiles_n);
+  const int grid = (EPI != EPI_RES_F32 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
+  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.M >= 512 &&
-         (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32);
+         (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
+         (uint64_t)a.M * a.N * 4 < (1ull << 32);      // 32-bit element / byte offsets inside the kernel
 }
 
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
+  bool persistent = true;
+  if (mt >= 1000) { persistent = false; mt -= 1000; }   // A/B: one tile per workgroup
   if (mt == 16) { launch_ht<6, EPI_RES_F32, 1>(s, a); return; }   // ablations (see tools/xp_gemm.py)
   if (mt == 26) { launch_ht<6, EPI_RES_F32, 2>(s, a); return; }
   if (mt == 18) { launch_ht<8, EPI_RES_F32, 1>(s, a); return; }
   if (mt == 28) { launch_ht<8, EPI_RES_F32, 2>(s, a); return; }
   if (mt != 6 && mt != 8 && mt != 257) {
     // pick the tile height that wastes fewer CU-rounds (one workgroup per CU)
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
-      if (num_cu <= 0) num_cu = 256;
-    }
+    const int num_cu = num_cu_cached();
     auto cost = [&](int m) {
       const long tiles = (long)((a.M + 32 * m - 1) / (32 * m)) * (a.N / 256);
       return (double)((tiles + num_cu - 1) / num_cu) * 32 * m * (m == 8 ? 1.0 : 1.04);
@@ -266,9 +367,9 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
   }
 #define MB_HT_CASE(E)                                                      \
   case E:                                                                  \
-    if (mt == 257) launch_ht<8, E, 0, true>(s, a);                         \
-    else if (mt == 8) launch_ht<8, E>(s, a);                               \
-    else launch_ht<6, E>(s, a);                                            \
+    if (mt == 257) launch_ht<8, E, 0, true>(s, a, persistent);             \
+    else if (mt == 8) launch_ht<8, E>(s, a, persistent);                   \
+    else launch_ht<6, E>(s, a, persistent);                                \
     break;
   switch (epi) {
     MB_HT_CASE(EPI_H16) MB_HT_CASE(EPI_GELU_H16) MB_HT_CASE(EPI_RES_F32) MB_HT_CASE(EPI_GELU_F32)

@@ -51,7 +51,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // erf with |abs err| < 2e-7 (Abramowitz-Stegun 7.1.26); used by the erf-GELU epilogue.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // 1-ulp v_rcp_f32 (the IEEE divide is 11 instructions)
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
