@@ -28,6 +28,8 @@
 // the output stores are issued -- they drain behind the next tile's first two K-tiles (the first counted
 // wait that covers them is in K-tile 1).  Output bursts of all CUs are otherwise fully exposed: measured
 // 9 / 17 / 34 us per tile (fp16 / GELU / fp32+residual epilogue) next to a 26 us K = 1024 main loop.
+// (Tried and rejected: starting the CUs 1/4 tile apart to de-synchronise those bursts -- slower by the delay itself,
+// i.e. the epilogue is bound per CU, not by aggregate HBM bandwidth.)
 #include <algorithm>
 
 #include "mb_kernels.h"
