@@ -130,13 +130,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MB_BENCH_FORCE_DEVICE / MB_BENCH_BACKEND exist only to exercise the N>1 code path on a 1-GPU box
+    # (tests/test_hip_bench.py: two ranks share cuda:0 over gloo); the driver's runs use one GPU per rank over RCCL.
+    dev_index = int(os.environ.get("MB_BENCH_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MB_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from maskbit_amd import ConvVQModel, LFQBert, _lib
     from maskbit_amd.parallel import gather_images
@@ -180,7 +187,7 @@ def main():
         prof = _lib.prof_read()
         _lib.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
@@ -199,10 +206,18 @@ def main():
             achieved = gemm_flops[dom] / (ms / calls * 1e-3) / 1e12
             fam_flops = sum(gemm_flops[k] * prof[k][0] for k in gemm_flops if k in prof)
             fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
-            roofline = {"bound": "mfma", "kernel": f"gemm_tn_kernel ({dom}: M={M}, N={4096 if dom == 'gemm_ffn_up' else (3072 if dom == 'gemm_qkv' else 1024)}, "
+            traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.*), if present
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if B == B_PER_GPU:
+                    traffic = pmc[dom.replace("gemm_", "")]["hbm_bytes_corrected"]
+            except Exception:
+                pass
+            roofline = {"bound": "mfma", "kernel": f"gemm_ht_kernel ({dom}: M={M}, N={4096 if dom == 'gemm_ffn_up' else (3072 if dom == 'gemm_qkv' else 1024)}, "
                                                    f"K={4096 if dom == 'gemm_ffn_down' else 1024})",
                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                        "traffic": None, "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
+                        "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_traffic.md)",
+                        "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
                         "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
                         "end_to_end_frac": value / world * (2 * NUM_STEPS * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
         cpu = None

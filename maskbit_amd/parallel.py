@@ -40,6 +40,8 @@ def gather_images(local: torch.Tensor, group=None) -> torch.Tensor:
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:          # test-only path: gloo collectives on host copies
+        return gather_images(local.cpu(), group).to(local.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
     sizes = [int(s.item()) for s in sizes]

@@ -1,0 +1,47 @@
+"""GPU tests of bench.py's contract: one JSON line with the driver's fields, and the N>1 launch path
+(two ranks sharing the one visible GPU over gloo -- the real runs use one GPU per rank over RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _json_line(out: str):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["unit"] == "images/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"] + 1e-9
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "workload" in d["config"]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MB_BENCH_FORCE_DEVICE="0", MB_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-prof"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"] + 1e-9
