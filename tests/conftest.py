@@ -14,6 +14,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # libmaskbit_hip.so is a build artefact (git-ignored): compile it if this checkout has none yet (hipcc cross-compiles
+    # gfx950 without a GPU).  If that is impossible the tests that need it fail loudly -- there is no fallback.
+    try:
+        from maskbit_amd import build as mb_build
+        if mb_build.needs_build():
+            mb_build.build()
+    except Exception as e:  # noqa: BLE001
+        print(f"[conftest] could not build libmaskbit_hip.so: {e}", file=sys.stderr)
 
 
 def pytest_collection_modifyitems(config, items):
