@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
         v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
       }
       if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
-        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+        const f32x2 g01 = gelu_erf2((f32x2){v0, v1}), g23 = gelu_erf2((f32x2){v2, v3});
+        v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y;
       }
       if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
         h16x4 o = {to_h(v0), to_h(v1), to_h(v2), to_h(v3)};

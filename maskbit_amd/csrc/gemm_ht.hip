@@ -117,10 +117,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.W + p.offB[h][j] + t * 64, buf + dstB[j], AUX);
   };
   // all of K-tiles 0 and 1 of a tile (both LDS parities must be free)
-  auto prologue = [&](const Plan& p) {
-    dma_x(p, 0); dma_a(p, 0, 0); dma_b(p, 0, 0); dma_b(p, 0, 1); dma_a(p, 0, 1);
-    if (nk > 1) { dma_a(p, 1, 0); dma_b(p, 1, 1); dma_a(p, 1, 1); dma_b(p, 1, 0); dma_x(p, 1); }
+  // (nk >= 2 is a precondition of this kernel: gemm_ht_supported)
+  auto prologue_rest = [&](const Plan& p) {            // 16 instructions per wave
+    dma_a(p, 0, 0); dma_b(p, 0, 0); dma_b(p, 0, 1); dma_a(p, 0, 1);
+    dma_a(p, 1, 0); dma_b(p, 1, 1); dma_a(p, 1, 1); dma_b(p, 1, 0);
   };
+  auto prologue = [&](const Plan& p) { dma_x(p, 0); dma_x(p, 1); prologue_rest(p); };
 
   // ---- fragment read offsets inside a half-tile (rows 128 B, slot swizzled with (row>>1)&7)
   int foff[2], xoffe[2];
@@ -216,17 +218,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the two groups
 
-    // ---- next tile: start its first two K-tiles NOW (all LDS is free), so they fly during the epilogue math
-    const int nvb = vb + gridDim.x;
-    const bool has_next = PERSIST && nvb < ntiles;
-    Plan nxt;
-    if (has_next) { make_plan(nvb, nxt); prologue(nxt); }
-
-    // ---- epilogue: acc[nt][mt] holds out[m][n..n+3] (m = ..+l15, n = ..+g*4); wave rows: half h = mt / MH, tile i = mt % MH.
-    // Row r = MT is the class-token row of a sequence-aligned tile (valid in lanes l15 == 0 only).
-    // Pass 1 (arithmetic, in place): + bias (+ residual, fetched one m-tile ahead of its use) (+ GELU).
-    // Pass 2 (after the DMA wait): stores; fp16 results of two neighbouring n-tiles are exchanged between lane
-    // rows g and g^1 with v_permlane16_swap so that a lane stores 8 consecutive columns (16 B; the tail is issue-bound).
     const float* __restrict__ resp = a.residual;
     float* __restrict__ out32 = a.out_f32;
     h16* __restrict__ out16 = a.out_h16;
@@ -239,22 +230,49 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       return r < MT ? n0 + wn * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + ge * 4 : n0 + wn * 64 + wm * 32 + nt * 16 + ge * 4;
     };
     auto row_ok = [&](int r) { return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : l15e == 0; };
-    {
-      float4 bias4[4];
+    // ---- next tile: start its first two K-tiles NOW (all LDS is free), so they fly during the epilogue math.
+    // The bias of THIS tile is fetched in between by inline-asm loads the compiler does not track: vmcnt retires in
+    // order, so one counted wait for "everything but the 16 DMA instructions issued after them" releases the bias
+    // while that DMA is still flying (the class-row DMA of wave 7 goes first to keep the count uniform).
+    const int nvb = vb + gridDim.x;
+    const bool has_next = PERSIST && nvb < ntiles;
+    Plan nxt;
+    if (has_next) { make_plan(nvb, nxt); dma_x(nxt, 0); dma_x(nxt, 1); }
+    f32x4 bias4[4], bcls[2];           // bcls: class-token row (indexing bias4 by wave id would put the array in scratch)
+#define MB_LDG16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bias4[nt] = *(const float4*)(a.bias + col_of(0, nt));
+    for (int nt = 0; nt < 4; ++nt) MB_LDG16(bias4[nt], a.bias + col_of(0, nt));
+    if (SEQ) { MB_LDG16(bcls[0], a.bias + col_of(MT, 0)); MB_LDG16(bcls[1], a.bias + col_of(MT, 1)); }
+    else { bcls[0] = bias4[0]; bcls[1] = bias4[1]; }
+#undef MB_LDG16
+    if (has_next) prologue_rest(nxt);
+    {
+      // ONE asm statement with the registers tied through it (separate per-case waits made the compiler copy the
+      // still-in-flight registers ahead of the wait): no next tile -> nothing was issued after the bias -> vmcnt(0).
+      const int hn = __builtin_amdgcn_readfirstlane(has_next ? 1 : 0);
+      asm volatile("s_cmp_lg_u32 %[hn], 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n1:\n\ts_waitcnt vmcnt(16)"
+                   : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]), "+v"(bcls[0]), "+v"(bcls[1])
+                   : [hn] "s"(hn) : "memory", "scc");
+    }
+
+    // ---- epilogue: acc[nt][mt] holds out[m][n..n+3] (m = ..+l15, n = ..+g*4); wave rows: half h = mt / MH, tile i = mt % MH.
+    // Row r = MT is the class-token row of a sequence-aligned tile (valid in lanes l15 == 0 only).
+    // Pass 1 (arithmetic, in place): + bias (+ residual, fetched one m-tile ahead of its use) (+ GELU).
+    // Pass 2 (after the DMA wait): stores; fp16 results of two neighbouring n-tiles are exchanged between lane
+    // rows g and g^1 with v_permlane16_swap so that a lane stores 8 consecutive columns (16 B; the tail is issue-bound).
+    {
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
         const int nn = r < MT ? 4 : 2;
 #pragma unroll
         for (int nt = 0; nt < nn; ++nt) {
           f32x4& c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
-          const float4 b = r < MT ? bias4[nt] : bias4[wm * 2 + (nt & 1)];
-          c[0] += b.x; c[1] += b.y; c[2] += b.z; c[3] += b.w;
+          c += r < MT ? bias4[nt] : bcls[nt & 1];
           if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c[e] = gelu_erf(c[e]);
+            const f32x2 lo = gelu_erf2((f32x2){c[0], c[1]}), hi = gelu_erf2((f32x2){c[2], c[3]});
+            c[0] = lo.x; c[1] = lo.y; c[2] = hi.x; c[3] = hi.y;
           }
+          asm volatile("" : "+v"(c));   // pin: the arithmetic stays ABOVE the DMA wait below (it is what hides that latency)
         }
       }
     }
@@ -342,7 +360,7 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
-  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.M >= 512 &&
+  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && a.M >= 512 &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
          (uint64_t)a.M * a.N * 4 < (1ull << 32);      // 32-bit element / byte offsets inside the kernel
 }

@@ -49,17 +49,26 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // erf with |abs err| < 2e-7 (Abramowitz-Stegun 7.1.26); used by the erf-GELU epilogue.
-__device__ __forceinline__ float fast_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // 1-ulp v_rcp_f32 (the IEEE divide is 11 instructions)
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = 1.0f - p * t * __expf(-ax * ax);
-  return copysignf(r, x);
+// Exact-erf GELU on a pair of values with packed fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32: two lanes-worth per issue).
+// gelu(x) = x*Phi(x) = max(x,0) - |x| * erfc(|x|/sqrt2)/2, and erfc(a) = t*P(t)*exp(-a^2) with t = 1/(1 + 0.3275911 a)
+// (Abramowitz-Stegun 7.1.26, |err| < 1.5e-7); the 1/2 and the 1/sqrt2 are folded into the constants. Writing the
+// negative branch as -|x|*erfc/2 also avoids the 1-(1-e) cancellation of the textbook 0.5*x*(1+erf) form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const float a0 = fabsf(x.x), a1 = fabsf(x.y);
+  const f32x2 t = {__builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, a0, 1.0f)),
+                   __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, a1, 1.0f))};
+  f32x2 p = __builtin_elementwise_fma(t, (f32x2)(0.5f * 1.061405429f), (f32x2)(-0.5f * 1.453152027f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * 1.421413741f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(-0.5f * 0.284496736f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * 0.254829592f));
+  p = p * t;
+  const f32x2 w = (x * x) * (f32x2)(-0.5f * 1.4426950408889634f);          // -a^2 * log2(e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const f32x2 h = p * e;                                                    // erfc(|x|/sqrt2)/2
+  return (f32x2){fmaf(-a0, h.x, fmaxf(x.x, 0.0f)), fmaf(-a1, h.y, fmaxf(x.y, 0.0f))};
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x}).x; }
 
 // XCD-aware bijective remap: hardware places block b on XCD b%8; give every XCD a contiguous
 // chunk of the logical tile list so neighbouring tiles (sharing an operand panel) share an L2.
