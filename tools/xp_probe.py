@@ -1,4 +1,5 @@
-"""Per-tile timeline of the persistent trunk GEMM (period = -9 makes thread 0 of every workgroup log wall_clock64)."""
+"""Per-tile timeline of the persistent trunk GEMM. Needs the probe build: `patch -p0 < tools/patches/gemm_ht_probe.patch`, rebuild
+(period = -9 then makes thread 0 of every workgroup log wall_clock64 / clock64 into the out_f32 buffer)."""
 import sys, os, time, torch
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
 from gemm_bench import dev, lib, _lib
