@@ -38,6 +38,8 @@ SAMPLER = dict(guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0, r
                mask_schedule_strategy="arccos", softmax_temperature=1.0)      # configs/generator/maskbit_generator_12bit.yaml
 F_SEQ = 162.33e9                        # algorithmic FLOPs per 257-token sequence forward
 F_DEC = 185.97e9                        # per decoded image
+DEC_BYTES_IDEAL = 426e6                  # per decoded image: 213.06 M elements x 2 B
+HBM_PEAK_GBS = 8000.0
 
 
 class Cfg(dict):
@@ -220,6 +222,19 @@ def main():
                         "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
                         "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
                         "end_to_end_frac": value / world * (2 * NUM_STEPS * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
+            # the two other rooflines the north star names: attention core on MFMA, decoder on HBM
+            if "attention" in prof:
+                c_, ms_ = prof["attention"]
+                fl = 2 * B * 16 * 4.0 * 257 * 257 * 64           # QK^T + PV per launch (nb = 2B sequences x 16 heads)
+                roofline["attention"] = {"bound": "mfma", "achieved": fl / (ms_ / c_ * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": fl / (ms_ / c_ * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                         "flops_per_launch": fl, "avg_launch_us": ms_ / c_ * 1e3}
+            if "decode" in prof:
+                c_, ms_ = prof["decode"]
+                by = B * DEC_BYTES_IDEAL                         # ideal-fusion 16-bit NHWC traffic per decode call
+                roofline["decoder"] = {"bound": "hbm", "achieved": by / (ms_ / c_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": by / (ms_ / c_ * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_call": by,
+                                       "mfma_frac": B * F_DEC / (ms_ / c_ * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_call_ms": ms_ / c_}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MB_ABI_VERSION 1
+#define MB_ABI_VERSION 2
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
 typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
@@ -36,6 +36,11 @@ typedef struct {
   int mlp;     /* mlp_dim (multiple of 64)         */
   int seq;     /* (img_size/input_stride)^2 = 256  */
   int nclass;  /* 1000; row nclass = "dropped"     */
+  /* Weight precision of the trunk/head GEMMs (no counterpart in the reference, which is fp32):
+   * 0 = one fp16 value per weight; 1 = "fp16x2": hi + lo fp16 halves of the power-of-two pre-scaled
+   * weight, both multiplied on the MFMA and summed in the fp32 accumulator (weight rounding error
+   * 2^-22 instead of 2^-11; twice the GEMM work).  See DESIGN.md, "Precision". */
+  int weight_split;
 } mb_gen_cfg;
 
 /* ConvDecoder configuration (modeling/modules/autoencoder.py:358-397, configs/tokenizer yaml files). */
@@ -110,6 +115,11 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
  * 1 gelu->fp16, 2 +residual->fp32, 3 gelu->fp32, 4 logits fp32 with every `period`-th row dropped);
  * A, W, out_h16 are fp16 device buffers.  variant: 0 auto, -1 the 128x128 kernel, 6 / 8 the half-tile kernel with
  * 192 / 256-row tiles, 257 its sequence-aligned tiles (M % 257 == 0). */
+/* Split-weight diagnostics: repack W[N,K] fp32 -> dst[N,2K] fp16 (hi | lo) + *scale_out, and the GEMM over such a weight
+ * (K = 2*ka, A is [M,ka]); `tmp` is 4 bytes of device scratch. */
+int mb_split_weights(const float* W, int N, int K, void* dst_h16, float* scale_out, void* tmp, mb_stream stream);
+int mb_gemm_split(int epi, const void* A, const void* W2, const float* bias, const float* residual, float* out_f32, void* out_h16,
+                  int M, int N, int ka, const float* scale, int period, int variant, mb_stream stream);
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
             void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
 int mb_prof_enable(int on);

@@ -11,11 +11,11 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmaskbit_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GenCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass")]
+    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass", "weight_split")]
 
 
 class DecCfg(C.Structure):
@@ -45,6 +45,9 @@ SIGNATURES = {
     "mb_dec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SamplePlan), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mb_split_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mb_gemm_split": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mb_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_void_p]),
     "mb_prof_enable": (C.c_int, [C.c_int]),

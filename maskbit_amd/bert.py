@@ -11,12 +11,15 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional
 
 import torch
 
 from . import _lib
 from .base_model import BaseModel, ParamSpec
+
+DEFAULT_WEIGHT_SPLIT = 0
 
 
 def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int) -> List[ParamSpec]:
@@ -60,6 +63,10 @@ class LFQBert(BaseModel):
         self.hidden_dim, self.depth, self.heads, self.mlp_dim = hidden_dim, depth, heads, mlp_dim
         self.dropout = dropout            # inference only: dropout is the identity in eval mode
         self.use_prenorm = False
+        # GEMM weight precision of the device engine (not a reference argument): 0 = fp16, 1 = fp16 hi+lo pairs ("fp16x2",
+        # twice the GEMM work, weight rounding 2^-22).  Default from MASKBIT_AMD_WEIGHT_SPLIT; may be changed before a call.
+        self.weight_split = int(os.environ.get("MASKBIT_AMD_WEIGHT_SPLIT", str(DEFAULT_WEIGHT_SPLIT)))
+        self._engine_split = None
         self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
         self._build(_generator_specs(hidden_dim, mlp_dim, depth, self.seq_len, self.bits, nclass,
                                      self.splits * self.effective_codebook_size))
@@ -69,7 +76,9 @@ class LFQBert(BaseModel):
 
     # ---- engine hooks ---------------------------------------------------------------------
     def _engine_create(self, capacity: int):
-        cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass)
+        cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass,
+                          int(self.weight_split))
+        self._engine_split = int(self.weight_split)
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
         return h
@@ -83,6 +92,8 @@ class LFQBert(BaseModel):
 
     def engine(self, min_seqs: int):
         """Device engine able to hold ``min_seqs`` sequences (CFG needs 2 x batch)."""
+        if self._engine is not None and self._engine_split != int(self.weight_split):
+            self._drop_engine()                                    # precision mode changed: rebuild and repack
         have = self._engine_key[1] if self._engine_key else 0
         return self._ensure_engine(max(min_seqs, have, 16))
 

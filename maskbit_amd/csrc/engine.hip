@@ -98,6 +98,11 @@ struct mb_gen {
   float *w_in = nullptr, *b_in = nullptr, *class_emb = nullptr, *pos = nullptr, *ln0g = nullptr, *ln0b = nullptr;
   h16 *wl = nullptr, *wp = nullptr;
   float *bl = nullptr, *lnhg = nullptr, *lnhb = nullptr, *bp = nullptr;
+  // split weights (cfg.weight_split): one output scale per GEMM weight [4*layer + {qkv, o, 1, 2}], then wl, wp
+  int split = 0;
+  float* wscale = nullptr;
+  unsigned* split_tmp = nullptr;
+  const float* sc(int idx) const { return split ? wscale + idx : nullptr; }
   // workspace
   float *x_f32 = nullptr, *y_f32 = nullptr;
   h16 *x_h16 = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;
@@ -123,6 +128,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   using namespace mb;
   const mb_gen_cfg& c = g->c;
   const int d = c.hidden, f = c.mlp, N = g->N, M = nb * N;
+  const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   {
     ProfScope p("embed_ln", s);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
@@ -132,22 +138,22 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     { ProfScope p("gemm_qkv", s);
-      gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d, 0}); }
+      gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
     { ProfScope p("attention", s); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
     { ProfScope p("gemm_attn_out", s);
-      gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->x_f32, g->y_f32, nullptr, M, d, d, 0}); }
+      gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->x_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)}); }
     { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_f32, g->x_h16, M, d); }
     { ProfScope p("gemm_ffn_up", s);
-      gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d, 0}); }
+      gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d * ks, 0, d, g->sc(4 * l + 2)}); }
     { ProfScope p("gemm_ffn_down", s);
-      gemm_tn(s, EPI_RES_F32, GemmArgs{g->h, L.w2, L.b2, g->x_f32, g->y_f32, nullptr, M, d, f, 0}); }
+      gemm_tn(s, EPI_RES_F32, GemmArgs{g->h, L.w2, L.b2, g->x_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)}); }
     { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_f32, g->x_h16, M, d); }
   }
   { ProfScope p("gemm_head", s);
-    gemm_tn(s, EPI_GELU_F32, GemmArgs{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d, 0}); }
+    gemm_tn(s, EPI_GELU_F32, GemmArgs{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)}); }
   { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, M, d); }
   { ProfScope p("gemm_head", s);
-    gemm_tn(s, EPI_LOGITS_F32, GemmArgs{g->x_h16, g->wp, g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d, N}); }
+    gemm_tn(s, EPI_LOGITS_F32, GemmArgs{g->x_h16, g->wp, g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)}); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -179,6 +185,25 @@ int mb_prof_read(char* buf, int buflen) {
   return (int)out.size();
 }
 
+int mb_split_weights(const float* W, int N, int K, void* dst_h16, float* scale_out, void* tmp, mb_stream stream) {
+  if (!W || !dst_h16 || !scale_out || !tmp || N <= 0 || K <= 0) return fail(-1, "mb_split_weights: bad arguments");
+  mb::split_f32_to_h16x2((hipStream_t)stream, W, (h16*)dst_h16, N, K, scale_out, (unsigned*)tmp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+int mb_gemm_split(int epi, const void* A, const void* W2, const float* bias, const float* residual, float* out_f32, void* out_h16,
+                  int M, int N, int ka, const float* scale, int period, int variant, mb_stream stream) {
+  if (!A || !W2 || !bias || !scale || epi < 0 || epi > 4) return fail(-1, "mb_gemm_split: bad arguments");
+  if (ka % 64) return fail(-1, "mb_gemm_split: ka must be a multiple of 64");
+  mb::GemmArgs a{(const h16*)A, (const h16*)W2, bias, residual, out_f32, (h16*)out_h16, M, N, 2 * ka, period, ka, scale};
+  ProfScope p("gemm_diag", (hipStream_t)stream);
+  mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // Diagnostic entry: one GEMM of the trunk family on caller buffers (tests and tools/gemm_bench.py).
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
             int M, int N, int K, int period, int variant, mb_stream stream) {
@@ -204,24 +229,27 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (c.seq + 1 > 288) return fail(-1, "seq+1 = %d tokens exceeds the 288-key attention tile", c.seq + 1);
   const int C = 1 << (c.bits / c.splits);
   if (C > 512 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d", C);
+  if (c.weight_split != 0 && c.weight_split != 1) return fail(-1, "weight_split must be 0 or 1");
   mb_gen* g = new mb_gen();
-  g->c = c; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
+  g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
   const size_t d = c.hidden, f = c.mlp, M = (size_t)max_seqs * g->N;
   int rc = 0;
   g->layers.resize(c.depth);
+  const size_t ws = g->split ? 2 : 1;                  // fp16 values per weight
+  rc |= galloc(g, &g->wscale, (size_t)4 * c.depth + 2); rc |= galloc(g, &g->split_tmp, 1);
   for (auto& L : g->layers) {
-    rc |= galloc(g, &L.wqkv, 3 * d * d); rc |= galloc(g, &L.bqkv, 3 * d);
-    rc |= galloc(g, &L.wo, d * d); rc |= galloc(g, &L.bo, d);
-    rc |= galloc(g, &L.w1, f * d); rc |= galloc(g, &L.b1, f);
-    rc |= galloc(g, &L.w2, d * f); rc |= galloc(g, &L.b2, d);
+    rc |= galloc(g, &L.wqkv, ws * 3 * d * d); rc |= galloc(g, &L.bqkv, 3 * d);
+    rc |= galloc(g, &L.wo, ws * d * d); rc |= galloc(g, &L.bo, d);
+    rc |= galloc(g, &L.w1, ws * f * d); rc |= galloc(g, &L.b1, f);
+    rc |= galloc(g, &L.w2, ws * d * f); rc |= galloc(g, &L.b2, d);
     rc |= galloc(g, &L.ln1g, d); rc |= galloc(g, &L.ln1b, d); rc |= galloc(g, &L.ln2g, d); rc |= galloc(g, &L.ln2b, d);
   }
   rc |= galloc(g, &g->w_in, d * c.bits); rc |= galloc(g, &g->b_in, d);
   rc |= galloc(g, &g->class_emb, (size_t)(c.nclass + 1) * d); rc |= galloc(g, &g->pos, (size_t)g->N * d);
   rc |= galloc(g, &g->ln0g, d); rc |= galloc(g, &g->ln0b, d);
-  rc |= galloc(g, &g->wl, d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
-  rc |= galloc(g, &g->wp, (size_t)c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
+  rc |= galloc(g, &g->wl, ws * d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
+  rc |= galloc(g, &g->wp, ws * c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
   rc |= galloc(g, &g->x_f32, M * d); rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->x_h16, M * d);
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
@@ -247,6 +275,7 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   size_t numel = 1;
   for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
   float* dst_f = nullptr; h16* dst_h = nullptr; size_t want = 0;
+  int wrows = 0, wcols = 0, sidx = -1;                 // GEMM weights: [rows, cols] and their output-scale slot
   int l = -1, sub = -1; char rest[96] = {0};
   std::string n(name);
   if (sscanf(name, "transformer.layers.%d.%d.%95s", &l, &sub, rest) == 3) {
@@ -254,16 +283,16 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
     mb_gen::Layer& L = g->layers[l];
     std::string r(rest);
     if (sub == 0) {
-      if (r == "mha.in_proj_weight") { dst_h = L.wqkv; want = 3 * d * d; }
+      if (r == "mha.in_proj_weight") { dst_h = L.wqkv; want = 3 * d * d; wrows = 3 * d; wcols = d; sidx = 4 * l; }
       else if (r == "mha.in_proj_bias") { dst_f = L.bqkv; want = 3 * d; }
-      else if (r == "mha.out_proj.weight") { dst_h = L.wo; want = d * d; }
+      else if (r == "mha.out_proj.weight") { dst_h = L.wo; want = d * d; wrows = d; wcols = d; sidx = 4 * l + 1; }
       else if (r == "mha.out_proj.bias") { dst_f = L.bo; want = d; }
       else if (r == "norm.weight") { dst_f = L.ln1g; want = d; }
       else if (r == "norm.bias") { dst_f = L.ln1b; want = d; }
     } else if (sub == 1) {
-      if (r == "net.0.weight") { dst_h = L.w1; want = f * d; }
+      if (r == "net.0.weight") { dst_h = L.w1; want = f * d; wrows = f; wcols = d; sidx = 4 * l + 2; }
       else if (r == "net.0.bias") { dst_f = L.b1; want = f; }
-      else if (r == "net.2.weight") { dst_h = L.w2; want = d * f; }
+      else if (r == "net.2.weight") { dst_h = L.w2; want = d * f; wrows = d; wcols = f; sidx = 4 * l + 3; }
       else if (r == "net.2.bias") { dst_f = L.b2; want = d; }
       else if (r == "norm.weight") { dst_f = L.ln2g; want = d; }
       else if (r == "norm.bias") { dst_f = L.ln2b; want = d; }
@@ -274,16 +303,17 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   else if (n == "input_proj.bias") { dst_f = g->b_in; want = d; }
   else if (n == "first_layer.0.weight") { dst_f = g->ln0g; want = d; }
   else if (n == "first_layer.0.bias") { dst_f = g->ln0b; want = d; }
-  else if (n == "last_layer.0.weight") { dst_h = g->wl; want = d * d; }
+  else if (n == "last_layer.0.weight") { dst_h = g->wl; want = d * d; wrows = d; wcols = d; sidx = 4 * c.depth; }
   else if (n == "last_layer.0.bias") { dst_f = g->bl; want = d; }
   else if (n == "last_layer.2.weight") { dst_f = g->lnhg; want = d; }
   else if (n == "last_layer.2.bias") { dst_f = g->lnhb; want = d; }
-  else if (n == "prediction_layer.weight") { dst_h = g->wp; want = (size_t)c.splits * g->C * d; }
+  else if (n == "prediction_layer.weight") { dst_h = g->wp; want = (size_t)c.splits * g->C * d; wrows = c.splits * g->C; wcols = d; sidx = 4 * c.depth + 1; }
   else if (n == "prediction_layer.bias") { dst_f = g->bp; want = (size_t)c.splits * g->C; }
   else if (n == "bits_to_indices") return 0;   // derived buffer (bert.py:383-384): recomputed on the device
   if (!dst_f && !dst_h) return fail(-2, "mb_gen_load: unknown checkpoint entry '%s'", name);
   if (numel != want) return fail(-4, "mb_gen_load: '%s' has %zu elements, expected %zu", name, numel, want);
   if (dst_f == g->w_in) mb::transpose_f32(s, data, g->w_in, (int)d, c.bits);       // [d,K] -> [K,d] for the embed kernel
+  else if (dst_h && g->split) mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
   else if (dst_h) mb::cast_f32_to_h16(s, data, dst_h, numel);
   else HIP_TRY(hipMemcpyAsync(dst_f, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   g->loaded++;

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   const int tiles_m = (a.M + BM - 1) / BM;
   const int L = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
-  const int K = a.K;
+  const int K = a.K, KA = a.ka ? a.ka : a.K, nka = KA / BK;
 
   // ---- staging: wave w owns rows [32w, 32w+32) of both tiles; 4 DMA instructions of 8 rows each
   const h16* xsrc[4];
@@ -38,15 +38,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     const int row = wave * 32 + j * 8 + (lane >> 3);
     const int slot = (lane & 7) ^ ((row >> 1) & 7);
     const int mr = min(m0 + row, a.M - 1), nr = min(n0 + row, a.N - 1);
-    xsrc[j] = a.A + (size_t)mr * K + slot * 8;
+    xsrc[j] = a.A + (size_t)mr * KA + slot * 8;
     wsrc[j] = a.W + (size_t)nr * K + slot * 8;
   }
   auto stage = [&](int t, int buf) {
+    const int ta = t < nka ? t : t - nka;          // split weights: A is swept once per weight half
     char* xb = smem + buf * 2 * TILE_BYTES + wave * 32 * 128;
     char* wb = xb + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      MB_GLDS16(xsrc[j] + t * BK, xb + j * 8 * 128);
+      MB_GLDS16(xsrc[j] + ta * BK, xb + j * 8 * 128);
       MB_GLDS16(wsrc[j] + t * BK, wb + j * 8 * 128);
     }
   };
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   }
 
   // ---- epilogue: lane holds out[m][n..n+3], m = ..+(lane&15), n = ..+(lane>>4)*4
+  const float sc = a.scale ? *a.scale : 1.0f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + (lane & 15);
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
       const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
       if (n >= a.N) continue;
       const float4 b = *(const float4*)(a.bias + n);
-      float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
+      float v0 = fmaf(acc[i][j][0], sc, b.x), v1 = fmaf(acc[i][j][1], sc, b.y), v2 = fmaf(acc[i][j][2], sc, b.z), v3 = fmaf(acc[i][j][3], sc, b.w);
       if (EPI == EPI_RES_F32) {
         const float4 r = *(const float4*)(a.residual + (size_t)m * a.N + n);
         v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
@@ -153,6 +155,38 @@ __global__ void cast_kernel(const float* __restrict__ src, h16* __restrict__ dst
 void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n) {
   const int blocks = (int)min((size_t)2048, (n / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(cast_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+}
+
+
+// ---- split-weight repack ----------------------------------------------------------------------
+__global__ void absmax_kernel(const float* __restrict__ src, size_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(src[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+__global__ void split_kernel(const float* __restrict__ src, h16* __restrict__ dst, int N, int K, const unsigned* __restrict__ amax,
+                             float* __restrict__ scale_out) {
+  const float mx = __uint_as_float(*amax);
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);                   // mx = f * 2^e, f in [0.5, 1)
+  const int S = mx > 0.f ? 15 - e : 0;                                   // mx * 2^S in [2^14, 2^15): below the fp16 maximum
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = ldexpf(1.0f, -S);
+  const size_t n = (size_t)N * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / K, k = i - r * K;
+    const float w = ldexpf(src[i], S);
+    const h16 hi = to_h(w);
+    dst[r * 2 * K + k] = hi;
+    dst[r * 2 * K + K + k] = to_h(w - (float)hi);
+  }
+}
+void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K, float* scale_out, unsigned* tmp) {
+  const size_t n = (size_t)N * K;
+  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+  (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
+  hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K, tmp, scale_out);
 }
 
 }  // namespace mb

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
   const int K = a.K, nk = K / 64;
+  const int KA = a.ka ? a.ka : K, nka = KA / 64;      // split weights: A has KA = K/2 columns and is swept twice
   const int ntiles = tiles_m * tiles_n;
 
   // ---- per-tile DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
@@ -95,21 +96,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int gm = min(p.m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
-        p.offA[h][j] = (uint32_t)gm * (uint32_t)K + slot_a * 8;
+        p.offA[h][j] = (uint32_t)gm * (uint32_t)KA + slot_a * 8;
         const int gn = min(p.n0 + wns * 64 + h * 32 + c, a.N - 1);
         p.offB[h][j] = (uint32_t)gn * (uint32_t)K + slot_b * 8;
       }
     }
     // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
-    p.offX = (uint32_t)min(p.m0 + 256, a.M - 1) * (uint32_t)K + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
+    p.offX = (uint32_t)min(p.m0 + 256, a.M - 1) * (uint32_t)KA + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
   };
   auto dma_x = [&](const Plan& p, int t) {
-    if (SEQ && wave == 7) MB_GLDS16_AUX(a.A + p.offX + t * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
+    if (SEQ && wave == 7) MB_GLDS16_AUX(a.A + p.offX + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
   };
   auto dma_a = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + h * AH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.A + p.offA[h][j] + t * 64, buf + dstA[j], AUX);
+    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.A + p.offA[h][j] + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
   };
   auto dma_b = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
@@ -261,13 +262,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     // Pass 2 (after the DMA wait): stores; fp16 results of two neighbouring n-tiles are exchanged between lane
     // rows g and g^1 with v_permlane16_swap so that a lane stores 8 consecutive columns (16 B; the tail is issue-bound).
     {
+      const float osc = a.scale ? *a.scale : 1.0f;          // split weights: undo their power-of-two pre-scale
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
         const int nn = r < MT ? 4 : 2;
 #pragma unroll
         for (int nt = 0; nt < nn; ++nt) {
           f32x4& c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
-          c += r < MT ? bias4[nt] : bcls[nt & 1];
+          c = __builtin_elementwise_fma(c, (f32x4)(osc), r < MT ? bias4[nt] : bcls[nt & 1]);
           if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
             const f32x2 lo = gelu_erf2((f32x2){c[0], c[1]}), hi = gelu_erf2((f32x2){c[2], c[3]});
             c[0] = lo.x; c[1] = lo.y; c[2] = hi.x; c[3] = hi.y;

@@ -21,6 +21,10 @@ struct GemmArgs {
   h16* out_h16;
   int M, N, K;
   int period;           // EPI_LOGITS_F32 only: tokens per sequence incl. the class row
+  // Split-weight ("fp16x2") GEMMs: W rows are [hi(K/2) | lo(K/2)] of a weight pre-scaled by a power of two, A has
+  // ka = K/2 columns and is swept twice, out = acc * (*scale) + bias.  ka = 0 / scale = null: plain GEMM.
+  int ka = 0;
+  const float* scale = nullptr;
 };
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -68,5 +72,8 @@ void combine_groups(hipStream_t s, const int64_t* tokens /*[rows,m]*/, int64_t* 
 
 // ---- fp32 -> h16 repack ------------------------------------------------------------------------
 void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n);
+// W[N,K] fp32 -> dst[N,2K] = [fp16(W*2^S) | fp16(W*2^S - hi)], S chosen from max|W| (tmp: one device uint32 of scratch);
+// *scale_out = 2^-S.  Stream-ordered, no host synchronisation.
+void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K, float* scale_out, unsigned* tmp);
 
 }  // namespace mb

@@ -92,3 +92,51 @@ def test_gemm_logits_epilogue_drops_class_rows():
     out = _run(4, A, W, bias, None, 0, period)
     ref = _ref(4, A, W, bias, None, period)
     assert out.shape == (nb * 256, N) and float((out - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("variant", [-1, 8, 0])
+@pytest.mark.parametrize("epi,M,N,K", [(2, 1028, 512, 1024), (0, 771, 256, 128), (4, 1028, 128, 256)])
+def test_split_weight_gemm(variant, epi, M, N, K):
+    """fp16x2 weights (mb_split_weights + mb_gemm_split): the product must track the fp32 weights, i.e. be far closer to an
+    fp64 reference than the same GEMM with weights rounded once to fp16, and the repack must be exact to ~2^-22."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(epi * 7 + variant)
+    period = 257 if epi == 4 else 0
+    A = torch.randn(M, K, device=DEV).half()
+    W = torch.randn(N, K, device=DEV) * 0.02
+    W[0, 0] = 0.37                                                 # sets the power-of-two scale; most weights are much smaller
+    bias = torch.randn(N, device=DEV) * 0.1
+    res = torch.randn(M, N, device=DEV) if epi == 2 else None
+    W2 = torch.empty(N, 2 * K, device=DEV, dtype=torch.float16)
+    scale = torch.zeros(1, device=DEV)
+    tmp = torch.zeros(1, device=DEV, dtype=torch.int32)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.mb_split_weights(W.data_ptr(), N, K, W2.data_ptr(), scale.data_ptr(), tmp.data_ptr(), st))
+    torch.cuda.synchronize()
+    s = float(scale)
+    assert s == 2.0 ** -16                                          # 0.37 * 2^16 = 24248 in [2^14, 2^15)
+    back = (W2[:, :K].double() + W2[:, K:].double()) * s
+    assert float((back - W.double()).abs().max()) <= 2.0 ** -22 * 0.37
+    rows = M if epi != 4 else (M // period) * (period - 1)
+    out32 = torch.full((rows, N), float("nan"), device=DEV) if epi in (2, 4) else None
+    out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16) if epi == 0 else None
+    _lib.check(lib.mb_gemm_split(epi, A.data_ptr(), W2.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None,
+                                 out32.data_ptr() if out32 is not None else None, out16.data_ptr() if out16 is not None else None,
+                                 M, N, K, scale.data_ptr(), period, variant, st))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t() + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    if epi == 4:
+        ref = ref.reshape(M // period, period, -1)[:, :period - 1].reshape(-1, N)
+    got = (out32 if out32 is not None else out16).double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    if epi == 0:
+        assert err < 4e-3                                           # one fp16 rounding of the result
+    else:
+        single = _run(epi, A, W.half(), bias, res, variant, period).double()
+        err_single = float((single - ref).abs().max())
+        print(f"max err split {err:.2e}  single-fp16 weights {err_single:.2e}")
+        assert err < 2e-5 and err < err_single / 8

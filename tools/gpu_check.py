@@ -149,24 +149,26 @@ def main():
         O.sample_loop(fwd, B, y, num_steps=N, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0,
                       randomize_temperature=8.2, mask_schedule_strategy="arccos", mask_token=64, codebook_splits=2, record=rec)
         print(f"  oracle loop {time.time() - t0:.1f}s on {torch.get_num_threads()} threads", flush=True)
-        tot_m = tot_n = 0
-        for i, r in enumerate(rec):
-            tin = r.tokens_in.to(dev).contiguous()
-            lg = m(torch.cat([tin, tin]), torch.cat([y, y]).to(dev), torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(dev))
-            lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
-            tout = torch.empty_like(tin); pred = torch.empty_like(tin)
-            qn, cn = r.exp_noise.to(dev).contiguous(), r.conf_noise.to(dev).contiguous()
-            k = int(torch.floor(torch.tensor(r.mask_ratio) * 512))
-            _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr(), r.scale, 1.0, qn.data_ptr(), cn.data_ptr(), k, tin.data_ptr(),
-                                          tout.data_ptr(), pred.data_ptr(), B, 256, 2, 64, torch.cuda.current_stream().cuda_stream))
-            torch.cuda.synchronize()
-            msk = r.tokens_in == 64
-            mm = int((pred.cpu() != r.pred)[msk].sum()); nn_ = int(msk.sum())
-            tot_m += mm; tot_n += nn_
-            pmax = torch.softmax(r.logits_c + r.scale * (r.logits_c - r.logits_u), -1).max(-1).values[msk].mean()
-            print(f"  step {i}: scale={r.scale:.3f} masked={nn_} pred mismatch={mm} ({mm / max(nn_, 1):.5f}) remask diff={int((tout.cpu() != r.tokens_out).sum())} "
-                  f"logit err max={float((lc.cpu() - r.logits_c).abs().max()):.3f} mean max-prob={float(pmax):.3f}", flush=True)
-        print(f"[tf_full] teacher-forced token mismatch over masked positions: {tot_m}/{tot_n} = {tot_m / tot_n:.6f}", flush=True)
+        for split in [int(v) for v in os.environ.get("TF_SPLITS", "0").split(",")]:
+            m.weight_split = split
+            tot_m = tot_n = 0
+            for i, r in enumerate(rec):
+                tin = r.tokens_in.to(dev).contiguous()
+                lg = m(torch.cat([tin, tin]), torch.cat([y, y]).to(dev), torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(dev))
+                lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
+                tout = torch.empty_like(tin); pred = torch.empty_like(tin)
+                qn, cn = r.exp_noise.to(dev).contiguous(), r.conf_noise.to(dev).contiguous()
+                k = int(torch.floor(torch.tensor(r.mask_ratio) * 512))
+                _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr(), r.scale, 1.0, qn.data_ptr(), cn.data_ptr(), k, tin.data_ptr(),
+                                              tout.data_ptr(), pred.data_ptr(), B, 256, 2, 64, torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                msk = r.tokens_in == 64
+                mm = int((pred.cpu() != r.pred)[msk].sum()); nn_ = int(msk.sum())
+                tot_m += mm; tot_n += nn_
+                pmax = torch.softmax(r.logits_c + r.scale * (r.logits_c - r.logits_u), -1).max(-1).values[msk].mean()
+                print(f"  step {i}: scale={r.scale:.3f} masked={nn_} pred mismatch={mm} ({mm / max(nn_, 1):.5f}) remask diff={int((tout.cpu() != r.tokens_out).sum())} "
+                      f"logit err max={float((lc.cpu() - r.logits_c).abs().max()):.3f} mean max-prob={float(pmax):.3f}", flush=True)
+            print(f"[tf_full] weight_split={split}: teacher-forced token mismatch over masked positions: {tot_m}/{tot_n} = {tot_m / tot_n:.6f}", flush=True)
         del m
 
     if "time" in what:
