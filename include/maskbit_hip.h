@@ -116,10 +116,15 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
  * A, W, out_h16 are fp16 device buffers.  variant: 0 auto, -1 the 128x128 kernel, 6 / 8 the half-tile kernel with
  * 192 / 256-row tiles, 257 its sequence-aligned tiles (M % 257 == 0). */
 /* Split-weight diagnostics: repack W[N,K] fp32 -> dst[N,2K] fp16 (hi | lo) + *scale_out, and the GEMM over such a weight
- * (K = 2*ka, A is [M,ka]); `tmp` is 4 bytes of device scratch. */
+ * (mb_gemm_ex with K = 2*ka, A is [M,ka]); `tmp` is 4 bytes of device scratch. */
 int mb_split_weights(const float* W, int N, int K, void* dst_h16, float* scale_out, void* tmp, mb_stream stream);
-int mb_gemm_split(int epi, const void* A, const void* W2, const float* bias, const float* residual, float* out_f32, void* out_h16,
-                  int M, int N, int ka, const float* scale, int period, int variant, mb_stream stream);
+int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
+               int M, int N, int K, int ka /*0, or K/2: split weights*/, const float* scale /*split weights*/,
+               const float* ln_stats /*or NULL: residual = LayerNorm(residual rows) from {mean,rstd}[M]*/, const float* ln_g,
+               const float* ln_b, int period, int variant, mb_stream stream);
+/* LayerNorm over rows (modeling/bert.py:69-70,137-139): any of x_f32 / x_h16 / stats ({mean, rstd} per row) may be NULL. */
+int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, float* stats, int M, int d,
+                 mb_stream stream);
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
             void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
 int mb_prof_enable(int on);

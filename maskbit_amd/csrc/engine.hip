@@ -104,7 +104,7 @@ struct mb_gen {
   unsigned* split_tmp = nullptr;
   const float* sc(int idx) const { return split ? wscale + idx : nullptr; }
   // workspace
-  float *x_f32 = nullptr, *y_f32 = nullptr;
+  float *y_f32 = nullptr, *ln_stats = nullptr;       // fp32 residual stream (pre-LayerNorm rows) and {mean, rstd} per row
   h16 *x_h16 = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;
   // loop state for mb_sample
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
@@ -132,7 +132,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   {
     ProfScope p("embed_ln", s);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
-                g->x_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass};
+                g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass};
     embed_ln(s, e);
   }
   for (int l = 0; l < c.depth; ++l) {
@@ -140,18 +140,25 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     { ProfScope p("gemm_qkv", s);
       gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
     { ProfScope p("attention", s); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+    // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
+    // GEMM operand and {mean, rstd}; the next residual GEMM re-derives the normalised rows in its epilogue and updates
+    // y_f32 in place.  (Layer 0's first residual is the embedding LayerNorm output, stored as is by embed_ln.)
     { ProfScope p("gemm_attn_out", s);
-      gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->x_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)}); }
-    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_f32, g->x_h16, M, d); }
+      GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
+      if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
+      gemm_tn(s, EPI_RES_F32, ga); }
+    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
     { ProfScope p("gemm_ffn_up", s);
       gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d * ks, 0, d, g->sc(4 * l + 2)}); }
     { ProfScope p("gemm_ffn_down", s);
-      gemm_tn(s, EPI_RES_F32, GemmArgs{g->h, L.w2, L.b2, g->x_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)}); }
-    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_f32, g->x_h16, M, d); }
+      GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
+      ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
+      gemm_tn(s, EPI_RES_F32, ga); }
+    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
   }
   { ProfScope p("gemm_head", s);
     gemm_tn(s, EPI_GELU_F32, GemmArgs{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)}); }
-  { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, M, d); }
+  { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
   { ProfScope p("gemm_head", s);
     gemm_tn(s, EPI_LOGITS_F32, GemmArgs{g->x_h16, g->wp, g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)}); }
   hipError_t e = hipGetLastError();
@@ -192,13 +199,23 @@ int mb_split_weights(const float* W, int N, int K, void* dst_h16, float* scale_o
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
-int mb_gemm_split(int epi, const void* A, const void* W2, const float* bias, const float* residual, float* out_f32, void* out_h16,
-                  int M, int N, int ka, const float* scale, int period, int variant, mb_stream stream) {
-  if (!A || !W2 || !bias || !scale || epi < 0 || epi > 4) return fail(-1, "mb_gemm_split: bad arguments");
-  if (ka % 64) return fail(-1, "mb_gemm_split: ka must be a multiple of 64");
-  mb::GemmArgs a{(const h16*)A, (const h16*)W2, bias, residual, out_f32, (h16*)out_h16, M, N, 2 * ka, period, ka, scale};
+int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
+               int M, int N, int K, int ka, const float* scale, const float* ln_stats, const float* ln_g, const float* ln_b,
+               int period, int variant, mb_stream stream) {
+  if (!A || !W || !bias || epi < 0 || epi > 4) return fail(-1, "mb_gemm_ex: bad arguments");
+  if (K % 64 || (ka && (ka % 64 || K != 2 * ka || !scale))) return fail(-1, "mb_gemm_ex: K must be a multiple of 64 (and 2*ka with a scale for split weights)");
+  if (ln_stats && (!ln_g || !ln_b || epi != mb::EPI_RES_F32)) return fail(-1, "mb_gemm_ex: LayerNorm residual needs gamma, beta and the fp32+residual epilogue");
+  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period, ka, scale, ln_stats, ln_g, ln_b};
   ProfScope p("gemm_diag", (hipStream_t)stream);
   mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, float* stats, int M, int d,
+                 mb_stream stream) {
+  if (!y || !gamma || !beta || M <= 0 || d <= 0 || d > 2048) return fail(-1, "mb_layernorm: bad arguments");
+  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, stats, M, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -250,7 +267,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   rc |= galloc(g, &g->ln0g, d); rc |= galloc(g, &g->ln0b, d);
   rc |= galloc(g, &g->wl, ws * d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
   rc |= galloc(g, &g->wp, ws * c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
-  rc |= galloc(g, &g->x_f32, M * d); rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->x_h16, M * d);
+  rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->ln_stats, M * 2); rc |= galloc(g, &g->x_h16, M * d);
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
   rc |= galloc(g, &g->tok_a, B * P); rc |= galloc(g, &g->tok_b, B * P); rc |= galloc(g, &g->tok_cfg, B * P);

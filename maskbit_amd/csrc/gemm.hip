@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
       float v0 = fmaf(acc[i][j][0], sc, b.x), v1 = fmaf(acc[i][j][1], sc, b.y), v2 = fmaf(acc[i][j][2], sc, b.z), v3 = fmaf(acc[i][j][3], sc, b.w);
       if (EPI == EPI_RES_F32) {
         const float4 r = *(const float4*)(a.residual + (size_t)m * a.N + n);
-        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+        if (a.ln_stats) {                            // residual = LayerNorm(previous y), re-derived (GemmArgs)
+          const float2 st = *(const float2*)(a.ln_stats + 2 * (size_t)m);
+          const float4 g = *(const float4*)(a.ln_g + n), be = *(const float4*)(a.ln_b + n);
+          v0 += ln_affine(r.x, st.x, st.y, g.x, be.x); v1 += ln_affine(r.y, st.x, st.y, g.y, be.y);
+          v2 += ln_affine(r.z, st.x, st.y, g.z, be.z); v3 += ln_affine(r.w, st.x, st.y, g.w, be.w);
+        } else { v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w; }
       }
       if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
         const f32x2 g01 = gelu_erf2((f32x2){v0, v1}), g23 = gelu_erf2((f32x2){v2, v3});

@@ -283,47 +283,87 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    float4 resv[2][4];                 // fp32+residual epilogue: residual rows are fetched one row ahead of their use
-    auto fetch_res = [&](int r, float4 (&dst)[4]) {
-      if (EPI == EPI_RES_F32) {
-        const uint32_t rb = (uint32_t)min(row_of(r), a.M - 1) * (uint32_t)a.N;      // clamped: always a legal address
+    if (EPI == EPI_RES_F32) {
+      // fp32 + residual: two sweeps over the rows, each covering ONE full 128-byte line per row (n-tiles 2p, 2p+1), the
+      // residual (and, for the LayerNorm form, the row's {mean, rstd}) fetched one row ahead of its use.  With ln_stats the
+      // buffer holds the pre-LayerNorm rows and the normalised residual is re-derived here (GemmArgs); in place is fine:
+      // every element is read and written by the same lane.
+      const bool lnres = a.ln_stats != nullptr;
+      auto finish = [&](f32x4 c, const float4& rr, const float2& st, const f32x4& gm, const f32x4& bt, int r, int nt) {
+        if (lnres) {
+          c[0] += ln_affine(rr.x, st.x, st.y, gm[0], bt[0]); c[1] += ln_affine(rr.y, st.x, st.y, gm[1], bt[1]);
+          c[2] += ln_affine(rr.z, st.x, st.y, gm[2], bt[2]); c[3] += ln_affine(rr.w, st.x, st.y, gm[3], bt[3]);
+        } else { c[0] += rr.x; c[1] += rr.y; c[2] += rr.z; c[3] += rr.w; }
+        *(float4*)((char*)out32 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)col_of(r, nt)) * 4u)) = make_float4(c[0], c[1], c[2], c[3]);
+      };
 #pragma unroll
-        for (int nt = 0; nt < (r < MT ? 4 : 2); ++nt) dst[nt] = *(const float4*)((const char*)resp + (size_t)((rb + (uint32_t)col_of(r, nt)) * 4u));
-      }
-    };
-    fetch_res(0, resv[0]);
+      for (int p = 0; p < 2; ++p) {
+        f32x4 gm[2] = {}, bt[2] = {};
+        if (lnres) {
 #pragma unroll
-    for (int r = 0; r < NROWS; ++r) {
-      if (r + 1 < NROWS) fetch_res(r + 1, resv[(r + 1) & 1]);
-      const bool ok = row_ok(r);
-      const int nn = r < MT ? 4 : 2;
-      if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
+          for (int q = 0; q < 2; ++q) { gm[q] = *(const f32x4*)(a.ln_g + col_of(0, 2 * p + q)); bt[q] = *(const f32x4*)(a.ln_b + col_of(0, 2 * p + q)); }
+        }
+        float4 rv[2][2]; float2 sv[2] = {};
+        auto fetch = [&](int r, float4 (&dst)[2], float2& st) {
+          const uint32_t rowc = (uint32_t)min(row_of(r), a.M - 1);                    // clamped: always a legal address
 #pragma unroll
-        for (int pr = 0; pr < nn / 2; ++pr) {
-          const f32x4 ca = r < MT ? acc[2 * pr][r < MT ? r : 0] : acce[0];
-          const f32x4 cb = r < MT ? acc[2 * pr + 1][r < MT ? r : 0] : acce[1];
-          const h16x2 ta0 = {to_h(ca[0]), to_h(ca[1])}, ta1 = {to_h(ca[2]), to_h(ca[3])};
-          const h16x2 tb0 = {to_h(cb[0]), to_h(cb[1])}, tb1 = {to_h(cb[2]), to_h(cb[3])};
-          // swap: lane rows with odd g of the first operand <-> even g of the second (16-lane rows)
-          const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta0), __builtin_bit_cast(uint32_t, tb0), false, false);
-          const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta1), __builtin_bit_cast(uint32_t, tb1), false, false);
-          // even g: 8 columns of n-tile 2pr starting at (g/2)*8;  odd g: the same 8 columns of n-tile 2pr+1
-          if (ok) {
-            const int n = col_of(r, 2 * pr + (ge & 1)) - (ge & 1) * 4;
-            *(uint4*)((char*)out16 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)n) * 2u)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          for (int q = 0; q < 2; ++q) dst[q] = *(const float4*)((const char*)resp + (size_t)((rowc * (uint32_t)a.N + (uint32_t)col_of(r, 2 * p + q)) * 4u));
+          if (lnres) st = *(const float2*)(a.ln_stats + 2 * (size_t)rowc);
+        };
+        fetch(0, rv[0], sv[0]);
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+          if (r + 1 < MT) fetch(r + 1, rv[(r + 1) & 1], sv[(r + 1) & 1]);
+          if (row_ok(r)) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) finish(acc[2 * p + q][r], rv[r & 1][q], sv[r & 1], gm[q], bt[q], r, 2 * p + q);
           }
         }
-      } else if (ok) {
+      }
+      if (SEQ) {                       // class-token row: this wave row's two n-tiles, lanes l15 == 0
+        f32x4 gm[2] = {}, bt[2] = {};
+        float4 rr[2]; float2 st = {};
+        const uint32_t rowc = (uint32_t)min(row_of(MT), a.M - 1);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          if (nt < nn) {
-            f32x4 c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
-            if (EPI == EPI_RES_F32) {
-              const float4 rr = resv[r & 1][nt];
-              c[0] += rr.x; c[1] += rr.y; c[2] += rr.z; c[3] += rr.w;
+        for (int q = 0; q < 2; ++q) {
+          rr[q] = *(const float4*)((const char*)resp + (size_t)((rowc * (uint32_t)a.N + (uint32_t)col_of(MT, q)) * 4u));
+          if (lnres) { gm[q] = *(const f32x4*)(a.ln_g + col_of(MT, q)); bt[q] = *(const f32x4*)(a.ln_b + col_of(MT, q)); }
+        }
+        if (lnres) st = *(const float2*)(a.ln_stats + 2 * (size_t)rowc);
+        if (row_ok(MT)) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) finish(acce[q], rr[q], st, gm[q], bt[q], MT, q);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NROWS; ++r) {
+        const bool ok = row_ok(r);
+        const int nn = r < MT ? 4 : 2;
+        if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
+#pragma unroll
+          for (int pr = 0; pr < nn / 2; ++pr) {
+            const f32x4 ca = r < MT ? acc[2 * pr][r < MT ? r : 0] : acce[0];
+            const f32x4 cb = r < MT ? acc[2 * pr + 1][r < MT ? r : 0] : acce[1];
+            const h16x2 ta0 = {to_h(ca[0]), to_h(ca[1])}, ta1 = {to_h(ca[2]), to_h(ca[3])};
+            const h16x2 tb0 = {to_h(cb[0]), to_h(cb[1])}, tb1 = {to_h(cb[2]), to_h(cb[3])};
+            // swap: lane rows with odd g of the first operand <-> even g of the second (16-lane rows)
+            const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta0), __builtin_bit_cast(uint32_t, tb0), false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta1), __builtin_bit_cast(uint32_t, tb1), false, false);
+            // even g: 8 columns of n-tile 2pr starting at (g/2)*8;  odd g: the same 8 columns of n-tile 2pr+1
+            if (ok) {
+              const int n = col_of(r, 2 * pr + (ge & 1)) - (ge & 1) * 4;
+              *(uint4*)((char*)out16 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)n) * 2u)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
-            *(float4*)((char*)out32 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)col_of(r, nt)) * 4u)) = make_float4(c[0], c[1], c[2], c[3]);
           }
+        } else if (ok) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            if (nt < nn) {
+              const f32x4 c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
+              *(float4*)((char*)out32 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)col_of(r, nt)) * 4u)) = make_float4(c[0], c[1], c[2], c[3]);
+            }
+        }
       }
     }
     if (!has_next) break;

@@ -70,6 +70,12 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x}).x; }
 
+// LayerNorm affine of one element, written with explicit roundings: the LayerNorm kernel and the GEMM epilogue that
+// re-derives the normalised residual from (y, mean, rstd) must produce the same bits.
+__device__ __forceinline__ float ln_affine(float v, float mean, float rstd, float g, float b) {
+  return __fmaf_rn(__fmul_rn(__fsub_rn(v, mean), rstd), g, b);
+}
+
 // XCD-aware bijective remap: hardware places block b on XCD b%8; give every XCD a contiguous
 // chunk of the logical tile list so neighbouring tiles (sharing an operand panel) share an L2.
 __device__ __forceinline__ int xcd_remap(int b, int nblk) {

@@ -25,14 +25,20 @@ struct GemmArgs {
   // ka = K/2 columns and is swept twice, out = acc * (*scale) + bias.  ka = 0 / scale = null: plain GEMM.
   int ka = 0;
   const float* scale = nullptr;
+  // EPI_RES_F32 with ln_stats != null: `residual` holds the PRE-LayerNorm rows y; the residual that is added is
+  // LayerNorm(y) = (y - mean) * rstd * ln_g + ln_b re-derived from ln_stats[m] = {mean, rstd} (what layernorm_rows
+  // wrote) -- bit-identical to the fp32 rows that kernel would have stored.  out_f32 may alias residual (in place).
+  const float* ln_stats = nullptr;
+  const float* ln_g = nullptr;
+  const float* ln_b = nullptr;
 };
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
 
-// ---- LayerNorm over rows of y[M,d] -> x_f32 (optional) and x_h16 (optional) ---------------------
+// ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, int M, int d);
+                    float* x_f32, h16* x_h16, float* stats, int M, int d);
 
 // ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------
 struct EmbedArgs {

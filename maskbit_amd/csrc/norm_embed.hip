@@ -15,7 +15,7 @@ constexpr int MAXS = 32;  // scalar fallback path: d <= 64 * MAXS = 2048
 template <int NV>
 __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          float eps, float* xo, h16* xb) {
+                                          float eps, float* xo, h16* xb, float* st = nullptr) {
   constexpr bool VEC = NV > 0;
   constexpr int nv = NV;
   float s = 0.f;
@@ -36,14 +36,15 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
     for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; if (c < d) { const float a = sc[q] - mean; ss += a * a; } }
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+  if (st && lane == 0) *(float2*)st = make_float2(mean, rstd);       // for the GEMM epilogue that re-derives these rows
   if (VEC) {
 #pragma unroll
     for (int q = 0; q < nv; ++q) {
       const int c = q * 256 + lane * 4;
       const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
       float4 o;
-      o.x = (v[q].x - mean) * rstd * g.x + b.x; o.y = (v[q].y - mean) * rstd * g.y + b.y;
-      o.z = (v[q].z - mean) * rstd * g.z + b.z; o.w = (v[q].w - mean) * rstd * g.w + b.w;
+      o.x = ln_affine(v[q].x, mean, rstd, g.x, b.x); o.y = ln_affine(v[q].y, mean, rstd, g.y, b.y);
+      o.z = ln_affine(v[q].z, mean, rstd, g.z, b.z); o.w = ln_affine(v[q].w, mean, rstd, g.w, b.w);
       if (xo) *(float4*)(xo + c) = o;
       if (xb) *(h16x4*)(xb + c) = h16x4{to_h(o.x), to_h(o.y), to_h(o.z), to_h(o.w)};
     }
@@ -51,7 +52,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
     for (int q = 0; q < ns; ++q) {
       const int c = lane + q * 64;
       if (c < d) {
-        const float o = (sc[q] - mean) * rstd * gamma[c] + beta[c];
+        const float o = ln_affine(sc[q], mean, rstd, gamma[c], beta[c]);
         if (xo) xo[c] = o;
         if (xb) xb[c] = to_h(o);
       }
@@ -62,7 +63,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* x_f32,
-                                                      h16* x_h16, int M, int d) {
+                                                      h16* x_h16, float* stats, int M, int d) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -76,15 +77,15 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   }
   else     { for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; sc[q] = c < d ? yr[c] : 0.f; } }
   ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
-                 x_h16 ? x_h16 + (size_t)row * d : nullptr);
+                 x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr);
 }
 
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, int M, int d) {
+                    float* x_f32, h16* x_h16, float* stats, int M, int d) {
   dim3 grid((M + 3) / 4), block(256);
-  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, M, d);
-  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, M, d);
-  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, M, d);
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d);
 }
 
 // One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,

@@ -97,7 +97,7 @@ def test_gemm_logits_epilogue_drops_class_rows():
 @pytest.mark.parametrize("variant", [-1, 8, 0])
 @pytest.mark.parametrize("epi,M,N,K", [(2, 1028, 512, 1024), (0, 771, 256, 128), (4, 1028, 128, 256)])
 def test_split_weight_gemm(variant, epi, M, N, K):
-    """fp16x2 weights (mb_split_weights + mb_gemm_split): the product must track the fp32 weights, i.e. be far closer to an
+    """fp16x2 weights (mb_split_weights + mb_gemm_ex): the product must track the fp32 weights, i.e. be far closer to an
     fp64 reference than the same GEMM with weights rounded once to fp16, and the repack must be exact to ~2^-22."""
     from maskbit_amd import _lib
     lib = _lib.load()
@@ -121,9 +121,9 @@ def test_split_weight_gemm(variant, epi, M, N, K):
     rows = M if epi != 4 else (M // period) * (period - 1)
     out32 = torch.full((rows, N), float("nan"), device=DEV) if epi in (2, 4) else None
     out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16) if epi == 0 else None
-    _lib.check(lib.mb_gemm_split(epi, A.data_ptr(), W2.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None,
-                                 out32.data_ptr() if out32 is not None else None, out16.data_ptr() if out16 is not None else None,
-                                 M, N, K, scale.data_ptr(), period, variant, st))
+    _lib.check(lib.mb_gemm_ex(epi, A.data_ptr(), W2.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None,
+                              out32.data_ptr() if out32 is not None else None, out16.data_ptr() if out16 is not None else None,
+                              M, N, 2 * K, K, scale.data_ptr(), None, None, None, period, variant, st))
     torch.cuda.synchronize()
     ref = A.double() @ W.double().t() + bias.double()
     if res is not None:
@@ -140,3 +140,35 @@ def test_split_weight_gemm(variant, epi, M, N, K):
         err_single = float((single - ref).abs().max())
         print(f"max err split {err:.2e}  single-fp16 weights {err_single:.2e}")
         assert err < 2e-5 and err < err_single / 8
+
+
+@pytest.mark.parametrize("variant", [-1, 6, 8, 0])
+@pytest.mark.parametrize("M,N,K", [(1028, 512, 256), (771, 256, 128), (600, 768, 192)])
+def test_layernorm_residual_epilogue(variant, M, N, K):
+    """The fp32+residual GEMM can take the PRE-LayerNorm rows plus {mean, rstd} and re-derive the normalised residual in its
+    epilogue, in place.  It must equal, bit for bit, the plain-residual GEMM fed with the fp32 rows mb_layernorm stores."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M + variant)
+    st = torch.cuda.current_stream().cuda_stream
+    A = torch.randn(M, K, device=DEV).half()
+    W = (torch.randn(N, K, device=DEV) * 0.05).half()
+    bias = torch.randn(N, device=DEV) * 0.1
+    y = torch.randn(M, N, device=DEV) * 1.7 + 0.3
+    g = torch.rand(N, device=DEV) + 0.5
+    b = torch.randn(N, device=DEV) * 0.2
+    x32 = torch.empty_like(y); x16 = torch.empty(M, N, device=DEV, dtype=torch.float16); stats = torch.empty(M, 2, device=DEV)
+    _lib.check(lib.mb_layernorm(y.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-12, x32.data_ptr(), x16.data_ptr(), stats.data_ptr(), M, N, st))
+    torch.cuda.synchronize()
+    ref_ln = torch.nn.functional.layer_norm(y, (N,), g, b, 1e-12)
+    assert float((x32 - ref_ln).abs().max()) < 2e-5
+    assert float((stats[:, 0] - y.mean(1)).abs().max()) < 1e-5
+    assert torch.equal(x16, x32.half())
+    plain = _run(2, A, W, bias, x32, variant)
+    buf = y.clone()                                                   # in place: residual == out
+    _lib.check(lib.mb_gemm_ex(2, A.data_ptr(), W.data_ptr(), bias.data_ptr(), buf.data_ptr(), buf.data_ptr(), None, M, N, K, 0, None,
+                              stats.data_ptr(), g.data_ptr(), b.data_ptr(), 0, variant, st))
+    torch.cuda.synchronize()
+    assert torch.equal(buf, plain)
+    ref = A.float() @ W.float().t() + bias + ref_ln
+    assert float((buf - ref).abs().max()) < 2e-3
