@@ -127,7 +127,7 @@ int mb_layernorm(const float* y, const float* gamma, const float* beta, float ep
                  mb_stream stream);
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
             void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
-int mb_prof_enable(int on);
+int mb_prof_enable(int on); /* 0 off; n >= 1: HIP-event timing of every kernel of every n-th generator forward (and of all other calls) */
 int mb_prof_read(char* buf, int buflen); /* host buffer; writes "name calls total_ms\n" lines */
 
 #ifdef __cplusplus

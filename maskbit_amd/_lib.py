@@ -87,8 +87,9 @@ def check(rc: int, what: str = "") -> None:
         raise RuntimeError(f"{what or 'libmaskbit_hip'} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
-def prof_enable(on: bool) -> None:
-    load().mb_prof_enable(1 if on else 0)
+def prof_enable(on, every: int = 1) -> None:
+    """HIP-event kernel timing on the launch stream; ``every`` = n times the kernels of every n-th generator forward only."""
+    load().mb_prof_enable(max(1, int(every)) if on else 0)
 
 
 def prof_read() -> dict:

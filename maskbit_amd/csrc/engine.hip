@@ -37,6 +37,9 @@ int fail(int code, const char* fmt, ...) {
 // ---- optional per-kernel device timing with HIP events on the launch stream ------------------
 struct Prof {
   bool on = false;
+  int stride = 1, tick = 0;         // generator forwards are sampled: kernels of every `stride`-th forward are timed
+  bool fwd_live = true;
+  void next_forward() { fwd_live = (tick++ % stride) == 0; }
   struct Rec { hipEvent_t a, b; int kind; };
   std::vector<Rec> recs;
   std::vector<std::string> names;
@@ -62,7 +65,7 @@ struct Prof {
 
 struct ProfScope {
   hipStream_t s; bool live; hipEvent_t a, b; int kind;
-  ProfScope(const char* name, hipStream_t st) : s(st), live(g_prof.on) {
+  ProfScope(const char* name, hipStream_t st, bool in_forward = false) : s(st), live(g_prof.on && (!in_forward || g_prof.fwd_live)) {
     if (!live) return;
     kind = g_prof.kind(name);
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -128,38 +131,39 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   using namespace mb;
   const mb_gen_cfg& c = g->c;
   const int d = c.hidden, f = c.mlp, N = g->N, M = nb * N;
+  g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   {
-    ProfScope p("embed_ln", s);
+    ProfScope p("embed_ln", s, true);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass};
     embed_ln(s, e);
   }
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
-    { ProfScope p("gemm_qkv", s);
+    { ProfScope p("gemm_qkv", s, true);
       gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
-    { ProfScope p("attention", s); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
     // GEMM operand and {mean, rstd}; the next residual GEMM re-derives the normalised rows in its epilogue and updates
     // y_f32 in place.  (Layer 0's first residual is the embedding LayerNorm output, stored as is by embed_ln.)
-    { ProfScope p("gemm_attn_out", s);
+    { ProfScope p("gemm_attn_out", s, true);
       GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
-    { ProfScope p("gemm_ffn_up", s);
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
+    { ProfScope p("gemm_ffn_up", s, true);
       gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d * ks, 0, d, g->sc(4 * l + 2)}); }
-    { ProfScope p("gemm_ffn_down", s);
+    { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
   }
-  { ProfScope p("gemm_head", s);
+  { ProfScope p("gemm_head", s, true);
     gemm_tn(s, EPI_GELU_F32, GemmArgs{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)}); }
-  { ProfScope p("layernorm", s); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
-  { ProfScope p("gemm_head", s);
+  { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
+  { ProfScope p("gemm_head", s, true);
     gemm_tn(s, EPI_LOGITS_F32, GemmArgs{g->x_h16, g->wp, g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)}); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
@@ -176,7 +180,7 @@ const char* mb_last_error(void) { return g_err.c_str(); }
 int mb_prof_enable(int on) {
   if (!on) g_prof.drain();
   g_prof.on = on != 0;
-  if (on) { g_prof.acc.clear(); }
+  if (on) { g_prof.acc.clear(); g_prof.stride = on; g_prof.tick = 0; }
   return 0;
 }
 int mb_prof_read(char* buf, int buflen) {

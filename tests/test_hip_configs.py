@@ -70,3 +70,17 @@ def test_baseline_config1_10bit_16steps_nocfg_full_size():
                                       randomize_temperature=10.5, mask_schedule_strategy="arccos")
     print(f"config[1] teacher-forced mismatch {mism:.2e}, mean |logit err| {logit_err:.4f}")
     assert logit_err < 0.03 and mism < 3e-3          # measured 1.5e-3 (fp16 storage; the mismatch is set by the head-gain-12 logit scale)
+
+
+@pytest.mark.timeout(900)
+def test_baseline_config5_14bit_cfg_full_size():
+    """BASELINE configs[4]'s generator (14-bit, C = 128, CFG 5.8, randomize_temperature 10.3) teacher-forced at full size:
+    6 steps of its sampler settings with B = 2 (the CPU oracle bounds the size; the 256-step schedule itself is covered by
+    the schedule goldens).  Same bound as the 12-bit parity test."""
+    cfg = O.GenCfg(bits=14, splits=2)
+    sd = O.make_generator_weights(cfg, seed=102, head_gain=12.0)
+    model = hip_generator(cfg, sd)
+    mism, logit_err = _teacher_forced(cfg, sd, model, 2, 6, torch.tensor([11, 407]), 98, guidance_scale=5.8, guidance_annealing="cosine",
+                                      scale_pow=3.0, randomize_temperature=10.3, mask_schedule_strategy="arccos")
+    print(f"config[4] generator teacher-forced mismatch {mism:.2e}, mean |logit err| {logit_err:.4f}")
+    assert logit_err < 0.03 and mism < 4e-3
