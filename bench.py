@@ -222,6 +222,8 @@ def main():
                         "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_traffic.md)",
                         "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
                         "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
+                        "peak_sustained_measured": {"mfma_tflops": 2090.0, "hbm_read_gbs": 6100.0, "hbm_copy_gbs": 5000.0,
+                                                    "source": "profiles/r01_peaks.md (tools/micro/peaks.hip; shader clock 2.0 GHz under MFMA load)"},
                         "end_to_end_frac": value / world * (2 * NUM_STEPS * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
             # the two other rooflines the north star names: attention core on MFMA, decoder on HBM
             if "attention" in prof:
