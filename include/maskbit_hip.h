@@ -52,6 +52,9 @@ typedef struct {
   int num_channels;    /* 3                                         */
   int channel_mult[8]; /* [1,1,2,2,4]                               */
   int latent_size;     /* token grid side: 16 (=> 256x256 output)   */
+  int build_encoder;   /* 1: also build ConvEncoder (autoencoder.py:230-286) for mb_enc_encode */
+  int sample_with_conv;/* encoder downsampling by stride-2 conv (every shipped config); 0 (avg-pool) is not built */
+  int enc_res_blocks;  /* num_res_blocks of the encoder (num_res_blocks above is the decoder's); 0 = same */
 } mb_dec_cfg;
 
 /* Per-step plan of modeling.modules.sample (modeling/modules/sampling.py:81-124), evaluated on the
@@ -98,6 +101,10 @@ int mb_dec_load(mb_dec* d, const char* name, const float* data, const int64_t* s
 /* tokens int64 [B, n] (K-bit codes) -> img_nchw fp32 [B,3,H,W] unclamped (may be NULL) and/or
  * img_nhwc_u8 uint8 [B,H,W,3] = trunc(clamp(x,0,1)*255) (scripts/eval_maskbit.py:134-135; may be NULL). */
 int mb_dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_nhwc_u8, int B, mb_stream stream);
+/* ---- encoder half: ConvVQModel.encode, modeling/conv_vqgan.py:70-83 (ConvEncoder autoencoder.py:264-286 +
+ * LookupFreeQuantizer sign/pack lookup_free.py:57-62,113-127).  img fp32 [B,C,H,W] -> indices int64 [B, h*w];
+ * zq (+-1 latent, fp32 [B,K,h,w]) and zraw (pre-sign encoder output) may be NULL.  Needs build_encoder = 1. */
+int mb_enc_encode(mb_dec* d, const float* img_nchw, int64_t* indices, float* zq, float* zraw, int B, mb_stream stream);
 
 /* ---- whole loop: modeling.modules.sample, sampling.py:55-136 ------------------------------- *
  * Runs num_steps x (forward [+CFG], step) then combine (factorization.py:7-24) + decode.

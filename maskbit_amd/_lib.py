@@ -21,7 +21,8 @@ class GenCfg(C.Structure):
 class DecCfg(C.Structure):
     _fields_ = [("token_size", C.c_int), ("hidden_channels", C.c_int), ("num_resolutions", C.c_int),
                 ("num_res_blocks", C.c_int), ("num_channels", C.c_int), ("channel_mult", C.c_int * 8),
-                ("latent_size", C.c_int)]
+                ("latent_size", C.c_int), ("build_encoder", C.c_int), ("sample_with_conv", C.c_int),
+                ("enc_res_blocks", C.c_int)]
 
 
 class SamplePlan(C.Structure):
@@ -43,6 +44,7 @@ SIGNATURES = {
     "mb_dec_destroy": (None, [C.c_void_p]),
     "mb_dec_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     "mb_dec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_enc_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SamplePlan), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mb_split_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,15 +1,16 @@
-"""MaskBit tokenizer (decode half) backed by the gfx950 engine.
+"""MaskBit tokenizer (decoder and encoder) backed by the gfx950 engine.
 
 Call surface of the reference's ``modeling.conv_vqgan.ConvVQModel`` (conv_vqgan.py:40-112):
 ``ConvVQModel(config)`` with an attribute-style config (+ ``.get``), the reference's checkpoint keys
 (``encoder.*``, ``decoder.*``, ``quantize.*``), ``decode_tokens(tokens [b, n]) -> image
 [b, 3, H, W]`` float32 unclamped and ``decode(z [b, K, h, w])``.  The decode itself is
-``mb_dec_decode``: NHWC bf16 implicit-GEMM convolutions on MFMA with fused GroupNorm+SiLU
+``mb_dec_decode``: NHWC fp16 implicit-GEMM convolutions on MFMA with fused GroupNorm+SiLU
 prologue, fused nearest-2x upsampling, bias and residual epilogues.
 
-The encoder half (image -> tokens) is stage-I plumbing outside the sampling hot path (SURVEY.md
-8f next-1): its parameters are held so that reference checkpoints load strictly, but
-``encode()`` / ``forward()`` raise until the GPU encoder exists.
+The encoder half (image -> tokens; stage-I plumbing outside the sampling hot path, SURVEY.md 8f
+next-1) runs on the same kernels through ``mb_enc_encode``: ``encode(x) -> (z_quantized,
+result_dict)`` with ``min_encoding_indices`` and ``forward(x) -> (reconstruction, result_dict)``
+(conv_vqgan.py:70-83,114-127), inference only.
 """
 from __future__ import annotations
 
@@ -45,7 +46,7 @@ def _res_block(p: str, cin: int, cout: int) -> List[ParamSpec]:
 
 def _tokenizer_specs(K, hc, mult, R, nrb_enc, nrb_dec, nch, sample_with_conv) -> List[ParamSpec]:
     s: List[ParamSpec] = []
-    # ---- encoder (held for checkpoint compatibility only; autoencoder.py:230-286)
+    # ---- encoder (autoencoder.py:230-286)
     emult = (1,) + tuple(mult)
     s.append(("encoder.conv_in.weight", (hc, nch, 3, 3), "kaiming"))
     c = hc
@@ -99,6 +100,7 @@ class ConvVQModel(BaseModel):
         self.num_res_blocks = int(config.num_res_blocks)
         self.num_res_blocks_decoder = int(_cfg_get(config, "num_res_blocks_decoder", self.num_res_blocks))
         self.num_channels = int(_cfg_get(config, "num_channels", 3))
+        self.sample_with_conv = bool(_cfg_get(config, "sample_with_conv", False))
         self._build(_tokenizer_specs(self.token_size, self.hidden_channels, self.channel_mult, self.num_resolutions,
                                      self.num_res_blocks, self.num_res_blocks_decoder, self.num_channels,
                                      bool(_cfg_get(config, "sample_with_conv", False))))
@@ -119,6 +121,9 @@ class ConvVQModel(BaseModel):
         for i, v in enumerate(self.channel_mult):
             cfg.channel_mult[i] = v
         cfg.latent_size = self._latent_size
+        cfg.sample_with_conv = 1 if self.sample_with_conv else 0
+        cfg.build_encoder = cfg.sample_with_conv               # the avg-pool encoder variant is not built: encode() raises for it
+        cfg.enc_res_blocks = self.num_res_blocks
         h = C.c_void_p()
         _lib.check(_lib.load().mb_dec_create(C.byref(cfg), capacity, C.byref(h)), "mb_dec_create")
         return h
@@ -179,9 +184,40 @@ class ConvVQModel(BaseModel):
         codes = ((z > 0).long() * w).sum(1).reshape(z.shape[0], -1)
         return self._decode_codes(codes.contiguous())
 
-    def encode(self, x):
-        raise NotImplementedError("ConvVQModel.encode is outside the sampling hot path and not built on the GPU yet "
-                                  "(SURVEY.md 8f next-1); the CPU plumbing case is covered by oracle/ in tests")
+    @torch.no_grad()
+    def _encode(self, x: torch.Tensor, want_raw: bool = False):
+        dev = self._require_cuda("encode")
+        if not self.sample_with_conv:
+            raise NotImplementedError("ConvVQModel.encode with sample_with_conv=False (average-pool downsampling) is not built; "
+                                      "every shipped MaskBit tokenizer config downsamples by convolution")
+        if x.dim() != 4 or x.shape[1] != self.num_channels:
+            raise ValueError(f"encode expects [b, {self.num_channels}, H, W], got {tuple(x.shape)}")
+        b, _, H, W = x.shape
+        down = 1 << (self.num_resolutions - 1)
+        if H != W or H % (16 * down):
+            raise ValueError(f"encode expects square images with a side that is a multiple of {16 * down}, got {H}x{W}")
+        side = H // down
+        img = x.to(device=dev, dtype=torch.float32).contiguous()
+        idx = torch.empty((b, side, side), dtype=torch.int64, device=dev)
+        zq = torch.empty((b, self.token_size, side, side), dtype=torch.float32, device=dev)
+        zraw = torch.empty_like(zq) if want_raw else None
+        h = self.engine(b, side)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mb_enc_encode(h, img.data_ptr(), idx.data_ptr(), zq.data_ptr(), zraw.data_ptr() if want_raw else None, b,
+                                                 torch.cuda.current_stream().cuda_stream), "mb_enc_encode")
+        return zq, idx, zraw
 
-    def forward(self, input):
-        raise NotImplementedError("ConvVQModel.forward (encode+decode) needs the encoder half; see encode()")
+    def encode(self, x: torch.Tensor):
+        """ConvVQModel.encode (conv_vqgan.py:70-83): image -> (z_quantized [b,K,h,w] in {-1,+1}, result_dict) with
+        ``min_encoding_indices`` [b,h,w] (lookup_free.py:57-95).  Inference only: the quantizer losses are returned as zeros
+        except the commitment term, which needs the pre-sign latent and is not computed on this path."""
+        zq, idx, _ = self._encode(x)
+        zero = torch.zeros((), device=zq.device)
+        return zq, dict(quantizer_loss=zero, commitment_loss=zero, entropy_loss=zero, per_sample_entropy=zero, avg_entropy=zero,
+                        min_encoding_indices=idx)
+
+    def forward(self, input: torch.Tensor):
+        """ConvVQModel.forward (conv_vqgan.py:114-127): (decode(encode(x)), result_dict)."""
+        zq, result = self.encode(input)
+        codes = result["min_encoding_indices"].reshape(zq.shape[0], -1)
+        return self._decode_codes(codes.contiguous()), result

@@ -41,7 +41,9 @@ __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcp
 template <int NI, int WN, int KS, bool UP, bool FINAL>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
   constexpr int WM = 4 / WN, MJ = TH / WM, BN = WN * NI * 16;
-  constexpr int PAD = KS / 2, HW_ = TW + 2 * PAD, HALO = (TH + 2 * PAD) * HW_, NTAP = KS * KS;
+  // KS = 3: symmetric pad 1.  KS = 2 (the stride-2 Conv2dSame of the encoder, run on a space-to-depth input): no pad before,
+  // one zero row/column after (autoencoder.py:18,31-36: TF "SAME" puts the odd pixel at the bottom/right).
+  constexpr int PAD = (KS - 1) / 2, HW_ = TW + KS - 1, HALO = (TH + KS - 1) * HW_, NTAP = KS * KS;
   constexpr int WT_BYTES = BN * 128;
   __shared__ __attribute__((aligned(16))) char smem[HALO * 128 + 2 * WT_BYTES];
   char* halo = smem;
@@ -258,15 +260,73 @@ __global__ void repack_conv_kernel(const float* __restrict__ w, h16* __restrict_
   }
 }
 
+// ---- encoder half (ConvEncoder, autoencoder.py:230-286; LFQ sign/pack, lookup_free.py:57-62,113-127) -------------
+// image fp32 NCHW -> fp16 NHWC padded to 64 channels
+__global__ void pack_image_kernel(const float* __restrict__ img, h16* __restrict__ out, int B, int C, int H, int W) {
+  const size_t npix = (size_t)B * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * 8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i >> 3; const int slot = (int)(i & 7);
+    const size_t b = p / ((size_t)H * W), yx = p - b * (size_t)H * W;
+    h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (slot == 0)
+      for (int c = 0; c < C && c < 8; ++c) v[c] = to_h(img[(b * C + c) * (size_t)H * W + yx]);
+    *(h16x8*)(out + p * CK + slot * 8) = v;
+  }
+}
+// space-to-depth: x[B,H,W,C] -> y[B,H/2,W/2,4C], channel (py*2+px)*C + c <- pixel (2Y+py, 2X+px)
+__global__ void s2d_kernel(const h16* __restrict__ x, h16* __restrict__ y, int B, int H, int W, int C) {
+  const int c8 = C / 8;
+  const size_t total = (size_t)B * H * W * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int sl = (int)(i % c8); size_t p = i / c8;
+    const int X = (int)(p % W); p /= W; const int Y = (int)(p % H); const size_t b = p / H;
+    const h16x8 v = *(const h16x8*)(x + ((b * H + Y) * W + X) * C + sl * 8);
+    *(h16x8*)(y + (((b * (H / 2) + (Y >> 1)) * (W / 2) + (X >> 1)) * 4 + ((Y & 1) * 2 + (X & 1))) * C + sl * 8) = v;
+  }
+}
+// OIHW 3x3 stride-2 weights -> [tap (by,bx)][Cout_pad][4*Cin] for the 2x2 conv on the space-to-depth input:
+// tap (by,bx), channel (py*2+px)*Cin + ci  <-  w[co][ci][2by+py][2bx+px] (zero where that index is 3)
+__global__ void repack_down_kernel(const float* __restrict__ w, h16* __restrict__ out, int Cout, int Cin, int Cout_pad) {
+  const size_t total = (size_t)4 * Cout_pad * 4 * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % (4 * Cin)); size_t r = i / (4 * Cin);
+    const int co = (int)(r % Cout_pad); const int tap = (int)(r / Cout_pad);
+    const int ci = ch % Cin, pp = ch / Cin, py = pp >> 1, px = pp & 1, by = tap >> 1, bx = tap & 1;
+    const int dy = 2 * by + py, dx = 2 * bx + px;
+    float v = 0.f;
+    if (co < Cout && dy < 3 && dx < 3) v = w[(((size_t)co * Cin + ci) * 3 + dy) * 3 + dx];
+    out[i] = to_h(v);
+  }
+}
+// z[B*h*w, Kp] (fp16 NHWC) -> indices (bit j = z_j > 0, LSB first), optional +-1 latent and raw z as fp32 NCHW
+__global__ void lfq_kernel(const h16* __restrict__ z, int64_t* __restrict__ idx, float* __restrict__ zq, float* __restrict__ zraw,
+                           int B, int HW, int K, int Kp) {
+  const size_t npix = (size_t)B * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = p / HW, yx = p - b * HW;
+    int64_t code = 0;
+    for (int j = 0; j < K; ++j) {
+      const float v = (float)z[p * Kp + j];
+      const bool pos = v > 0.0f;
+      code |= (int64_t)pos << j;
+      if (zq) zq[(b * K + j) * HW + yx] = pos ? 1.0f : -1.0f;
+      if (zraw) zraw[(b * K + j) * HW + yx] = v;
+    }
+    idx[p] = code;
+  }
+}
+
 // ================================================================================================
 struct Conv {
   std::string name; int cin = 0, cout = 0, ks = 3; bool has_bias = false, up = false;
+  bool down = false;       // stride-2 3x3 Conv2dSame, executed as a 2x2 conv on the space-to-depth input (cin_pad = 4*cin)
+  int cout_w = 0;          // output channels in the checkpoint (cout may be rounded up for 8-byte stores)
   int cin_pad = 0, cout_pad = 0;
   h16* w = nullptr; float* b = nullptr;
 };
 struct Norm { std::string name; int c = 0; float *g = nullptr, *b = nullptr; };
 struct ResBlock { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; };
-struct Stage { std::vector<ResBlock> blocks; Conv up; bool has_up = false; };
+struct Stage { std::vector<ResBlock> blocks; Conv up; bool has_up = false; };   // `up`: upsample_conv (decoder) / down_conv (encoder)
 
 }  // namespace mb
 
@@ -277,6 +337,12 @@ struct mb_dec {
   mb::Norm norm_out;
   std::vector<mb::ResBlock> mid;
   std::vector<mb::Stage> up;
+  // encoder half (built when cfg.build_encoder): conv_in, down stages, mid, norm_out, conv_out
+  bool has_enc = false;
+  mb::Conv e_conv_in, e_conv_out;
+  mb::Norm e_norm_out;
+  std::vector<mb::ResBlock> e_mid;
+  std::vector<mb::Stage> e_down;
   h16* buf[3] = {nullptr, nullptr, nullptr};
   h16* z = nullptr;
   float* gn_part = nullptr;
@@ -299,7 +365,7 @@ bool dalloc(mb_dec* d, T** p, size_t n, std::string& err) {
 
 bool init_conv(mb_dec* d, Conv& c, const std::string& name, int cin, int cout, int ks, bool bias, bool up, bool final_,
                std::string& err) {
-  c.name = name; c.cin = cin; c.cout = cout; c.ks = ks; c.has_bias = bias; c.up = up;
+  c.name = name; c.cin = cin; c.cout = cout; c.cout_w = cout; c.ks = ks; c.has_bias = bias; c.up = up;
   c.cin_pad = (cin + CK - 1) / CK * CK;
   c.cout_pad = final_ ? 16 : (cout + 127) / 128 * 128;
   if (!dalloc(d, &c.w, (size_t)ks * ks * c.cout_pad * c.cin_pad, err)) return false;
@@ -328,6 +394,7 @@ void launch_conv(hipStream_t s, const Conv& c, const h16* in, const float2* gn, 
   dim3 grid((unsigned)((size_t)B * (H / TH) * (W / TW) * (c.cout_pad / bn))), block(256);
   if (final_) hipLaunchKernelGGL((conv_kernel<1, 1, 3, false, true>), grid, block, 0, s, a);
   else if (c.ks == 1) hipLaunchKernelGGL((conv_kernel<4, 2, 1, false, false>), grid, block, 0, s, a);
+  else if (c.ks == 2) hipLaunchKernelGGL((conv_kernel<4, 2, 2, false, false>), grid, block, 0, s, a);
   else if (c.up) hipLaunchKernelGGL((conv_kernel<4, 2, 3, true, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((conv_kernel<4, 2, 3, false, false>), grid, block, 0, s, a);
 }
@@ -387,7 +454,7 @@ mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
   int last = top;
   size_t max_elems = 0;
   int res = cfg.latent_size;
-  max_elems = (size_t)res * res * top;
+  max_elems = std::max((size_t)res * res * top, (size_t)d->out_res * d->out_res * (size_t)std::max(CK, hc));
   for (int s = 0; ok && s < R; ++s) {                    // up.0 = coarsest level (autoencoder.py:384-392)
     const int lvl = R - 1 - s;
     const int cin = hc * mult[lvl + 1], cout = hc * mult[lvl];
@@ -409,6 +476,41 @@ mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
   }
   ok = ok && init_norm(d, d->norm_out, "decoder.norm_out", last, err) &&
        init_conv(d, d->conv_out, "decoder.conv_out", last, cfg.num_channels, 3, true, false, true, err);
+  if (ok && cfg.build_encoder) {                          // ConvEncoder (autoencoder.py:230-262): mirrors the decoder top-down
+    if (!cfg.sample_with_conv) { err = "encoder with average-pool downsampling (sample_with_conv = False) is not built"; ok = false; }
+    const int enrb = cfg.enc_res_blocks > 0 ? cfg.enc_res_blocks : cfg.num_res_blocks;
+    std::vector<int> imult{1};
+    imult.insert(imult.end(), cfg.channel_mult, cfg.channel_mult + R);
+    ok = ok && init_conv(d, d->e_conv_in, "encoder.conv_in", cfg.num_channels, hc, 3, false, false, false, err);
+    d->e_down.resize(R);
+    for (int s = 0; ok && s < R; ++s) {
+      const int cin = hc * imult[s], cout = hc * imult[s + 1];
+      Stage& st = d->e_down[s];
+      st.blocks.resize(enrb);
+      int c = cin;
+      for (int r = 0; ok && r < enrb; ++r) {
+        ok = init_block(d, st.blocks[r], "encoder.down." + std::to_string(s) + ".res_blocks." + std::to_string(r), c, cout, err);
+        c = cout;
+      }
+      st.has_up = s < R - 1;
+      if (ok && st.has_up) {                              // DownsamplingStage.down_conv: 3x3, stride 2, bias (autoencoder.py:165)
+        Conv& dc = st.up;
+        dc.name = "encoder.down." + std::to_string(s) + ".down_conv";
+        dc.cin = cout; dc.cout = cout; dc.cout_w = cout; dc.ks = 2; dc.has_bias = true; dc.down = true;
+        dc.cin_pad = 4 * cout; dc.cout_pad = (cout + 127) / 128 * 128;
+        ok = dalloc(d, &dc.w, (size_t)4 * dc.cout_pad * dc.cin_pad, err) && dalloc(d, &dc.b, (size_t)dc.cout_pad, err);
+        if (ok) (void)hipMemset(dc.b, 0, dc.cout_pad * sizeof(float));
+      }
+    }
+    d->e_mid.resize(enrb);
+    for (int r = 0; ok && r < enrb; ++r)
+      ok = init_block(d, d->e_mid[r], "encoder.mid.res_blocks." + std::to_string(r), top, top, err);
+    const int k4 = (cfg.token_size + 3) / 4 * 4;           // stored channel count of z (8-byte stores)
+    ok = ok && init_norm(d, d->e_norm_out, "encoder.norm_out", top, err) &&
+         init_conv(d, d->e_conv_out, "encoder.conv_out", top, k4, 1, true, false, false, err);
+    d->e_conv_out.cout_w = cfg.token_size;
+    d->has_enc = ok;
+  }
   for (int i = 0; ok && i < 3; ++i) ok = dalloc(d, &d->buf[i], (size_t)max_batch * max_elems, err);
   ok = ok && dalloc(d, &d->z, (size_t)max_batch * cfg.latent_size * cfg.latent_size * CK, err) &&
        dalloc(d, &d->gn_part, (size_t)max_batch * GN_MAXCHUNK * 64, err) && dalloc(d, &d->gn_ss, (size_t)max_batch * 4096, err);
@@ -424,7 +526,8 @@ void dec_destroy(mb_dec* d) {
 
 int dec_load(mb_dec* d, const char* name, const float* data, const int64_t* shape, int ndim, hipStream_t s, std::string& err) {
   const std::string n(name);
-  if (n.rfind("encoder.", 0) == 0 || n.rfind("quantize.", 0) == 0) return 0;   // encode half / derived buffers: not on this path
+  if (n.rfind("quantize.", 0) == 0) return 0;                                    // derived buffers
+  if (n.rfind("encoder.", 0) == 0 && !d->has_enc) return 0;                       // encode half not built in this engine
   size_t numel = 1;
   for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
   std::vector<Conv*> convs{&d->conv_in, &d->conv_out};
@@ -435,15 +538,23 @@ int dec_load(mb_dec* d, const char* name, const float* data, const int64_t* shap
   };
   for (auto& rb : d->mid) add_block(rb);
   for (auto& st : d->up) { for (auto& rb : st.blocks) add_block(rb); if (st.has_up) convs.push_back(&st.up); }
+  if (d->has_enc) {
+    convs.push_back(&d->e_conv_in); convs.push_back(&d->e_conv_out); norms.push_back(&d->e_norm_out);
+    for (auto& rb : d->e_mid) add_block(rb);
+    for (auto& st : d->e_down) { for (auto& rb : st.blocks) add_block(rb); if (st.has_up) convs.push_back(&st.up); }
+  }
   for (Conv* c : convs) {
     Conv* hit = nullptr; bool is_bias = false;
     if (!find_conv(*c, n, &hit, &is_bias)) continue;
     if (is_bias) {
-      if (numel != (size_t)c->cout) { err = n + ": wrong bias size"; return -4; }
+      if (numel != (size_t)c->cout_w) { err = n + ": wrong bias size"; return -4; }
       if (hipMemcpyAsync(c->b, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) { err = "copy failed"; return -10; }
+    } else if (c->down) {
+      if (numel != (size_t)c->cout_w * c->cin * 9) { err = n + ": wrong weight size"; return -4; }
+      hipLaunchKernelGGL(repack_down_kernel, dim3(512), dim3(256), 0, s, data, c->w, c->cout_w, c->cin, c->cout_pad);
     } else {
-      if (numel != (size_t)c->cout * c->cin * c->ks * c->ks) { err = n + ": wrong weight size"; return -4; }
-      hipLaunchKernelGGL(repack_conv_kernel, dim3(512), dim3(256), 0, s, data, c->w, c->cout, c->cin, c->ks, c->cout_pad, c->cin_pad);
+      if (numel != (size_t)c->cout_w * c->cin * c->ks * c->ks) { err = n + ": wrong weight size"; return -4; }
+      hipLaunchKernelGGL(repack_conv_kernel, dim3(512), dim3(256), 0, s, data, c->w, c->cout_w, c->cin, c->ks, c->cout_pad, c->cin_pad);
     }
     return 0;
   }
@@ -479,6 +590,39 @@ int dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_n
   }
   launch_gn(s, d, d->norm_out, d->buf[xi], B, res * res);
   launch_conv(s, d->conv_out, d->buf[xi], d->gn_ss, nullptr, nullptr, img_nchw, img_nhwc_u8, B, res, res, true);
+  return 0;
+}
+
+// ConvVQModel.encode (conv_vqgan.py:70-83): image [B,C,H,W] fp32 -> code indices [B, h*w] (+ optional +-1 latent / raw z, fp32 NCHW)
+int enc_encode(mb_dec* d, const float* img, int64_t* indices, float* zq, float* zraw, int B, hipStream_t s, std::string& err) {
+  if (!d->has_enc) { err = "this engine was created without the encoder half (mb_dec_cfg.build_encoder)"; return -1; }
+  if (B <= 0 || B > d->max_batch) { err = "batch outside [1, max_batch]"; return -1; }
+  const mb_dec_cfg& c = d->c;
+  int res = d->out_res;
+  const size_t npix = (size_t)B * res * res;
+  hipLaunchKernelGGL(pack_image_kernel, dim3((unsigned)std::min<size_t>(4096, (npix * 8 + 255) / 256)), dim3(256), 0, s,
+                     img, d->buf[2], B, c.num_channels, res, res);
+  launch_conv(s, d->e_conv_in, d->buf[2], nullptr, nullptr, d->buf[0], nullptr, nullptr, B, res, res, false);
+  int xi = 0;
+  for (auto& st : d->e_down) {
+    for (auto& rb : st.blocks) xi = run_block(s, d, rb, xi, B, res, res);
+    if (st.has_up) {
+      const int t = (xi + 1) % 3, t2 = (xi + 2) % 3;
+      const size_t n8 = (size_t)B * res * res * (st.up.cin / 8);
+      hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)std::min<size_t>(4096, (n8 + 255) / 256)), dim3(256), 0, s, d->buf[xi], d->buf[t], B, res, res,
+                         st.up.cin);
+      res /= 2;
+      launch_conv(s, st.up, d->buf[t], nullptr, nullptr, d->buf[t2], nullptr, nullptr, B, res, res, false);
+      xi = t2;
+    }
+  }
+  for (auto& rb : d->e_mid) xi = run_block(s, d, rb, xi, B, res, res);
+  launch_gn(s, d, d->e_norm_out, d->buf[xi], B, res * res);
+  const int t = (xi + 1) % 3;
+  launch_conv(s, d->e_conv_out, d->buf[xi], d->gn_ss, nullptr, d->buf[t], nullptr, nullptr, B, res, res, false);
+  const size_t np = (size_t)B * res * res;
+  hipLaunchKernelGGL(lfq_kernel, dim3((unsigned)std::min<size_t>(1024, (np + 255) / 256)), dim3(256), 0, s, d->buf[t], indices, zq, zraw, B, res * res,
+                     c.token_size, d->e_conv_out.cout);
   return 0;
 }
 

@@ -396,6 +396,17 @@ int mb_dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* im
   return 0;
 }
 
+int mb_enc_encode(mb_dec* d, const float* img_nchw, int64_t* indices, float* zq, float* zraw, int B, mb_stream stream) {
+  if (!d || !img_nchw || !indices) return fail(-1, "mb_enc_encode: null argument");
+  std::string err;
+  ProfScope p("encode", (hipStream_t)stream);
+  int rc = mb::enc_encode(d, img_nchw, indices, zq, zraw, B, (hipStream_t)stream, err);
+  if (rc) return fail(rc, "mb_enc_encode: %s", err.c_str());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // ================================================================================================
 // whole loop (sampling.py:55-136)
 // ================================================================================================
