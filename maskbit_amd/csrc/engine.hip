@@ -249,7 +249,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (c.heads <= 0 || c.hidden % c.heads || (dh != 32 && dh != 64)) return fail(-1, "hidden/heads must be 32 or 64 (got %d)", dh);
   if (c.seq + 1 > 288) return fail(-1, "seq+1 = %d tokens exceeds the 288-key attention tile", c.seq + 1);
   const int C = 1 << (c.bits / c.splits);
-  if (C > 512 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d", C);
+  if (C > 4096 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d (the fused step kernel holds up to 4096 codes per group)", C);
   if (c.weight_split != 0 && c.weight_split != 1) return fail(-1, "weight_split must be 0 or 1");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;

@@ -109,13 +109,16 @@ __global__ __launch_bounds__(512) void sample_step_kernel(StepArgs a, const int6
 }
 
 int sample_step(hipStream_t s, const StepArgs& a, const int64_t* tokens_in) {
-  if (a.C > 512 || a.P > 8192) return -1;
+  if (a.C > 4096 || a.P > 8192) return -1;
   const size_t shm = (size_t)a.P * 8 + 16 * 4 + 16;
   dim3 grid(a.B), block(512);
   if (a.C <= 64) hipLaunchKernelGGL(sample_step_kernel<1>, grid, block, shm, s, a, tokens_in);
   else if (a.C <= 128) hipLaunchKernelGGL(sample_step_kernel<2>, grid, block, shm, s, a, tokens_in);
   else if (a.C <= 256) hipLaunchKernelGGL(sample_step_kernel<4>, grid, block, shm, s, a, tokens_in);
-  else hipLaunchKernelGGL(sample_step_kernel<8>, grid, block, shm, s, a, tokens_in);
+  else if (a.C <= 512) hipLaunchKernelGGL(sample_step_kernel<8>, grid, block, shm, s, a, tokens_in);
+  else if (a.C <= 1024) hipLaunchKernelGGL(sample_step_kernel<16>, grid, block, shm, s, a, tokens_in);   // single-group codebooks (codebook_splits = 1)
+  else if (a.C <= 2048) hipLaunchKernelGGL(sample_step_kernel<32>, grid, block, shm, s, a, tokens_in);
+  else hipLaunchKernelGGL(sample_step_kernel<64>, grid, block, shm, s, a, tokens_in);
   return 0;
 }
 

@@ -42,18 +42,20 @@ def _teacher_forced(cfg, sd, model, B, N, labels, seed, **kw):
     return bad / tot, max_logit_err
 
 
-@pytest.mark.parametrize("bits", [10, 14, 18])
-def test_other_bit_widths_tiny(bits):
-    """C = 32 (half a wave per row), 128 and 512 (2 / 8 logits per lane); head N = 64 / 256 / 1024."""
-    cfg = O.GenCfg(bits=bits, splits=2, hidden=128, depth=2, heads=4, mlp=256, seq=256, nclass=10)
+@pytest.mark.parametrize("bits,splits", [(10, 2), (14, 2), (18, 2), (12, 4), (12, 3), (8, 1), (10, 1), (12, 1)])
+def test_other_bit_widths_tiny(bits, splits):
+    """splits = 2: C = 32 (half a wave per row), 128 and 512 (2 / 8 logits per lane), head N = 64 / 256 / 1024.
+    Other codebook_splits: 4 groups of C = 8, 3 of 16, and single-group codebooks of 256 / 1024 (the
+    reference's default constructor arguments) / 4096 codes (16 / 64 logits per lane in the step kernel)."""
+    cfg = O.GenCfg(bits=bits, splits=splits, hidden=128, depth=2, heads=4, mlp=256, seq=256, nclass=10)
     sd = O.make_generator_weights(cfg, seed=40 + bits, head_gain=20.0)
     model = hip_generator(cfg, sd)
     g = torch.Generator().manual_seed(bits)
-    toks = torch.randint(0, cfg.group_codes + 1, (3, 256, 2), generator=g)          # includes mask tokens
+    toks = torch.randint(0, cfg.group_codes + 1, (3, 256, splits), generator=g)     # includes mask tokens
     labels = torch.tensor([0, 5, 9])
     out = model(toks.to(DEV), labels.to(DEV), torch.tensor([False, True, False], device=DEV))
     ref = O.lfq_bert_forward(sd, cfg, toks, labels, torch.tensor([False, True, False]))
-    assert out.shape == (3, 256, 2, cfg.group_codes)
+    assert out.shape == (3, 256, splits, cfg.group_codes)
     assert float((out.cpu() - ref).norm() / ref.norm()) < 2e-3
     mism, _ = _teacher_forced(cfg, sd, model, 3, 4, labels, 7, guidance_scale=3.0, guidance_annealing="cosine", scale_pow=2.5,
                               randomize_temperature=7.5, mask_schedule_strategy="arccos")
