@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
   // variant: 0 auto; -1 this 128x128 kernel; 6 / 8 the half-tile kernel with that MT; 257 its sequence-aligned tiles;
   // 16/26 (MT 6) and 18/28 (MT 8): DMA-only / compute-only ablations of the half-tile kernel (timing experiments)
+  if (variant == 4 && gemm_ht_supported(epi, a)) { gemm_w4(s, epi, a); return; }
   if (variant >= 0 && gemm_ht_supported(epi, a)) {
     if (variant % 1000 == 257 && a.M % 257) variant = variant - variant % 1000;
     gemm_ht(s, epi, a, variant);

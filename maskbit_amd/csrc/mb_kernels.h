@@ -35,6 +35,7 @@ struct GemmArgs {
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
+void gemm_w4(hipStream_t s, GemmEpi epi, const GemmArgs& a);   // 4-wave 128x128-per-wave variant (gemm_w4.hip)
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,

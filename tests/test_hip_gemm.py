@@ -172,3 +172,14 @@ def test_layernorm_residual_epilogue(variant, M, N, K):
     assert torch.equal(buf, plain)
     ref = A.float() @ W.float().t() + bias + ref_ln
     assert float((buf - ref).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("epi,M,N,K", [(0, 1300, 512, 256), (1, 1024, 256, 128), (2, 771, 768, 192), (3, 600, 256, 64 * 5)])
+def test_four_wave_variant_matches_half_tile_kernel(epi, M, N, K):
+    """The experimental 4-wave kernel (variant 4) accumulates in the same order: bit-identical to the production kernel."""
+    torch.manual_seed(epi)
+    A = torch.randn(M, K, device=DEV).half()
+    W = (torch.randn(N, K, device=DEV) * 0.05).half()
+    bias = torch.randn(N, device=DEV) * 0.1
+    res = torch.randn(M, N, device=DEV) if epi == 2 else None
+    assert torch.equal(_run(epi, A, W, bias, res, 4), _run(epi, A, W, bias, res, 8))
