@@ -41,6 +41,12 @@ typedef struct {
    * weight, both multiplied on the MFMA and summed in the fp32 accumulator (weight rounding error
    * 2^-22 instead of 2^-11; twice the GEMM work).  See DESIGN.md, "Precision". */
   int weight_split;
+  /* Generator variants of modeling/bert.py: prenorm = use_prenorm (LayerNorm before each sub-layer, raw residual,
+   * norm_after_transformer; bert.py:49-59,106-123,498-499); embed_tables = the `Bert` class (bert.py:184-340): per-group
+   * nn.Embedding(C+1, hidden) inputs summed, output head tied to those tables plus a per-position bias [seq, C].
+   * Checkpoint keys then are tok_emb_list.{g}.weight and bias.{g} instead of input_proj.* / prediction_layer.*. */
+  int prenorm;
+  int embed_tables;
 } mb_gen_cfg;
 
 /* ConvDecoder configuration (modeling/modules/autoencoder.py:358-397, configs/tokenizer yaml files). */

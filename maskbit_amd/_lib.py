@@ -15,7 +15,7 @@ ABI_VERSION = 2
 
 
 class GenCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass", "weight_split")]
+    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass", "weight_split", "prenorm", "embed_tables")]
 
 
 class DecCfg(C.Structure):

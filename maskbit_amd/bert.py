@@ -5,7 +5,8 @@ keywords, same checkpoint keys, ``model(img_tokens, class_labels,
 -> logits [b, seq, m, C]`` float32.  The forward itself is ``mb_gen_forward`` in
 libmaskbit_hip.so: fused bit-token embed + LayerNorm, 24 x (bf16 MFMA QKV GEMM, LDS-resident
 attention, out-proj GEMM + residual, LayerNorm, FFN GEMMs with fused erf-GELU / residual), head.
-Only the post-norm variant (``use_prenorm=False``, every shipped config) is implemented.
+Both the post-norm (every shipped config) and the pre-norm variant run on the engine; ``Bert`` is the
+embedding-table sibling of ``LFQBert``.
 """
 from __future__ import annotations
 
@@ -22,13 +23,19 @@ from .base_model import BaseModel, ParamSpec
 DEFAULT_WEIGHT_SPLIT = 0
 
 
-def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int) -> List[ParamSpec]:
-    s: List[ParamSpec] = [
-        ("pos_emb", (1, seq + 1, d), "normal"),
-        ("class_emb.weight", (nclass + 1, d), "normal"),
-        ("input_proj.weight", (d, bits), "normal"), ("input_proj.bias", (d,), "zeros"),
-        ("first_layer.0.weight", (d,), "ones"), ("first_layer.0.bias", (d,), "zeros"),
-    ]
+def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int, prenorm: bool = False,
+                     tables: int = 0, codes: int = 0) -> List[ParamSpec]:
+    """Checkpoint entries in the reference's registration order.  ``tables`` > 0: the embedding-table `Bert` (bert.py:222-262)
+    with that many groups of ``codes`` + 1 rows; otherwise LFQBert (bert.py:386-417)."""
+    s: List[ParamSpec] = []
+    if tables:
+        s += [("class_emb.weight", (nclass + 1, d), "normal")]
+        s += [(f"tok_emb_list.{g}.weight", (codes + 1, d), "normal") for g in range(tables)]
+        s += [("pos_emb", (1, seq + 1, d), "normal")]
+    else:
+        s += [("pos_emb", (1, seq + 1, d), "normal"), ("class_emb.weight", (nclass + 1, d), "normal"),
+              ("input_proj.weight", (d, bits), "normal"), ("input_proj.bias", (d,), "zeros")]
+    s += [("first_layer.0.weight", (d,), "ones"), ("first_layer.0.bias", (d,), "zeros")]
     for l in range(depth):
         a, m = f"transformer.layers.{l}.0", f"transformer.layers.{l}.1"
         s += [(a + ".mha.in_proj_weight", (3 * d, d), "normal"), (a + ".mha.in_proj_bias", (3 * d,), "zeros"),
@@ -37,9 +44,14 @@ def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: in
               (m + ".net.0.weight", (f, d), "normal"), (m + ".net.0.bias", (f,), "zeros"),
               (m + ".net.2.weight", (d, f), "normal"), (m + ".net.2.bias", (d,), "zeros"),
               (m + ".norm.weight", (d,), "ones"), (m + ".norm.bias", (d,), "zeros")]
+    if prenorm:
+        s += [("norm_after_transformer.weight", (d,), "ones"), ("norm_after_transformer.bias", (d,), "zeros")]
     s += [("last_layer.0.weight", (d, d), "normal"), ("last_layer.0.bias", (d,), "zeros"),
-          ("last_layer.2.weight", (d,), "ones"), ("last_layer.2.bias", (d,), "zeros"),
-          ("prediction_layer.weight", (out, d), "normal"), ("prediction_layer.bias", (out,), "zeros")]
+          ("last_layer.2.weight", (d,), "ones"), ("last_layer.2.bias", (d,), "zeros")]
+    if tables:
+        s += [(f"bias.{g}", (seq, codes), "zeros") for g in range(tables)]
+    else:
+        s += [("prediction_layer.weight", (out, d), "normal"), ("prediction_layer.bias", (out,), "zeros")]
     return s
 
 
@@ -47,9 +59,6 @@ class LFQBert(BaseModel):
     def __init__(self, img_size=256, hidden_dim=768, codebook_size=1024, codebook_splits=1, depth=24, heads=8,
                  mlp_dim=3072, dropout=0.1, nclass=1000, input_stride: int = 16, use_prenorm: bool = False):
         super().__init__()
-        if use_prenorm:
-            raise NotImplementedError("LFQBert(use_prenorm=True) is not implemented by the HIP engine "
-                                      "(no shipped MaskBit config uses it; SURVEY.md 8f next-3)")
         self.nclass = nclass
         self.drop_label = nclass
         self.seq_len = (img_size // input_stride) ** 2
@@ -62,14 +71,17 @@ class LFQBert(BaseModel):
         self.mask_token = self.effective_codebook_size
         self.hidden_dim, self.depth, self.heads, self.mlp_dim = hidden_dim, depth, heads, mlp_dim
         self.dropout = dropout            # inference only: dropout is the identity in eval mode
-        self.use_prenorm = False
+        self.use_prenorm = bool(use_prenorm)
+        self.embed_tables = bool(getattr(self, "_EMBED_TABLES", False))
         # GEMM weight precision of the device engine (not a reference argument): 0 = fp16, 1 = fp16 hi+lo pairs ("fp16x2",
         # twice the GEMM work, weight rounding 2^-22).  Default from MASKBIT_AMD_WEIGHT_SPLIT; may be changed before a call.
         self.weight_split = int(os.environ.get("MASKBIT_AMD_WEIGHT_SPLIT", str(DEFAULT_WEIGHT_SPLIT)))
         self._engine_split = None
-        self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
+        if not self.embed_tables:
+            self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
         self._build(_generator_specs(hidden_dim, mlp_dim, depth, self.seq_len, self.bits, nclass,
-                                     self.splits * self.effective_codebook_size))
+                                     self.splits * self.effective_codebook_size, prenorm=self.use_prenorm,
+                                     tables=self.splits if self.embed_tables else 0, codes=self.effective_codebook_size))
 
     def get_group_splits(self) -> int:
         return self.splits
@@ -77,7 +89,7 @@ class LFQBert(BaseModel):
     # ---- engine hooks ---------------------------------------------------------------------
     def _engine_create(self, capacity: int):
         cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass,
-                          int(self.weight_split))
+                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables))
         self._engine_split = int(self.weight_split)
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
@@ -116,6 +128,9 @@ class LFQBert(BaseModel):
         if class_labels.numel() != b:
             raise ValueError(f"class_labels must hold {b} labels, got {tuple(class_labels.shape)}")
         self._check_labels(class_labels)
+        if self.embed_tables and img_tokens.device.type == "cpu" and img_tokens.numel() and \
+                (int(img_tokens.min()) < 0 or int(img_tokens.max()) > self.effective_codebook_size):
+            raise IndexError(f"token outside [0, {self.effective_codebook_size}]")          # nn.Embedding would raise (bert.py:313)
         toks = img_tokens.to(device=dev, dtype=torch.int64).contiguous()
         labs = class_labels.to(device=dev, dtype=torch.int64).reshape(b).contiguous()     # never mutated (cf. bert.py:482-484)
         drop = None
@@ -129,10 +144,8 @@ class LFQBert(BaseModel):
         return logits
 
 
-class Bert(BaseModel):
-    """The embedding-table generator (reference bert.py:184-340).  No shipped MaskBit config selects it
-    (all use ``model_cls: lfq_bert``); it is importable for ``scripts/eval_maskbit.py`` but not built yet."""
-
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        raise NotImplementedError("modeling.bert.Bert (model_cls='bert') is not implemented by the HIP engine yet (SURVEY.md 8f next-3)")
+class Bert(LFQBert):
+    """The embedding-table generator (reference bert.py:184-340): per-group ``nn.Embedding(C + 1, hidden)`` inputs summed, the
+    output head tied to those tables (``x @ tok_emb.weight.T[:, :C]``) plus a per-position bias [seq, C].  Same trunk, same
+    engine: only the embed kernel's input mode and the head GEMM's weight / bias sources differ."""
+    _EMBED_TABLES = True

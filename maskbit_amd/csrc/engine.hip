@@ -101,6 +101,8 @@ struct mb_gen {
   float *w_in = nullptr, *b_in = nullptr, *class_emb = nullptr, *pos = nullptr, *ln0g = nullptr, *ln0b = nullptr;
   h16 *wl = nullptr, *wp = nullptr;
   float *bl = nullptr, *lnhg = nullptr, *lnhb = nullptr, *bp = nullptr;
+  float *lnag = nullptr, *lnab = nullptr;              // norm_after_transformer (pre-norm variant)
+  float *tables = nullptr, *bias_pos = nullptr;       // Bert: embedding tables [m][C+1][d]; output bias [seq][m*C]
   // split weights (cfg.weight_split): one output scale per GEMM weight [4*layer + {qkv, o, 1, 2}], then wl, wp
   int split = 0;
   float* wscale = nullptr;
@@ -136,9 +138,28 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   {
     ProfScope p("embed_ln", s, true);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
-                g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass};
+                g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
     embed_ln(s, e);
   }
+  if (c.prenorm) {
+    // use_prenorm (bert.py:49-59, 106-123): x = x + Attn(LN(x)); x = x + FFN(LN(x)); the fp32 stream buffer holds x itself, every
+    // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
+    for (int l = 0; l < c.depth; ++l) {
+      const mb_gen::Layer& L = g->layers[l];
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
+      { ProfScope p("gemm_qkv", s, true);
+        gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
+      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+      { ProfScope p("gemm_attn_out", s, true);
+        gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)}); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
+      { ProfScope p("gemm_ffn_up", s, true);
+        gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d * ks, 0, d, g->sc(4 * l + 2)}); }
+      { ProfScope p("gemm_ffn_down", s, true);
+        gemm_tn(s, EPI_RES_F32, GemmArgs{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)}); }
+    }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }   // norm_after_transformer
+  } else {
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     { ProfScope p("gemm_qkv", s, true);
@@ -160,11 +181,14 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       gemm_tn(s, EPI_RES_F32, ga); }
     { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
   }
+  }
   { ProfScope p("gemm_head", s, true);
     gemm_tn(s, EPI_GELU_F32, GemmArgs{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)}); }
   { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
   { ProfScope p("gemm_head", s, true);
-    gemm_tn(s, EPI_LOGITS_F32, GemmArgs{g->x_h16, g->wp, g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)}); }
+    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)};
+    ga.bias_per_pos = c.embed_tables;
+    gemm_tn(s, EPI_LOGITS_F32, ga); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -251,6 +275,9 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   const int C = 1 << (c.bits / c.splits);
   if (C > 4096 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d (the fused step kernel holds up to 4096 codes per group)", C);
   if (c.weight_split != 0 && c.weight_split != 1) return fail(-1, "weight_split must be 0 or 1");
+  if ((c.prenorm != 0 && c.prenorm != 1) || (c.embed_tables != 0 && c.embed_tables != 1)) return fail(-1, "prenorm / embed_tables must be 0 or 1");
+  if (c.embed_tables && c.weight_split) return fail(-1, "weight_split is not supported with embed_tables (the tied head spans one table per group)");
+  if (c.embed_tables && c.splits > 8) return fail(-1, "embed_tables supports up to 8 token groups");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
@@ -267,6 +294,8 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
     rc |= galloc(g, &L.ln1g, d); rc |= galloc(g, &L.ln1b, d); rc |= galloc(g, &L.ln2g, d); rc |= galloc(g, &L.ln2b, d);
   }
   rc |= galloc(g, &g->w_in, d * c.bits); rc |= galloc(g, &g->b_in, d);
+  if (c.prenorm) { rc |= galloc(g, &g->lnag, d); rc |= galloc(g, &g->lnab, d); }
+  if (c.embed_tables) { rc |= galloc(g, &g->tables, (size_t)c.splits * (C + 1) * d); rc |= galloc(g, &g->bias_pos, (size_t)c.seq * c.splits * C); }
   rc |= galloc(g, &g->class_emb, (size_t)(c.nclass + 1) * d); rc |= galloc(g, &g->pos, (size_t)g->N * d);
   rc |= galloc(g, &g->ln0g, d); rc |= galloc(g, &g->ln0b, d);
   rc |= galloc(g, &g->wl, ws * d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
@@ -331,6 +360,29 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   else if (n == "prediction_layer.weight") { dst_h = g->wp; want = (size_t)c.splits * g->C * d; wrows = c.splits * g->C; wcols = d; sidx = 4 * c.depth + 1; }
   else if (n == "prediction_layer.bias") { dst_f = g->bp; want = (size_t)c.splits * g->C; }
   else if (n == "bits_to_indices") return 0;   // derived buffer (bert.py:383-384): recomputed on the device
+  else if (c.prenorm && n == "norm_after_transformer.weight") { dst_f = g->lnag; want = d; }
+  else if (c.prenorm && n == "norm_after_transformer.bias") { dst_f = g->lnab; want = d; }
+  else if (c.embed_tables) {
+    int q = -1;
+    if (sscanf(name, "tok_emb_list.%d.weight", &q) == 1 && n == "tok_emb_list." + std::to_string(q) + ".weight") {
+      // Bert (bert.py:224-226, 329-332): the table is the input embedding (fp32, gathered) AND, rows 0..C-1, the output head
+      if (q < 0 || q >= c.splits) return fail(-2, "group index out of range in '%s'", name);
+      const size_t rows = (size_t)g->C + 1;
+      if (numel != rows * d) return fail(-4, "mb_gen_load: '%s' has %zu elements, expected %zu", name, numel, rows * d);
+      HIP_TRY(hipMemcpyAsync(g->tables + (size_t)q * rows * d, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+      mb::cast_f32_to_h16(s, data, g->wp + (size_t)q * g->C * d, (size_t)g->C * d);
+      g->loaded++;
+      return 0;
+    }
+    if (sscanf(name, "bias.%d", &q) == 1 && n == "bias." + std::to_string(q)) {
+      if (q < 0 || q >= c.splits) return fail(-2, "group index out of range in '%s'", name);
+      if (numel != (size_t)c.seq * g->C) return fail(-4, "mb_gen_load: '%s' has %zu elements, expected %zu", name, numel, (size_t)c.seq * g->C);
+      HIP_TRY(hipMemcpy2DAsync(g->bias_pos + (size_t)q * g->C, (size_t)c.splits * g->C * sizeof(float), data, (size_t)g->C * sizeof(float),
+                               (size_t)g->C * sizeof(float), (size_t)c.seq, hipMemcpyDeviceToDevice, s));
+      g->loaded++;
+      return 0;
+    }
+  }
   if (!dst_f && !dst_h) return fail(-2, "mb_gen_load: unknown checkpoint entry '%s'", name);
   if (numel != want) return fail(-4, "mb_gen_load: '%s' has %zu elements, expected %zu", name, numel, want);
   if (dst_f == g->w_in) mb::transpose_f32(s, data, g->w_in, (int)d, c.bits);       // [d,K] -> [K,d] for the embed kernel

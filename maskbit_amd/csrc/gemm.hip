@@ -94,16 +94,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     const int m = m0 + wm * 64 + j * 16 + (lane & 15);
     if (m >= a.M) continue;
     size_t orow = (size_t)m;
+    const float* brow = a.bias;
     if (EPI == EPI_LOGITS_F32) {
       const int sq = m / a.period, pos = m - sq * a.period;
       if (pos == a.period - 1) continue;           // class-token row is not a prediction (bert.py:503)
       orow = (size_t)sq * (a.period - 1) + pos;
+      if (a.bias_per_pos) brow = a.bias + (size_t)pos * a.N;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
       if (n >= a.N) continue;
-      const float4 b = *(const float4*)(a.bias + n);
+      const float4 b = *(const float4*)(brow + n);
       float v0 = fmaf(acc[i][j][0], sc, b.x), v1 = fmaf(acc[i][j][1], sc, b.y), v2 = fmaf(acc[i][j][2], sc, b.z), v3 = fmaf(acc[i][j][3], sc, b.w);
       if (EPI == EPI_RES_F32) {
         const float4 r = *(const float4*)(a.residual + (size_t)m * a.N + n);

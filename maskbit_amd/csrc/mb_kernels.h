@@ -31,6 +31,8 @@ struct GemmArgs {
   const float* ln_stats = nullptr;
   const float* ln_g = nullptr;
   const float* ln_b = nullptr;
+  // EPI_LOGITS_F32: bias is [period - 1][N] (one row per position: Bert's per-position output bias, bert.py:262,332) when set
+  int bias_per_pos = 0;
 };
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -53,6 +55,8 @@ struct EmbedArgs {
   const float* gamma; const float* beta;
   float* x_f32; h16* x_h16;   // [nb*(seq+1), d]
   int nb, seq, m, gbits, d, nclass;
+  // Bert (modeling/bert.py:313-315): per-group embedding tables [m][2^gbits + 1][d] summed instead of the bit projection
+  const float* tables = nullptr;
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);

@@ -105,9 +105,15 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
   const int d = a.d, K = a.m * a.gbits;
   uint32_t plus = 0, live = 0;       // bit j of `plus` set -> +1; bit j of `live` clear -> 0
   const float* cls = nullptr;
+  const float* trow[8] = {};         // Bert: the embedding-table row of each group's token (index 2^gbits = mask token)
   if (t < a.seq) {
     for (int g = 0; g < a.m; ++g) {
       const int64_t idx = a.tokens[((size_t)sq * a.seq + t) * a.m + g];
+      if (a.tables && g < 8) {
+        const int64_t nrow = ((int64_t)1 << a.gbits) + 1;
+        const int64_t ix = idx < 0 ? 0 : (idx >= nrow ? nrow - 1 : idx);            // never read outside the table (host validates)
+        trow[g] = a.tables + ((size_t)g * nrow + (size_t)ix) * d;
+      }
       const uint32_t gm = (1u << a.gbits) - 1u;
       if (idx != ((int64_t)1 << a.gbits)) { live |= gm << (g * a.gbits); plus |= ((uint32_t)idx & gm) << (g * a.gbits); }
     }
@@ -125,8 +131,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c = q * 256 + lane * 4;
-      float4 e = cls ? *(const float4*)(cls + c) : *(const float4*)(a.b_in + c);
-      if (!cls) {
+      float4 e = cls ? *(const float4*)(cls + c) : (a.tables ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(a.b_in + c));
+      if (!cls && a.tables) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          if (g < a.m) { const float4 w = *(const float4*)(trow[g] + c); e.x += w.x; e.y += w.y; e.z += w.z; e.w += w.w; }
+      } else if (!cls) {
 #pragma unroll
         for (int j = 0; j < MAXBITS; ++j) {
           if (j < K) {
@@ -145,7 +155,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
       float e = 0.f;
       if (c < d) {
         if (cls) e = cls[c];
-        else {
+        else if (a.tables) {
+          for (int g = 0; g < a.m && g < 8; ++g) e += trow[g][c];
+        } else {
           e = a.b_in[c];
           for (int j = 0; j < K; ++j) {
             const float sj = ((live >> j) & 1u) ? (((plus >> j) & 1u) ? 1.f : -1.f) : 0.f;

@@ -45,6 +45,8 @@ class GenCfg:
     mlp: int = 4096           # f
     seq: int = 256            # (img_size // input_stride) ** 2
     nclass: int = 1000
+    prenorm: bool = False     # use_prenorm (bert.py:49-59,106-123,326-327,498-499)
+    kind: str = "lfq"         # "lfq": LFQBert (bit-vector input projection); "bert": Bert (embedding tables, tied output head)
 
     @property
     def group_bits(self) -> int:
@@ -126,9 +128,32 @@ def attention(x: Tensor, sd: StateDict, p: str, heads: int) -> Tensor:
     return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
 
 
+def _trunk(sd: StateDict, cfg: GenCfg, x: Tensor) -> Tensor:
+    """first_layer LayerNorm, TransformerEncoder (post- or pre-norm), norm_after_transformer (pre-norm only), last_layer
+    (bert.py:27-70, 84-141, 166-180, 496-500)."""
+    x = _ln(x, sd, "first_layer.0", 1e-12)
+    for l in range(cfg.depth):
+        a = f"transformer.layers.{l}.0"
+        f = f"transformer.layers.{l}.1"
+        if cfg.prenorm:                                                                    # :49-59, :106-123
+            x = attention(_ln(x, sd, a + ".norm", 1e-12), sd, a + ".mha", cfg.heads) + x
+            y = _ln(x, sd, f + ".norm", 1e-12)
+            x = F.linear(F.gelu(F.linear(y, sd[f + ".net.0.weight"], sd[f + ".net.0.bias"])), sd[f + ".net.2.weight"], sd[f + ".net.2.bias"]) + x
+        else:
+            x = _ln(attention(x, sd, a + ".mha", cfg.heads) + x, sd, a + ".norm", 1e-12)      # :137-139
+            h = F.gelu(F.linear(x, sd[f + ".net.0.weight"], sd[f + ".net.0.bias"]))           # erf GELU
+            x = _ln(F.linear(h, sd[f + ".net.2.weight"], sd[f + ".net.2.bias"]) + x, sd, f + ".norm", 1e-12)
+    if cfg.prenorm:
+        x = _ln(x, sd, "norm_after_transformer", 1e-12)                                    # :498-499
+    x = F.gelu(F.linear(x, sd["last_layer.0.weight"], sd["last_layer.0.bias"]))
+    return _ln(x, sd, "last_layer.2", 1e-12)
+
+
 def lfq_bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor,
                      drop: Optional[Tensor] = None) -> Tensor:
-    """LFQBert.forward, post-norm variant (bert.py:456-508). Returns [b,seq,m,C] fp32."""
+    """LFQBert.forward (bert.py:456-508) or, for cfg.kind == "bert", Bert.forward (bert.py:283-340). Returns [b,seq,m,C] fp32."""
+    if cfg.kind == "bert":
+        return bert_forward(sd, cfg, tokens, labels, drop)
     b = tokens.shape[0]
     lab = labels.long().clone()
     if drop is not None:
@@ -136,18 +161,26 @@ def lfq_bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor,
     x_tok = F.linear(token_bit_vectors(tokens, cfg), sd["input_proj.weight"], sd["input_proj.bias"])
     x_cls = sd["class_emb.weight"][lab].unsqueeze(1)
     x = torch.cat([x_tok, x_cls], dim=1) + sd["pos_emb"]                          # class row LAST
-    x = _ln(x, sd, "first_layer.0", 1e-12)
-    for l in range(cfg.depth):
-        a = f"transformer.layers.{l}.0"
-        f = f"transformer.layers.{l}.1"
-        x = _ln(attention(x, sd, a + ".mha", cfg.heads) + x, sd, a + ".norm", 1e-12)      # :137-139
-        h = F.gelu(F.linear(x, sd[f + ".net.0.weight"], sd[f + ".net.0.bias"]))           # erf GELU
-        x = _ln(F.linear(h, sd[f + ".net.2.weight"], sd[f + ".net.2.bias"]) + x, sd, f + ".norm", 1e-12)
-    x = F.gelu(F.linear(x, sd["last_layer.0.weight"], sd["last_layer.0.bias"]))
-    x = _ln(x, sd, "last_layer.2", 1e-12)
+    x = _trunk(sd, cfg, x)
     logits = F.linear(x, sd["prediction_layer.weight"], sd["prediction_layer.bias"])
     logits = logits.reshape(b, cfg.seq + 1, cfg.splits, cfg.group_codes)
     return logits[:, :cfg.seq]
+
+
+def bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor, drop: Optional[Tensor] = None) -> Tensor:
+    """Bert.forward (bert.py:283-340): per-group embedding tables summed, output head tied to them plus a per-position bias."""
+    lab = labels.long().clone()
+    if drop is not None:
+        lab = torch.where(drop.bool(), torch.full_like(lab, cfg.nclass), lab)     # :309-311
+    x_tok = sd["tok_emb_list.0.weight"][tokens[..., 0]]
+    for g in range(1, cfg.splits):
+        x_tok = x_tok + sd[f"tok_emb_list.{g}.weight"][tokens[..., g]]            # :313-315
+    x_cls = sd["class_emb.weight"][lab].unsqueeze(1)
+    x = torch.cat([x_tok, x_cls], dim=1) + sd["pos_emb"]
+    x = _trunk(sd, cfg, x)
+    C_ = cfg.group_codes
+    logits = [torch.matmul(x, sd[f"tok_emb_list.{g}.weight"].t()[:, :C_])[:, :cfg.seq] + sd[f"bias.{g}"] for g in range(cfg.splits)]   # :329-332
+    return torch.stack(logits, dim=2)
 
 
 # --------------------------------------------------------------------------- schedule
@@ -377,13 +410,19 @@ def make_generator_weights(cfg: GenCfg, seed: int = 0, head_gain: float = 1.0) -
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g) * 0.02
     d, f = cfg.hidden, cfg.mlp
-    sd: StateDict = {
-        "pos_emb": rn(1, cfg.seq + 1, d),
-        "bits_to_indices": (1 << torch.arange(cfg.group_bits)).to(torch.int32),
-        "class_emb.weight": rn(cfg.nclass + 1, d),
-        "input_proj.weight": rn(d, cfg.bits), "input_proj.bias": rn(d),
-        "first_layer.0.weight": torch.ones(d) + rn(d), "first_layer.0.bias": rn(d),
-    }
+    if cfg.kind == "bert":            # Bert (bert.py:222-262): embedding tables instead of the bit projection, tied head + per-position bias
+        sd: StateDict = {"pos_emb": rn(1, cfg.seq + 1, d), "class_emb.weight": rn(cfg.nclass + 1, d)}
+        for q in range(cfg.splits):
+            sd[f"tok_emb_list.{q}.weight"] = rn(cfg.group_codes + 1, d) * (head_gain if head_gain != 1.0 else 1.0)
+        sd["first_layer.0.weight"] = torch.ones(d) + rn(d); sd["first_layer.0.bias"] = rn(d)
+    else:
+        sd = {
+            "pos_emb": rn(1, cfg.seq + 1, d),
+            "bits_to_indices": (1 << torch.arange(cfg.group_bits)).to(torch.int32),
+            "class_emb.weight": rn(cfg.nclass + 1, d),
+            "input_proj.weight": rn(d, cfg.bits), "input_proj.bias": rn(d),
+            "first_layer.0.weight": torch.ones(d) + rn(d), "first_layer.0.bias": rn(d),
+        }
     for l in range(cfg.depth):
         a, ff = f"transformer.layers.{l}.0", f"transformer.layers.{l}.1"
         sd[a + ".mha.in_proj_weight"] = rn(3 * d, d); sd[a + ".mha.in_proj_bias"] = rn(3 * d)
@@ -394,8 +433,14 @@ def make_generator_weights(cfg: GenCfg, seed: int = 0, head_gain: float = 1.0) -
         sd[ff + ".norm.weight"] = torch.ones(d) + rn(d); sd[ff + ".norm.bias"] = rn(d)
     sd["last_layer.0.weight"] = rn(d, d); sd["last_layer.0.bias"] = rn(d)
     sd["last_layer.2.weight"] = torch.ones(d) + rn(d); sd["last_layer.2.bias"] = rn(d)
-    sd["prediction_layer.weight"] = rn(cfg.splits * cfg.group_codes, d) * head_gain
-    sd["prediction_layer.bias"] = rn(cfg.splits * cfg.group_codes)
+    if cfg.kind == "bert":
+        for q in range(cfg.splits):
+            sd[f"bias.{q}"] = rn(cfg.seq, cfg.group_codes)
+    else:
+        sd["prediction_layer.weight"] = rn(cfg.splits * cfg.group_codes, d) * head_gain
+        sd["prediction_layer.bias"] = rn(cfg.splits * cfg.group_codes)
+    if cfg.prenorm:                   # drawn last: the streams of the post-norm configurations are unchanged
+        sd["norm_after_transformer.weight"] = torch.ones(d) + rn(d); sd["norm_after_transformer.bias"] = rn(d)
     return sd
 
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from maskbit_amd import _lib
-    assert ctypes.sizeof(_lib.GenCfg) == 9 * 4
+    assert ctypes.sizeof(_lib.GenCfg) == 11 * 4
     assert ctypes.sizeof(_lib.DecCfg) == (5 + 8 + 1 + 3) * 4
     assert ctypes.sizeof(_lib.SamplePlan) == 8 + 3 * 8
 
@@ -77,8 +77,20 @@ def test_import_paths_of_the_reference_drivers():
     from modeling.modules import sample, BaseModel
     import maskbit_amd
     assert LFQBert is maskbit_amd.LFQBert and ConvVQModel is maskbit_amd.ConvVQModel and sample is maskbit_amd.sample
-    with pytest.raises(NotImplementedError):
-        Bert()
+    assert issubclass(Bert, LFQBert)
+
+
+def test_generator_variants_take_the_reference_checkpoint_keys():
+    """use_prenorm and the embedding-table Bert: the oracle's seeded state dicts (whose key names / shapes were loaded strict=True
+    into the REAL reference classes by oracle/make_golden_variants.py) load strict into ours."""
+    from maskbit_amd import LFQBert
+    from maskbit_amd.bert import Bert
+    base = dict(bits=12, splits=2, hidden=128, depth=2, heads=4, mlp=256, seq=256, nclass=10)
+    for cls, cfg in ((LFQBert, O.GenCfg(**base, prenorm=True)), (Bert, O.GenCfg(**base, kind="bert")), (Bert, O.GenCfg(**base, kind="bert", prenorm=True))):
+        sd = O.make_generator_weights(cfg, seed=1)
+        m = cls(img_size=256, hidden_dim=128, codebook_size=4096, codebook_splits=2, depth=2, heads=4, mlp_dim=256, nclass=10, use_prenorm=cfg.prenorm)
+        m.load_state_dict(sd, strict=True)
+        assert set(m.state_dict().keys()) == set(sd.keys())
 
 
 def test_no_cpu_fallback():

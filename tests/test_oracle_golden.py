@@ -157,3 +157,15 @@ def test_decode_full12_and_config1():
     assert (idx != ref_idx).float().mean().item() <= 2 / 256      # sign of a ~0 pre-activation may flip under conv-algo noise
     rec = O.decode_tokens(sd10, cfg10, ref_idx.reshape(1, -1))
     assert (rec[:, :, 100:132, 100:132] - torch.from_numpy(z1["recon_crop"])).abs().max().item() < 2e-4
+
+
+def test_generator_variants_match_reference_goldens():
+    """Oracle restatement of LFQBert(use_prenorm=True) and of the embedding-table Bert (post-/pre-norm, 2 and 3 groups) against
+    logits captured from the real reference classes (oracle/make_golden_variants.py)."""
+    from oracle.make_golden_variants import VARIANTS
+    z = load_golden("gen_variants_tiny.npz")
+    for name, (cfg, seed) in VARIANTS.items():
+        sd = O.make_generator_weights(cfg, seed=seed, head_gain=20.0)
+        assert sha(sd["pos_emb"]) == str(z[f"{name}.w_sha"])
+        got = O.lfq_bert_forward(sd, cfg, torch.from_numpy(z[f"{name}.tokens"]), torch.from_numpy(z[f"{name}.labels"]), torch.from_numpy(z[f"{name}.drop"]))
+        assert float((got - torch.from_numpy(z[f"{name}.logits"])).abs().max()) < 2e-4, name
