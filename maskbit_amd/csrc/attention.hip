@@ -202,9 +202,157 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
   }
 }
 
+// ---- long sequences (N > 288, e.g. the 512x512 models' 1025 tokens): K/V streamed in 128-key blocks, online softmax ------------
+// One workgroup per (sequence, head, 64-query chunk); wave w owns query tile 4*chunk + w.  Same transposed formulation and the
+// same fragment reads as attention_kernel; the running row maximum m and denominator l live in the lane that owns the query
+// column, and the output accumulators are rescaled by exp2((m_old - m_new) * c) when a block raises the maximum
+// (Milakov-Gimelshein / FlashAttention-style streaming softmax).  K/V blocks are double-buffered through LDS by LDS-DMA.
+constexpr int ATTL_KB = 128;             // keys per block
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __restrict__ qkv, h16* __restrict__ out,
+                                                               int N, int d, int heads, int nchunk, float scale_log2e) {
+  constexpr int ROW = DH * 2, SL = DH / 8, KS = DH / 32, NT = DH / 16, RPI = 64 / SL;
+  constexpr int BLK_BYTES = ATTL_KB * ROW;                 // one operand block
+  constexpr int NINST = ATTL_KB / RPI;                     // DMA instructions per operand block (16 or 8)
+  constexpr int NKT = ATTL_KB / 16;                        // key tiles per block
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * BLK_BYTES];   // [buffer][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int chunk = bid % nchunk; bid /= nchunk;
+  const int sq = bid / heads, h = bid - sq * heads;
+  const size_t rs = (size_t)3 * d;
+  const h16* base = qkv + (size_t)sq * N * rs + h * DH;
+  auto kswz = [](int row) { return SL == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
+  auto vswz = [](int row) { return SL == 8 ? (((row >> 1) & 3) << 1) : (((row >> 1) & 1) << 1); };
+  const int nblk = (N + ATTL_KB - 1) / ATTL_KB;
+  auto stage = [&](int b, int buf) {                       // rows >= N re-read row N-1 (masked below)
+    char* Kb = smem + buf * 2 * BLK_BYTES;
+    char* Vb = Kb + BLK_BYTES;
+    for (int j = wave; j < NINST; j += 4) {
+      const int r = j * RPI + lane / SL, p = lane % SL;    // row inside the block: the swizzle uses the block-local row
+      const h16* src = base + (size_t)min(b * ATTL_KB + r, N - 1) * rs;
+      MB_GLDS16(src + d + (p ^ kswz(r)) * 8, Kb + j * 1024);
+      MB_GLDS16(src + 2 * d + (p ^ vswz(r)) * 8, Vb + j * 1024);
+    }
+  };
+  const int l15 = lane & 15, g = lane >> 4;
+  const int qt = chunk * 4 + wave;                         // this wave's query tile (may lie beyond N: computed, never stored)
+  h16x8 qf[KS];
+  {
+    const int qrow = min(qt * 16 + l15, N - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qrow * rs + (ks * 4 + g) * 8);
+  }
+  const int koff = l15 * ROW;
+  const int vrow = g * 4 + (l15 >> 2), vchunk = (l15 & 3) * 8;
+  unsigned vb_nt[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) vb_nt[nt] = vrow * ROW + ((((nt * 32 + vchunk) >> 4) ^ vswz(vrow)) << 4) + (vchunk & 8);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  for (int b = 0; b < nblk; ++b) {
+    if (b + 1 < nblk) stage(b + 1, (b + 1) & 1);
+    // block b has landed once at most the DMA instructions of block b+1 (NINST/4 pairs per wave) are outstanding
+    if (b + 1 < nblk) {
+      if constexpr (NINST == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* Kb = smem + (b & 1) * 2 * BLK_BYTES;
+    const unsigned Vb = (unsigned)(uintptr_t)(Kb + BLK_BYTES);
+    // ---- S^T tiles of this block
+    f32x4 sblk[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      sblk[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = kt * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const h16x8 kf = *(const h16x8*)(Kb + kt * 16 * ROW + koff + (((ks * 4 + g) ^ kswz(row)) * 16));
+        sblk[kt] = MB_MFMA_16x16x32(kf, qf[ks], sblk[kt]);
+      }
+    }
+    // ---- online softmax: block maximum, rescale, probabilities
+    const int key0 = b * ATTL_KB;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (key0 + kt * 16 + g * 4 + r >= N) sblk[kt][r] = -INFINITY;
+        mx = fmaxf(mx, sblk[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);                   // finite: every block holds at least one real key
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first block
+    const float mxs = m_new * scale_log2e;
+    float sum = 0.f;
+    h16x4 pk[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(sblk[kt][r], scale_log2e, -mxs)); sum += p[r]; }
+      pk[kt] = h16x4{(h16)p[0], (h16)p[1], (h16)p[2], (h16)p[3]};
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+    asm volatile("" : "+v"(l_run));                           // the cross-lane ops above have retired before the asm LDS reads
+    // ---- O^T += V^T P^T over the block's 32-key k-blocks
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb) {
+      uint2 v[NT][2];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned ad = Vb + vb_nt[nt];
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[nt][0]) : "v"(ad + (2 * kb) * 16 * ROW) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[nt][1]) : "v"(ad + (2 * kb + 1) * 16 * ROW) : "memory");
+      }
+      if constexpr (NT == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]),
+                     "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[3][0]), "+v"(v[3][1])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1])::"memory");
+      const h16x8 pf = __builtin_shufflevector(pk[2 * kb], pk[2 * kb + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 raw = {v[nt][0].x, v[nt][0].y, v[nt][1].x, v[nt][1].y};
+        o[nt] = MB_MFMA_16x16x32(__builtin_bit_cast(h16x8, raw), pf, o[nt]);
+      }
+    }
+    __syncthreads();                                          // everyone is done with this buffer before it is refilled
+  }
+  const int q = qt * 16 + l15;
+  if (q < N) {
+    const float inv = 1.0f / l_run;
+    h16* orow = out + ((size_t)sq * N + q) * d + h * DH;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      *(h16x4*)(orow + nt * 16 + g * 4) = h16x4{to_h(o[nt][0] * inv), to_h(o[nt][1] * inv), to_h(o[nt][2] * inv), to_h(o[nt][3] * inv)};
+  }
+}
+
 void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads) {
   const int dh = d / heads;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  if (N > ATT_NP) {                                           // longer than one head's K/V fits in LDS: streaming kernel
+    const int nchunk = (N + 63) / 64;
+    dim3 grid(nb * heads * nchunk), block(256);
+    if (dh == 64) hipLaunchKernelGGL(attention_long_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e);
+    else hipLaunchKernelGGL(attention_long_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e);
+    return;
+  }
   dim3 grid(nb * heads), block(64 * ATT_NW);
   if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, scale_log2e);
   else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, scale_log2e);

@@ -271,7 +271,8 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (c.hidden > 2048) return fail(-1, "hidden > 2048 is not supported");
   const int dh = c.heads > 0 ? c.hidden / c.heads : 0;
   if (c.heads <= 0 || c.hidden % c.heads || (dh != 32 && dh != 64)) return fail(-1, "hidden/heads must be 32 or 64 (got %d)", dh);
-  if (c.seq + 1 > 288) return fail(-1, "seq+1 = %d tokens exceeds the 288-key attention tile", c.seq + 1);
+  if (c.seq < 1 || c.seq > 4096) return fail(-1, "seq = %d outside [1, 4096]", c.seq);   // > 287 tokens: streaming attention kernel
+  if ((size_t)c.seq * c.splits > 8192) return fail(-1, "seq * splits = %zu exceeds the step kernel's 8192 positions", (size_t)c.seq * c.splits);
   const int C = 1 << (c.bits / c.splits);
   if (C > 4096 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d (the fused step kernel holds up to 4096 codes per group)", C);
   if (c.weight_split != 0 && c.weight_split != 1) return fail(-1, "weight_split must be 0 or 1");
