@@ -179,3 +179,31 @@ def test_sharded_noise_slices_reproduce_the_single_device_run():
         parts.append((u8, st))
     assert torch.equal(torch.cat([p[1] for p in parts], 1), steps_full)
     assert torch.equal(torch.cat([p[0] for p in parts], 0), u8_full)
+
+
+@pytest.mark.parametrize("num_steps,B,scale", [(1, 1, 7.1), (2, 2, 0.0), (3, 5, 3.0)])
+def test_short_loops_and_odd_batches_vs_oracle(num_steps, B, scale):
+    """Edge cases of the loop: a single step, no guidance, batch 1 / odd batches.  The oracle runs the same loop with the same
+    noise on the CPU; step 0 is teacher-forced by construction, later steps are free-running (bounded mismatch)."""
+    from maskbit_amd.sampling import build_plan, run_loop
+    gsd, tsd, gm, tm = tiny_models()
+    torch.manual_seed(100 + num_steps)
+    g = torch.distributions.Gumbel(0.0, 1.0)
+    qs, cs = [], []
+    for i in range(num_steps):
+        qs.append(torch.empty(B * 512, 64).exponential_(1))
+        cs.append(g.sample((B, 256, 2)) * 4.5 * (1 - (i + 1) / num_steps))
+    q, c = torch.stack(qs), torch.stack(cs)
+    labels = torch.arange(B) % 10
+    plan = build_plan(num_steps, 512, scale, "cosine", 3.0, 1.0, False, "arccos")
+    img, _, steps, codes = run_loop(gm, tm, labels, plan, q.to(DEV), c.to(DEV))
+    rec = []
+    torch.manual_seed(100 + num_steps)                      # the oracle draws the identical stream itself
+    O.sample_loop(lambda t, yy, dd: O.lfq_bert_forward(gsd, TINY_GEN, t, yy, dd), B, labels, num_steps=num_steps, guidance_scale=scale,
+                  guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=4.5, mask_schedule_strategy="arccos", mask_token=64,
+                  codebook_splits=2, record=rec)
+    assert steps.shape == (num_steps, B, 256, 2)
+    assert token_mismatch(steps[0].cpu(), rec[0].pred) < 1e-2
+    assert int((steps[-1] == 64).sum()) == 0 and int(steps.max()) < 64
+    assert img.shape == (B, 3, 64, 64) and torch.isfinite(img).all()
+    assert torch.equal(codes.cpu(), O.combine_groups(steps[-1].cpu(), 12, 2).long())
