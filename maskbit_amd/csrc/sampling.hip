@@ -12,7 +12,7 @@
 namespace mb {
 
 template <int CPL>   // logits per lane: C <= 64*CPL
-__global__ __launch_bounds__(512) void sample_step_kernel(StepArgs a, const int64_t* __restrict__ tokens_in) {
+__global__ __launch_bounds__(1024) void sample_step_kernel(StepArgs a, const int64_t* __restrict__ tokens_in) {
   extern __shared__ float sm[];
   const int P = a.P, C = a.C;
   float* conf_s = sm;                    // [P]
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512) void sample_step_kernel(StepArgs a, const int6
 int sample_step(hipStream_t s, const StepArgs& a, const int64_t* tokens_in) {
   if (a.C > 4096 || a.P > 8192) return -1;
   const size_t shm = (size_t)a.P * 8 + 16 * 4 + 16;
-  dim3 grid(a.B), block(512);
+  dim3 grid(a.B), block(1024);          // 16 waves: the per-row chain (load -> 4 wave reductions) is latency-bound, more rows in flight
   if (a.C <= 64) hipLaunchKernelGGL(sample_step_kernel<1>, grid, block, shm, s, a, tokens_in);
   else if (a.C <= 128) hipLaunchKernelGGL(sample_step_kernel<2>, grid, block, shm, s, a, tokens_in);
   else if (a.C <= 256) hipLaunchKernelGGL(sample_step_kernel<4>, grid, block, shm, s, a, tokens_in);
