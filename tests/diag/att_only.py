@@ -1,6 +1,8 @@
 """Run a few generator forwards (target for rocprofv3 --pmc passes on attention_kernel)."""
 import sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import maskbit_oracle as O
 from hip_helpers import hip_generator
 cfg = O.GenCfg(bits=12, splits=2, depth=2)

@@ -1,6 +1,6 @@
 """How does the CPU oracle scale with torch threads on this host? (informs bench.py's cpu_baseline)"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import maskbit_oracle as O
 cfg = O.GenCfg(bits=12, splits=2)
 sd = O.make_generator_weights(cfg, seed=100, head_gain=12.0)

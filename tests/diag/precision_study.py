@@ -3,7 +3,7 @@ Rounds exactly what the HIP engine rounds: GEMM operands (activations + weights)
 output, FFN hidden; accumulates in fp32; residual stream and LayerNorm in fp32."""
 import math, sys, time, os
 import torch, torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import maskbit_oracle as O
 

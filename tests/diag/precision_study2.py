@@ -1,6 +1,6 @@
 """Which fp16 rounding point contributes most to the token mismatch? (CPU emulation, one component kept in fp32 at a time)"""
 import math, sys, os, torch, torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import maskbit_oracle as O
 h16 = lambda x: x.to(torch.float16).to(torch.float32)

@@ -1,7 +1,7 @@
 """Would folding LayerNorm into the consumer GEMM (fp16(y) . (W*gamma)^T, normalised in the epilogue from row statistics) cost
 precision against the current path (fp16(LayerNorm(y)) . W^T)?  CPU emulation on the full 12-bit model, 4 CFG steps."""
 import math, sys, os, torch, torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import maskbit_oracle as O
 h16 = lambda x: x.to(torch.float16).to(torch.float32)

@@ -1,6 +1,6 @@
 """Logit error of the HIP forward vs the fp32 oracle for weight_split = 0 / 1 (full 12-bit model, random masked tokens)."""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import maskbit_oracle as O
 from hip_helpers import hip_generator
