@@ -5,15 +5,15 @@
 
 // 16-bit storage type of activations and packed weights.  IEEE fp16 by default: the sampler feeds its
 // own output back for 64 steps and classifier-free guidance multiplies logit errors by up to ~8x,
-// so the 8-bit mantissa of h16 costs ~1e-2 token mismatch against the fp32 reference where fp16's
+// so the 8-bit mantissa of bf16 costs ~1e-2 token mismatch against the fp32 reference where fp16's
 // 11 bits give ~1e-3 at the same MFMA rate (measured; DESIGN.md "Precision").  Build with
-// -DMB_HALF_BF16=1 to get the h16 variant for A/B runs.  Accumulation is always fp32.
+// -DMB_HALF_BF16=1 to get the bf16 variant for A/B runs.  Accumulation is always fp32.
 #ifndef MB_HALF_BF16
 #define MB_HALF_BF16 0
 #endif
 #if MB_HALF_BF16
 typedef __bf16 h16;
-#define MB_MFMA_16x16x32(a, b, c) MB_MFMA_16x16x32(a, b, c)
+#define MB_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define MB_H16_MAX 3.3e38f
 #else
 typedef _Float16 h16;
@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 typedef __attribute__((ext_vector_type(4))) h16 h16x4;
 typedef __attribute__((ext_vector_type(8))) h16 h16x8;
 
-// fp32 -> storage half with saturation instead of +-inf (fp16 only; a no-op clamp for h16)
+// fp32 -> storage half with saturation instead of +-inf (fp16 only; a no-op clamp for bf16)
 __device__ __forceinline__ h16 to_h(float x) { return (h16)__builtin_amdgcn_fmed3f(x, -MB_H16_MAX, MB_H16_MAX); }
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -48,7 +48,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// erf with |abs err| < 2e-7 (Abramowitz-Stegun 7.1.26); used by the erf-GELU epilogue.
 // Exact-erf GELU on a pair of values with packed fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32: two lanes-worth per issue).
 // gelu(x) = x*Phi(x) = max(x,0) - |x| * erfc(|x|/sqrt2)/2, and erfc(a) = t*P(t)*exp(-a^2) with t = 1/(1 + 0.3275911 a)
 // (Abramowitz-Stegun 7.1.26, |err| < 1.5e-7); the 1/2 and the 1/sqrt2 are folded into the constants. Writing the
