@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       xa[i][ks] = *(const h16x8*)(par + (H) * AH_BYTES + xbase + i * 16 * 128 + foff[ks]);
 #define MB_LOAD_B(H)                                                                            \
   if (XP != 1) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
-      wb[i][ks] = *(const h16x8*)(par + wbase + (H) * BH_BYTES + i * 16 * 128 + foff[ks]);
+      wb[H][i][ks] = *(const h16x8*)(par + wbase + (H) * BH_BYTES + i * 16 * 128 + foff[ks]);
 #define MB_SYNC_L()                                     \
   __builtin_amdgcn_s_barrier();                         \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #define MB_MMA(AH, BH)                                                                              \
   if (XP != 1) _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)       \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
-          acc[(BH) * 2 + n][(AH) * MH + i] = MB_MFMA_16x16x32(wb[n][ks], xa[i][ks], acc[(BH) * 2 + n][(AH) * MH + i]); \
+          acc[(BH) * 2 + n][(AH) * MH + i] = MB_MFMA_16x16x32(wb[BH][n][ks], xa[i][ks], acc[(BH) * 2 + n][(AH) * MH + i]); \
   __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acce[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // SEQ: class row x this wave row's 2 n-tiles
-    h16x8 xa[MH][2], wb[2][2];
+    h16x8 xa[MH][2], wb[2][2][2];       // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
     if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
     for (int t = 0; t < nk; ++t) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[n][ks], xe[ks], acce[n]);
+          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[0][n][ks], xe[ks], acce[n]);
       }
       MB_MMA(0, 0)
       // ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill B0 of the other parity
@@ -197,17 +197,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[n][ks], xe[ks], acce[n]);
+          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[1][n][ks], xe[ks], acce[n]);
       }
       MB_MMA(0, 1)
       // ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2
       MB_LOAD_A(1)
       if (n2) dma_a(cur, t + 2, 0);
       MB_SYNC_L() MB_MMA(1, 1)
-      // ---- phase 3: (A1, B0); refill B1 (and X) of this parity with K-tile t+2; K-tile t+1 must have landed.
+      // ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1 (and X) of this parity with K-tile t+2; K-tile t+1 must have landed.
       // In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output
       // stores stay in flight until the wait of K-tile 1.
-      MB_LOAD_B(0)
       if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); }
       if (t >= 1 || XP == 2) {
         if (n2) {
