@@ -207,3 +207,28 @@ def test_short_loops_and_odd_batches_vs_oracle(num_steps, B, scale):
     assert int((steps[-1] == 64).sum()) == 0 and int(steps.max()) < 64
     assert img.shape == (B, 3, 64, 64) and torch.isfinite(img).all()
     assert torch.equal(codes.cpu(), O.combine_groups(steps[-1].cpu(), 12, 2).long())
+
+
+def test_eval_harness_matches_batchwise_sample_and_reference_postprocessing():
+    """the eval_maskbit.py:107-135 loop with the uint8 NHWC epilogue on the device and the host copy of batch i
+    overlapped with batch i+1 gives, bit for bit, what batch-by-batch sample() + clamp / x255 / permute / truncating cast gives."""
+    from maskbit_amd import generate_uint8, sample
+    _, _, gm, tm = tiny_models()
+    kw = dict(softmax_temperature=1.0, randomize_temperature=8.2, mask_schedule_strategy="arccos", num_steps=6, guidance_scale=7.1,
+              guidance_annealing="cosine", use_sampling_annealing=False, scale_pow=3.0)
+    labels = torch.tensor([1, 4, 8, 0, 9, 3, 2, 2, 7], dtype=torch.int, device=DEV)          # int32 on the device, as randperm(dtype=int) gives
+    torch.manual_seed(11)
+    got = list(generate_uint8(gm, tm, labels, 3, **kw))
+    assert len(got) == 3 and all(g.shape == (3, 64, 64, 3) and g.dtype.name == "uint8" for g in got)
+    torch.manual_seed(11)
+    for i in range(3):
+        img, _ = sample(gm, tm, num_samples=3, labels=labels[3 * i: 3 * i + 3].long(), mask_token=64, patch_size=16, codebook_size=4096,
+                        codebook_splits=2, **kw)
+        want = (torch.clamp(img, 0.0, 1.0) * 255.0).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8).numpy()
+        assert (got[i] == want).all(), f"batch {i}"
+    assert any((got[0] != got[j]).any() for j in (1, 2))                                       # different labels / noise per batch
+    # a partial last batch is dropped, as total_samples // batchsize does in the reference
+    torch.manual_seed(11)
+    assert len(list(generate_uint8(gm, tm, labels[:8], 3, **kw))) == 2
+    with pytest.raises(IndexError):
+        list(generate_uint8(gm, tm, torch.tensor([1, 2, 30]), 3, **kw))

@@ -153,3 +153,16 @@ def test_load_pretrained_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         m.load_pretrained(str(tmp_path / "missing.bin"))
     assert m.device == torch.device("cpu") and m.dtype == torch.float32
+
+
+def test_eval_harness_host_pieces():
+    """eval_maskbit.py:77-80 (mask token from the codebook size) and :107-108 (label protocol)."""
+    from maskbit_amd import eval_labels, mask_token_for
+    assert mask_token_for(4096, 2) == 64 and mask_token_for(1024, 2) == 32 and mask_token_for(2 ** 14, 2) == 128
+    assert mask_token_for(1024, 1) == 1024 and mask_token_for(4096, 3) == 16 and mask_token_for(2 ** 18, 2) == 512
+    torch.manual_seed(3)
+    lab = eval_labels("cpu")
+    torch.manual_seed(3)
+    ref = torch.randperm(1000, dtype=torch.int).repeat(50)
+    assert lab.dtype == torch.int32 and lab.shape == (50000,) and torch.equal(lab, ref)
+    assert torch.equal(lab[:1000].sort().values, torch.arange(1000, dtype=torch.int32))
