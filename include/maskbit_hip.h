@@ -87,6 +87,11 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
  * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */
 int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop,
                    float* logits, int nb, mb_stream stream);
+/* The same forward with `return_attn=True` (bert.py:461, 505-508; nn.MultiheadAttention need_weights with head averaging,
+ * bert.py:119,137): additionally attn fp32 [depth, nb, seq+1, seq+1], layer l's softmax weights averaged over the heads
+ * (class token = last row / column).  Visualisation path, not used by sample(). */
+int mb_gen_forward_attn(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop,
+                        float* logits, float* attn, int nb, mb_stream stream);
 
 /* ---- one sampling step after the forward: sampling.py:90-131 ------------------------------ *
  * logits_u NULL => no guidance.  `scale` = guidance_scale * a_i (sampling.py:91-98), `temperature`

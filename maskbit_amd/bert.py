@@ -118,9 +118,9 @@ class LFQBert(BaseModel):
     # ---- forward ----------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, img_tokens: torch.Tensor, class_labels: torch.Tensor,
-                drop_label_mask: Optional[torch.Tensor] = None, return_attn: bool = False) -> torch.Tensor:
-        if return_attn:
-            raise NotImplementedError("return_attn=True (attention maps) is not produced by the fused HIP attention kernel")
+                drop_label_mask: Optional[torch.Tensor] = None, return_attn: bool = False):
+        """-> logits [b, seq, m, C]; with ``return_attn`` (bert.py:461, 505-508) the tuple (logits, [one head-averaged attention map
+        [b, seq+1, seq+1] per layer]) -- the maps come from a separate plain kernel reading the same Q/K rows."""
         dev = self._require_cuda("forward")
         if img_tokens.dim() != 3 or img_tokens.shape[1] != self.seq_len or img_tokens.shape[2] != self.splits:
             raise ValueError(f"img_tokens must be [b, {self.seq_len}, {self.splits}], got {tuple(img_tokens.shape)}")
@@ -139,6 +139,13 @@ class LFQBert(BaseModel):
         logits = torch.empty((b, self.seq_len, self.splits, self.effective_codebook_size), dtype=torch.float32, device=dev)
         h = self.engine(b)
         with torch.cuda.device(dev):
+            if return_attn:
+                n1 = self.seq_len + 1
+                attn = torch.empty((self.depth, b, n1, n1), dtype=torch.float32, device=dev)
+                _lib.check(_lib.load().mb_gen_forward_attn(h, toks.data_ptr(), labs.data_ptr(), drop.data_ptr() if drop is not None else None,
+                                                           logits.data_ptr(), attn.data_ptr(), b, torch.cuda.current_stream().cuda_stream),
+                           "mb_gen_forward_attn")
+                return logits, list(attn.unbind(0))
             _lib.check(_lib.load().mb_gen_forward(h, toks.data_ptr(), labs.data_ptr(), drop.data_ptr() if drop is not None else None,
                                                   logits.data_ptr(), b, torch.cuda.current_stream().cuda_stream), "mb_gen_forward")
         return logits

@@ -122,7 +122,7 @@ class ConvVQModel(BaseModel):
             cfg.channel_mult[i] = v
         cfg.latent_size = self._latent_size
         cfg.sample_with_conv = 1 if self.sample_with_conv else 0
-        cfg.build_encoder = cfg.sample_with_conv               # the avg-pool encoder variant is not built: encode() raises for it
+        cfg.build_encoder = 1
         cfg.enc_res_blocks = self.num_res_blocks
         h = C.c_void_p()
         _lib.check(_lib.load().mb_dec_create(C.byref(cfg), capacity, C.byref(h)), "mb_dec_create")
@@ -187,9 +187,6 @@ class ConvVQModel(BaseModel):
     @torch.no_grad()
     def _encode(self, x: torch.Tensor, want_raw: bool = False):
         dev = self._require_cuda("encode")
-        if not self.sample_with_conv:
-            raise NotImplementedError("ConvVQModel.encode with sample_with_conv=False (average-pool downsampling) is not built; "
-                                      "every shipped MaskBit tokenizer config downsamples by convolution")
         if x.dim() != 4 or x.shape[1] != self.num_channels:
             raise ValueError(f"encode expects [b, {self.num_channels}, H, W], got {tuple(x.shape)}")
         b, _, H, W = x.shape

@@ -343,6 +343,69 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
   }
 }
 
+// ---- return_attn=True (bert.py:119,137: need_weights with the default average_attn_weights): the head-averaged softmax
+// weights [nb, N, N] fp32 of one layer, from the same fp16 qkv rows the fused kernel consumes.  A diagnostic path (attention
+// maps for visualisation), not on the sampling loop: plain fp32 FMAs, one wave per query row, scores kept in LDS.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_probs_kernel(const h16* __restrict__ qkv, float* __restrict__ out, int N, int d, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rows_per_seq = (N + 3) / 4;
+  const int seq = blockIdx.x / rows_per_seq, r = (blockIdx.x % rows_per_seq) * 4 + wave;
+  if (r >= N) return;
+  float* sc = (float*)smem + (size_t)wave * 2 * N;          // scores of the current head
+  float* av = sc + N;                                        // running mean over the heads
+  for (int j = lane; j < N; j += 64) av[j] = 0.f;
+  const float scale = 1.0f / sqrtf((float)DH), invh = 1.0f / (float)heads;
+  const h16* base = qkv + (size_t)seq * N * 3 * d;
+  for (int h = 0; h < heads; ++h) {
+    float q[DH];
+    const h16* qp = base + (size_t)r * 3 * d + h * DH;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i) {
+      const h16x8 v = *(const h16x8*)(qp + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[i * 8 + e] = (float)v[e] * scale;
+    }
+    float mx = -3.0e38f;
+    for (int j = lane; j < N; j += 64) {
+      const h16* kp = base + (size_t)j * 3 * d + d + h * DH;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < DH / 8; ++i) {
+        const h16x8 v = *(const h16x8*)(kp + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf(q[i * 8 + e], (float)v[e], a);
+      }
+      sc[j] = a;
+      mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float w = invh / sum;
+    for (int j = lane; j < N; j += 64) av[j] = fmaf(sc[j], w, av[j]);
+  }
+  float* orow = out + ((size_t)seq * N + r) * N;
+  for (int j = lane; j < N; j += 64) orow[j] = av[j];
+}
+
+int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads) {
+  const int dh = d / heads;
+  const size_t lds = (size_t)4 * 2 * N * sizeof(float);
+  if ((dh != 32 && dh != 64) || lds > 160 * 1024) return -1;
+  dim3 grid(nb * ((N + 3) / 4)), block(256);
+  if (dh == 64) {
+    (void)hipFuncSetAttribute((const void*)attention_probs_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attention_probs_kernel<64>, grid, block, lds, s, qkv, out, N, d, heads);
+  } else {
+    (void)hipFuncSetAttribute((const void*)attention_probs_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attention_probs_kernel<32>, grid, block, lds, s, qkv, out, N, d, heads);
+  }
+  return 0;
+}
+
 void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads) {
   const int dh = d / heads;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);

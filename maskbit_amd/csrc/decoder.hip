@@ -284,6 +284,22 @@ __global__ void s2d_kernel(const h16* __restrict__ x, h16* __restrict__ y, int B
     *(h16x8*)(y + (((b * (H / 2) + (Y >> 1)) * (W / 2) + (X >> 1)) * 4 + ((Y & 1) * 2 + (X & 1))) * C + sl * 8) = v;
   }
 }
+// F.avg_pool2d(kernel 2, stride 2) (autoencoder.py:182): x[B,H,W,C] -> y[B,H/2,W/2,C], fp32 mean of the four fp16 inputs
+__global__ void avgpool2_kernel(const h16* __restrict__ x, h16* __restrict__ y, int B, int H, int W, int C) {
+  const int c8 = C / 8, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)B * Ho * Wo * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int sl = (int)(i % c8); size_t p = i / c8;
+    const int X = (int)(p % Wo); p /= Wo; const int Y = (int)(p % Ho); const size_t b = p / Ho;
+    const h16* src = x + ((b * H + 2 * Y) * W + 2 * X) * C + sl * 8;
+    const h16x8 v00 = *(const h16x8*)src, v01 = *(const h16x8*)(src + C), v10 = *(const h16x8*)(src + (size_t)W * C),
+                v11 = *(const h16x8*)(src + (size_t)W * C + C);
+    h16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = to_h(((float)v00[c] + (float)v01[c] + (float)v10[c] + (float)v11[c]) * 0.25f);
+    *(h16x8*)(y + ((b * Ho + Y) * Wo + X) * C + sl * 8) = o;
+  }
+}
 // OIHW 3x3 stride-2 weights -> [tap (by,bx)][Cout_pad][4*Cin] for the 2x2 conv on the space-to-depth input:
 // tap (by,bx), channel (py*2+px)*Cin + ci  <-  w[co][ci][2by+py][2bx+px] (zero where that index is 3)
 __global__ void repack_down_kernel(const float* __restrict__ w, h16* __restrict__ out, int Cout, int Cin, int Cout_pad) {
@@ -477,7 +493,6 @@ mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
   ok = ok && init_norm(d, d->norm_out, "decoder.norm_out", last, err) &&
        init_conv(d, d->conv_out, "decoder.conv_out", last, cfg.num_channels, 3, true, false, true, err);
   if (ok && cfg.build_encoder) {                          // ConvEncoder (autoencoder.py:230-262): mirrors the decoder top-down
-    if (!cfg.sample_with_conv) { err = "encoder with average-pool downsampling (sample_with_conv = False) is not built"; ok = false; }
     const int enrb = cfg.enc_res_blocks > 0 ? cfg.enc_res_blocks : cfg.num_res_blocks;
     std::vector<int> imult{1};
     imult.insert(imult.end(), cfg.channel_mult, cfg.channel_mult + R);
@@ -492,8 +507,9 @@ mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
         ok = init_block(d, st.blocks[r], "encoder.down." + std::to_string(s) + ".res_blocks." + std::to_string(r), c, cout, err);
         c = cout;
       }
-      st.has_up = s < R - 1;
-      if (ok && st.has_up) {                              // DownsamplingStage.down_conv: 3x3, stride 2, bias (autoencoder.py:165)
+      st.has_up = s < R - 1;                              // a downsampling step follows: down_conv, or avg_pool2d when !sample_with_conv
+      st.up.cin = cout;
+      if (ok && st.has_up && cfg.sample_with_conv) {      // DownsamplingStage.down_conv: 3x3, stride 2, bias (autoencoder.py:165)
         Conv& dc = st.up;
         dc.name = "encoder.down." + std::to_string(s) + ".down_conv";
         dc.cin = cout; dc.cout = cout; dc.cout_w = cout; dc.ks = 2; dc.has_bias = true; dc.down = true;
@@ -541,7 +557,7 @@ int dec_load(mb_dec* d, const char* name, const float* data, const int64_t* shap
   if (d->has_enc) {
     convs.push_back(&d->e_conv_in); convs.push_back(&d->e_conv_out); norms.push_back(&d->e_norm_out);
     for (auto& rb : d->e_mid) add_block(rb);
-    for (auto& st : d->e_down) { for (auto& rb : st.blocks) add_block(rb); if (st.has_up) convs.push_back(&st.up); }
+    for (auto& st : d->e_down) { for (auto& rb : st.blocks) add_block(rb); if (st.has_up && d->c.sample_with_conv) convs.push_back(&st.up); }
   }
   for (Conv* c : convs) {
     Conv* hit = nullptr; bool is_bias = false;
@@ -609,6 +625,13 @@ int enc_encode(mb_dec* d, const float* img, int64_t* indices, float* zq, float* 
     if (st.has_up) {
       const int t = (xi + 1) % 3, t2 = (xi + 2) % 3;
       const size_t n8 = (size_t)B * res * res * (st.up.cin / 8);
+      if (!c.sample_with_conv) {                           // F.avg_pool2d(2, 2) (autoencoder.py:182)
+        hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)std::min<size_t>(4096, (n8 / 4 + 255) / 256)), dim3(256), 0, s, d->buf[xi], d->buf[t], B, res,
+                           res, st.up.cin);
+        res /= 2;
+        xi = t;
+        continue;
+      }
       hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)std::min<size_t>(4096, (n8 + 255) / 256)), dim3(256), 0, s, d->buf[xi], d->buf[t], B, res, res,
                          st.up.cin);
       res /= 2;

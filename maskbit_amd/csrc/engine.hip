@@ -129,10 +129,15 @@ int galloc(mb_gen* g, T** p, size_t n) {
 }
 
 int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits,
-                     int nb, hipStream_t s) {
+                     int nb, hipStream_t s, float* attn = nullptr) {
   using namespace mb;
   const mb_gen_cfg& c = g->c;
   const int d = c.hidden, f = c.mlp, N = g->N, M = nb * N;
+  // return_attn: layer l's head-averaged attention weights go to attn[l][nb][N][N], computed from the same qkv rows
+  auto attn_maps = [&](int l) {
+    return attn ? attention_probs(s, g->qkv, attn + (size_t)l * nb * N * N, nb, N, d, c.heads) : 0;
+  };
+  int attn_rc = 0;
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   {
@@ -150,6 +155,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       { ProfScope p("gemm_qkv", s, true);
         gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
       { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+      attn_rc |= attn_maps(l);
       { ProfScope p("gemm_attn_out", s, true);
         gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)}); }
       { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
@@ -165,6 +171,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     { ProfScope p("gemm_qkv", s, true);
       gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
     { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+    attn_rc |= attn_maps(l);
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
     // GEMM operand and {mean, rstd}; the next residual GEMM re-derives the normalised rows in its epilogue and updates
     // y_f32 in place.  (Layer 0's first residual is the embedding LayerNorm output, stored as is by embed_ln.)
@@ -191,6 +198,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     gemm_tn(s, EPI_LOGITS_F32, ga); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  if (attn_rc) return fail(-3, "attention maps: head dim %d / %d tokens not supported", d / c.heads, N);
   return 0;
 }
 
@@ -399,6 +407,13 @@ int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, cons
   if (!g || !tokens || !labels || !logits) return fail(-1, "mb_gen_forward: null argument");
   if (nb <= 0 || nb > g->max_seqs) return fail(-1, "mb_gen_forward: nb=%d outside [1, %d]", nb, g->max_seqs);
   return gen_forward_impl(g, tokens, labels, drop, logits, nb, (hipStream_t)stream);
+}
+
+int mb_gen_forward_attn(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, float* attn,
+                        int nb, mb_stream stream) {
+  if (!g || !tokens || !labels || !logits || !attn) return fail(-1, "mb_gen_forward_attn: null argument");
+  if (nb <= 0 || nb > g->max_seqs) return fail(-1, "mb_gen_forward_attn: nb=%d outside [1, %d]", nb, g->max_seqs);
+  return gen_forward_impl(g, tokens, labels, drop, logits, nb, (hipStream_t)stream, attn);
 }
 
 int mb_sample_step(const float* logits_c, const float* logits_u, float scale, float temperature,

@@ -63,6 +63,8 @@ void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
 void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads);
+// head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
+int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 
 // ---- fused sampling step (sampling.py:90-131) ----------------------------------------------------
 struct StepArgs {

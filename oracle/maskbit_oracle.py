@@ -113,8 +113,10 @@ def token_bit_vectors(tokens: Tensor, cfg: GenCfg) -> Tensor:
     return v.reshape(tokens.shape[0], tokens.shape[1], cfg.splits * gb)
 
 
-def attention(x: Tensor, sd: StateDict, p: str, heads: int) -> Tensor:
-    """nn.MultiheadAttention(batch_first, packed in_proj) self-attention (bert.py:84,137)."""
+def attention(x: Tensor, sd: StateDict, p: str, heads: int, attn_out: Optional[list] = None) -> Tensor:
+    """nn.MultiheadAttention(batch_first, packed in_proj) self-attention (bert.py:84,137).  With ``attn_out`` the attention
+    weights averaged over the heads, [b, n, n], are appended to it (``need_weights=True`` with the module's default
+    ``average_attn_weights=True``, bert.py:119,137)."""
     b, n, d = x.shape
     dh = d // heads
     qkv = F.linear(x, sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"])
@@ -123,12 +125,15 @@ def attention(x: Tensor, sd: StateDict, p: str, heads: int) -> Tensor:
     k = k.reshape(b, n, heads, dh).transpose(1, 2)
     v = v.reshape(b, n, heads, dh).transpose(1, 2)
     s = (q * (1.0 / math.sqrt(dh))) @ k.transpose(-1, -2)
-    o = torch.softmax(s, dim=-1) @ v
+    w = torch.softmax(s, dim=-1)
+    if attn_out is not None:
+        attn_out.append(w.mean(dim=1))
+    o = w @ v
     o = o.transpose(1, 2).reshape(b, n, d)
     return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
 
 
-def _trunk(sd: StateDict, cfg: GenCfg, x: Tensor) -> Tensor:
+def _trunk(sd: StateDict, cfg: GenCfg, x: Tensor, attn_out: Optional[list] = None) -> Tensor:
     """first_layer LayerNorm, TransformerEncoder (post- or pre-norm), norm_after_transformer (pre-norm only), last_layer
     (bert.py:27-70, 84-141, 166-180, 496-500)."""
     x = _ln(x, sd, "first_layer.0", 1e-12)
@@ -136,11 +141,11 @@ def _trunk(sd: StateDict, cfg: GenCfg, x: Tensor) -> Tensor:
         a = f"transformer.layers.{l}.0"
         f = f"transformer.layers.{l}.1"
         if cfg.prenorm:                                                                    # :49-59, :106-123
-            x = attention(_ln(x, sd, a + ".norm", 1e-12), sd, a + ".mha", cfg.heads) + x
+            x = attention(_ln(x, sd, a + ".norm", 1e-12), sd, a + ".mha", cfg.heads, attn_out) + x
             y = _ln(x, sd, f + ".norm", 1e-12)
             x = F.linear(F.gelu(F.linear(y, sd[f + ".net.0.weight"], sd[f + ".net.0.bias"])), sd[f + ".net.2.weight"], sd[f + ".net.2.bias"]) + x
         else:
-            x = _ln(attention(x, sd, a + ".mha", cfg.heads) + x, sd, a + ".norm", 1e-12)      # :137-139
+            x = _ln(attention(x, sd, a + ".mha", cfg.heads, attn_out) + x, sd, a + ".norm", 1e-12)      # :137-139
             h = F.gelu(F.linear(x, sd[f + ".net.0.weight"], sd[f + ".net.0.bias"]))           # erf GELU
             x = _ln(F.linear(h, sd[f + ".net.2.weight"], sd[f + ".net.2.bias"]) + x, sd, f + ".norm", 1e-12)
     if cfg.prenorm:
@@ -150,10 +155,11 @@ def _trunk(sd: StateDict, cfg: GenCfg, x: Tensor) -> Tensor:
 
 
 def lfq_bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor,
-                     drop: Optional[Tensor] = None) -> Tensor:
-    """LFQBert.forward (bert.py:456-508) or, for cfg.kind == "bert", Bert.forward (bert.py:283-340). Returns [b,seq,m,C] fp32."""
+                     drop: Optional[Tensor] = None, return_attn: bool = False):
+    """LFQBert.forward (bert.py:456-508) or, for cfg.kind == "bert", Bert.forward (bert.py:283-340). Returns [b,seq,m,C] fp32;
+    with ``return_attn`` (bert.py:505-508 / 337-340) a tuple (logits, [per-layer head-averaged attention [b, seq+1, seq+1]])."""
     if cfg.kind == "bert":
-        return bert_forward(sd, cfg, tokens, labels, drop)
+        return bert_forward(sd, cfg, tokens, labels, drop, return_attn)
     b = tokens.shape[0]
     lab = labels.long().clone()
     if drop is not None:
@@ -161,13 +167,14 @@ def lfq_bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor,
     x_tok = F.linear(token_bit_vectors(tokens, cfg), sd["input_proj.weight"], sd["input_proj.bias"])
     x_cls = sd["class_emb.weight"][lab].unsqueeze(1)
     x = torch.cat([x_tok, x_cls], dim=1) + sd["pos_emb"]                          # class row LAST
-    x = _trunk(sd, cfg, x)
+    attn = [] if return_attn else None
+    x = _trunk(sd, cfg, x, attn)
     logits = F.linear(x, sd["prediction_layer.weight"], sd["prediction_layer.bias"])
     logits = logits.reshape(b, cfg.seq + 1, cfg.splits, cfg.group_codes)
-    return logits[:, :cfg.seq]
+    return (logits[:, :cfg.seq], attn) if return_attn else logits[:, :cfg.seq]
 
 
-def bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor, drop: Optional[Tensor] = None) -> Tensor:
+def bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor, drop: Optional[Tensor] = None, return_attn: bool = False):
     """Bert.forward (bert.py:283-340): per-group embedding tables summed, output head tied to them plus a per-position bias."""
     lab = labels.long().clone()
     if drop is not None:
@@ -177,10 +184,12 @@ def bert_forward(sd: StateDict, cfg: GenCfg, tokens: Tensor, labels: Tensor, dro
         x_tok = x_tok + sd[f"tok_emb_list.{g}.weight"][tokens[..., g]]            # :313-315
     x_cls = sd["class_emb.weight"][lab].unsqueeze(1)
     x = torch.cat([x_tok, x_cls], dim=1) + sd["pos_emb"]
-    x = _trunk(sd, cfg, x)
+    attn = [] if return_attn else None
+    x = _trunk(sd, cfg, x, attn)
     C_ = cfg.group_codes
     logits = [torch.matmul(x, sd[f"tok_emb_list.{g}.weight"].t()[:, :C_])[:, :cfg.seq] + sd[f"bias.{g}"] for g in range(cfg.splits)]   # :329-332
-    return torch.stack(logits, dim=2)
+    out = torch.stack(logits, dim=2)
+    return (out, attn) if return_attn else out
 
 
 # --------------------------------------------------------------------------- schedule

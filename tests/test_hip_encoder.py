@@ -88,3 +88,33 @@ def test_encoder_rejects_bad_input():
         tk.encode(torch.zeros(1, 3, 60, 64, device=DEV))
     with pytest.raises(ValueError):
         tk.encode(torch.zeros(1, 4, 64, 64, device=DEV))
+
+
+def test_encoder_average_pool_variant_vs_reference_golden():
+    """sample_with_conv=False (autoencoder.py:179-182): avg_pool2d(2, 2) between the encoder stages; golden from the reference."""
+    from oracle.make_golden_variants import AVGPOOL_TOK as cfg
+    z = load_golden("tok_avgpool_tiny.npz")
+    sd = O.make_tokenizer_weights(cfg, seed=int(z["seed"]), with_encoder=True)
+    tk = hip_tokenizer(cfg, sd)
+    x = torch.from_numpy(z["enc_input"])
+    zq, idx, zraw = tk._encode(x.to(DEV), want_raw=True)
+    # pre-sign latent against the oracle (same stages, pooling instead of the strided conv)
+    h = O._conv_same(x, sd["encoder.conv_in.weight"], None)
+    for s in range(cfg.num_resolutions):
+        for r in range(cfg.num_res_blocks):
+            h = O._res_block(h, sd, f"encoder.down.{s}.res_blocks.{r}")
+        if s < cfg.num_resolutions - 1:
+            h = torch.nn.functional.avg_pool2d(h, 2, 2)
+    for r in range(cfg.num_res_blocks):
+        h = O._res_block(h, sd, f"encoder.mid.res_blocks.{r}")
+    zref = O._conv_same(O._gn_silu(h, sd, "encoder.norm_out"), sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"])
+    err = float((zraw.cpu() - zref).abs().max())
+    assert err < 0.03 * float(zref.abs().mean())
+    K = cfg.token_size
+    bits = (idx.cpu()[..., None] >> torch.arange(K)) & 1
+    ref_bits = (torch.from_numpy(z["enc_indices"]).long()[..., None] >> torch.arange(K)) & 1
+    clear = zref.permute(0, 2, 3, 1).abs() > 2 * err
+    assert bool((bits == ref_bits)[clear].all()) and float((bits != ref_bits).float().mean()) < 0.02
+    # decode of the reference's own codes against the reference's reconstruction
+    rec = tk.decode(torch.from_numpy(z["enc_zq"]).float().to(DEV))
+    assert float((rec.cpu() - torch.from_numpy(z["recon"]).float()).abs().max()) < 0.03

@@ -105,8 +105,8 @@ def test_generator_rejects_bad_input():
     m = hip_generator(TINY_GEN, golden_weights(z))
     with pytest.raises(ValueError):
         m(torch.zeros(1, 255, 2, dtype=torch.long, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 256, 2, dtype=torch.long, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), None, return_attn=True)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 256, 2, dtype=torch.long, device=DEV), torch.zeros(2, dtype=torch.long, device=DEV), None, return_attn=True)
 
 
 # --------------------------------------------------------------------------------------------- sampling step

@@ -63,3 +63,38 @@ def test_variant_full_width_prenorm_bert():
     with pytest.raises(RuntimeError):                     # the tied head has one table per group: fp16x2 weights are refused loudly
         m.weight_split = 1
         m(toks.to(DEV), y.to(DEV), drop.to(DEV))
+
+
+@pytest.mark.parametrize("name", ["attn_lfq_postnorm", "attn_lfq_prenorm", "attn_bert_postnorm"])
+def test_return_attn_vs_reference_golden(name):
+    """return_attn=True: (logits, [head-averaged attention map per layer]) against the maps captured from the reference classes."""
+    from oracle.make_golden_variants import ATTN_VARIANTS
+    cfg, seed = ATTN_VARIANTS[name]
+    z = load_golden("gen_variants_tiny.npz")
+    sd = O.make_generator_weights(cfg, seed=seed, head_gain=20.0)
+    m = _build(cfg, sd)
+    args = [torch.from_numpy(z[f"{name}.{k}"]).to(DEV) for k in ("tokens", "labels", "drop")]
+    logits, attn = m(*args, return_attn=True)
+    assert isinstance(attn, list) and len(attn) == cfg.depth and all(a.shape == (2, 257, 257) and a.dtype == torch.float32 for a in attn)
+    assert torch.equal(logits, m(*args))                                        # the maps are a side output: logits unchanged
+    want = torch.from_numpy(z[f"{name}.attn"]).float()
+    for l in range(cfg.depth):
+        got = attn[l].cpu()
+        assert float((got.sum(-1) - 1).abs().max()) < 1e-5                      # rows are distributions
+        err = float((got - want[l]).abs().max())
+        print(f"{name} layer {l}: max |attn err| {err:.2e} (max weight {float(want[l].max()):.3f})")
+        assert err < 2e-3                                                       # fp16 Q/K rows + fp16 storage of the golden
+
+
+def test_return_attn_full_width():
+    """hidden 1024 / 16 heads of 64 (the shipped width), 2 layers, 3 sequences, against the oracle's maps."""
+    cfg = O.GenCfg(bits=12, splits=2, depth=2)
+    sd = O.make_generator_weights(cfg, seed=78, head_gain=12.0)
+    m = _build(cfg, sd)
+    g = torch.Generator().manual_seed(4)
+    toks = torch.randint(0, 65, (3, 256, 2), generator=g); y = torch.tensor([5, 900, 17]); drop = torch.tensor([False, True, False])
+    logits, attn = m(toks.to(DEV), y.to(DEV), drop.to(DEV), return_attn=True)
+    ref_logits, ref_attn = O.lfq_bert_forward(sd, cfg, toks, y, drop, return_attn=True)
+    assert float((logits.cpu() - ref_logits).norm() / ref_logits.norm()) < 2e-3
+    for l in range(2):
+        assert float((attn[l].cpu() - ref_attn[l]).abs().max()) < 1e-3

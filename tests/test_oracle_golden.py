@@ -169,3 +169,35 @@ def test_generator_variants_match_reference_goldens():
         assert sha(sd["pos_emb"]) == str(z[f"{name}.w_sha"])
         got = O.lfq_bert_forward(sd, cfg, torch.from_numpy(z[f"{name}.tokens"]), torch.from_numpy(z[f"{name}.labels"]), torch.from_numpy(z[f"{name}.drop"]))
         assert float((got - torch.from_numpy(z[f"{name}.logits"])).abs().max()) < 2e-4, name
+
+
+def test_return_attn_matches_reference_goldens():
+    """return_attn=True (bert.py:461, 505-508): logits unchanged and one head-averaged attention map [b, 257, 257] per layer,
+    post- / pre-norm LFQBert and the table Bert, against maps captured from the reference (stored as fp16)."""
+    from oracle.make_golden_variants import ATTN_VARIANTS
+    z = load_golden("gen_variants_tiny.npz")
+    for name, (cfg, seed) in ATTN_VARIANTS.items():
+        sd = O.make_generator_weights(cfg, seed=seed, head_gain=20.0)
+        assert sha(sd["pos_emb"]) == str(z[f"{name}.w_sha"])
+        toks, labels, drop = (torch.from_numpy(z[f"{name}.{k}"]) for k in ("tokens", "labels", "drop"))
+        logits, attn = O.lfq_bert_forward(sd, cfg, toks, labels, drop, return_attn=True)
+        assert float((logits - torch.from_numpy(z[f"{name}.logits"])).abs().max()) < 2e-4, name
+        assert torch.equal(logits, O.lfq_bert_forward(sd, cfg, toks, labels, drop))
+        want = torch.from_numpy(z[f"{name}.attn"]).float()
+        assert len(attn) == cfg.depth and want.shape == (cfg.depth, 2, 257, 257)
+        for l in range(cfg.depth):
+            assert float((attn[l] - want[l]).abs().max()) < 1e-3, (name, l)               # fp16 storage of values in [0, 1]
+            assert float((attn[l].sum(-1) - 1).abs().max()) < 1e-5
+
+
+def test_tokenizer_average_pool_variant_matches_reference_golden():
+    """sample_with_conv=False: F.avg_pool2d(2, 2) between the encoder stages instead of the stride-2 convolution (autoencoder.py:179-182)."""
+    from oracle.make_golden_variants import AVGPOOL_TOK as cfg
+    z = load_golden("tok_avgpool_tiny.npz")
+    sd = O.make_tokenizer_weights(cfg, seed=int(z["seed"]), with_encoder=True)
+    assert sha(sd["encoder.conv_in.weight"]) == str(z["w_sha_enc_conv_in"]) and len(sd) == int(z["n_keys"])
+    assert not any("down_conv" in k for k in sd)
+    zq, idx = O.encode_image(sd, cfg, torch.from_numpy(z["enc_input"]))
+    assert torch.equal(idx, torch.from_numpy(z["enc_indices"])) and torch.equal(zq, torch.from_numpy(z["enc_zq"]).float())
+    rec = O.decode_latents(sd, cfg, zq)
+    assert float((rec - torch.from_numpy(z["recon"]).float()).abs().max()) < 5e-3          # fp16 storage of O(1) pixels
