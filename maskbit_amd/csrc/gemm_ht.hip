@@ -130,7 +130,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     foff[ks] = l15 * 128 + (((ks * 4 + g) ^ (l15 >> 1)) * 16);
-    xoffe[ks] = 2 * AH_BYTES + 2 * BH_BYTES + (l15 & 7) * 128 + (((ks * 4 + g) ^ ((l15 & 7) >> 1)) * 16);
+    // class row: only lane row 0 feeds a result that is kept, so the other 15 lane rows read their usual (conflict-free)
+    // A-fragment addresses instead of the X buffer -- 16 lanes on the 8 X rows was a 2-way bank conflict on every read
+    xoffe[ks] = l15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + (ks * 4 + g) * 16 : foff[ks];
   }
   const int xbase = wm * (8 * MT) * 128;              // this wave's rows inside an A half-tile
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
