@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MB_ABI_VERSION 2
+#define MB_ABI_VERSION 3
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
 typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
@@ -47,6 +47,12 @@ typedef struct {
    * Checkpoint keys then are tok_emb_list.{g}.weight and bias.{g} instead of input_proj.* / prediction_layer.*. */
   int prenorm;
   int embed_tables;
+  /* Activation precision of the GEMMs that consume a LayerNorm output (QKV projection and FFN up-projection): 0 = one fp16
+   * value per element; 1 = fp16 hi + lo pairs (x = hi + lo, |x - hi - lo| <= 2^-22 |x|): the LayerNorm kernels store both
+   * halves and those two GEMMs sweep the weight twice (hi.W + lo.W in the same fp32 accumulator; twice their work).  With
+   * classifier-free guidance this rounding point decides the token parity: see DESIGN.md, "Precision".  Not combined with
+   * weight_split. */
+  int act_split;
 } mb_gen_cfg;
 
 /* ConvDecoder configuration (modeling/modules/autoencoder.py:358-397, configs/tokenizer yaml files). */
@@ -141,8 +147,12 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
                const float* ln_stats /*or NULL: residual = LayerNorm(residual rows) from {mean,rstd}[M]*/, const float* ln_g,
                const float* ln_b, int period, int variant, mb_stream stream);
 /* LayerNorm over rows (modeling/bert.py:69-70,137-139): any of x_f32 / x_h16 / stats ({mean, rstd} per row) may be NULL. */
-int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, float* stats, int M, int d,
-                 mb_stream stream);
+int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x_lo, float* stats,
+                 int M, int d, mb_stream stream);
+/* A GEMM with split activations: out = (A_hi + A_lo) . W^T + bias through the engine's kernels (A_hi, A_lo fp16 [M, kw], W fp16
+ * [N, kw]; x_lo as written by mb_layernorm).  Diagnostic / test entry for mb_gen_cfg.act_split. */
+int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual,
+                      float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
             void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
 int mb_prof_enable(int on); /* 0 off; n >= 1: HIP-event timing of every kernel of every n-th generator forward (and of all other calls) */

@@ -11,11 +11,11 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmaskbit_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GenCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass", "weight_split", "prenorm", "embed_tables")]
+    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass", "weight_split", "prenorm", "embed_tables", "act_split")]
 
 
 class DecCfg(C.Structure):
@@ -51,7 +51,9 @@ SIGNATURES = {
     "mb_split_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mb_gemm_ex": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "mb_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mb_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mb_gemm_act_split": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]),
     "mb_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_void_p]),
     "mb_prof_enable": (C.c_int, [C.c_int]),

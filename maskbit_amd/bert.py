@@ -21,6 +21,7 @@ from . import _lib
 from .base_model import BaseModel, ParamSpec
 
 DEFAULT_WEIGHT_SPLIT = 0
+DEFAULT_ACT_SPLIT = 0
 
 
 def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int, prenorm: bool = False,
@@ -76,6 +77,9 @@ class LFQBert(BaseModel):
         # GEMM weight precision of the device engine (not a reference argument): 0 = fp16, 1 = fp16 hi+lo pairs ("fp16x2",
         # twice the GEMM work, weight rounding 2^-22).  Default from MASKBIT_AMD_WEIGHT_SPLIT; may be changed before a call.
         self.weight_split = int(os.environ.get("MASKBIT_AMD_WEIGHT_SPLIT", str(DEFAULT_WEIGHT_SPLIT)))
+        # Activation precision of the GEMMs that read a LayerNorm output (QKV, FFN up): 0 = fp16, 1 = fp16 hi+lo pairs (those two GEMMs
+        # do twice the work).  Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
+        self.act_split = int(os.environ.get("MASKBIT_AMD_ACT_SPLIT", str(DEFAULT_ACT_SPLIT)))
         self._engine_split = None
         if not self.embed_tables:
             self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
@@ -89,8 +93,8 @@ class LFQBert(BaseModel):
     # ---- engine hooks ---------------------------------------------------------------------
     def _engine_create(self, capacity: int):
         cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass,
-                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables))
-        self._engine_split = int(self.weight_split)
+                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables), int(self.act_split))
+        self._engine_split = (int(self.weight_split), int(self.act_split))
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
         return h
@@ -104,7 +108,7 @@ class LFQBert(BaseModel):
 
     def engine(self, min_seqs: int):
         """Device engine able to hold ``min_seqs`` sequences (CFG needs 2 x batch)."""
-        if self._engine is not None and self._engine_split != int(self.weight_split):
+        if self._engine is not None and self._engine_split != (int(self.weight_split), int(self.act_split)):
             self._drop_engine()                                    # precision mode changed: rebuild and repack
         have = self._engine_key[1] if self._engine_key else 0
         return self._ensure_engine(max(min_seqs, have, 16))

@@ -110,7 +110,7 @@ struct mb_gen {
   const float* sc(int idx) const { return split ? wscale + idx : nullptr; }
   // workspace
   float *y_f32 = nullptr, *ln_stats = nullptr;       // fp32 residual stream (pre-LayerNorm rows) and {mean, rstd} per row
-  h16 *x_h16 = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;
+  h16 *x_h16 = nullptr, *x_lo = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;   // x_lo: lo halves of x_h16 (cfg.act_split)
   // loop state for mb_sample
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
   uint8_t* drop_cfg = nullptr;
@@ -140,10 +140,18 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   int attn_rc = 0;
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
+  // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
+  // K = 2d K-tiles, the first d columns pairing x_h16 with W, the second d columns x_lo with the same W
+  auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc) {
+    GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
+    if (g->x_lo) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
+    gemm_tn(s, epi, ga);
+  };
   {
     ProfScope p("embed_ln", s, true);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
+    e.x_lo = g->x_lo;
     embed_ln(s, e);
   }
   if (c.prenorm) {
@@ -151,16 +159,16 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
     for (int l = 0; l < c.depth; ++l) {
       const mb_gen::Layer& L = g->layers[l];
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
       { ProfScope p("gemm_qkv", s, true);
-        gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
+        xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l)); }
       { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
       attn_rc |= attn_maps(l);
       { ProfScope p("gemm_attn_out", s, true);
         gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)}); }
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
       { ProfScope p("gemm_ffn_up", s, true);
-        gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d * ks, 0, d, g->sc(4 * l + 2)}); }
+        xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2)); }
       { ProfScope p("gemm_ffn_down", s, true);
         gemm_tn(s, EPI_RES_F32, GemmArgs{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)}); }
     }
@@ -169,7 +177,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     { ProfScope p("gemm_qkv", s, true);
-      gemm_tn(s, EPI_H16, GemmArgs{g->x_h16, L.wqkv, L.bqkv, nullptr, nullptr, g->qkv, M, 3 * d, d * ks, 0, d, g->sc(4 * l)}); }
+      xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l)); }
     { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
     attn_rc |= attn_maps(l);
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
@@ -179,14 +187,14 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo); }
     { ProfScope p("gemm_ffn_up", s, true);
-      gemm_tn(s, EPI_GELU_H16, GemmArgs{g->x_h16, L.w1, L.b1, nullptr, nullptr, g->h, M, f, d * ks, 0, d, g->sc(4 * l + 2)}); }
+      xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2)); }
     { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo); }
   }
   }
   { ProfScope p("gemm_head", s, true);
@@ -248,10 +256,21 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
-int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, float* stats, int M, int d,
-                 mb_stream stream) {
+int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual, float* out_f32,
+                      void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
+  if (!A_hi || !A_lo || !W || !bias || epi < 0 || epi > 3 || kw <= 0 || kw % 64) return fail(-1, "mb_gemm_act_split: bad arguments");
+  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, 2 * kw, 0, 0, nullptr};
+  a.A2 = (const h16*)A_lo; a.kw = kw;
+  ProfScope p("gemm_diag", (hipStream_t)stream);
+  mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x_lo, float* stats, int M,
+                 int d, mb_stream stream) {
   if (!y || !gamma || !beta || M <= 0 || d <= 0 || d > 2048) return fail(-1, "mb_layernorm: bad arguments");
-  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, stats, M, d);
+  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, stats, M, d, (h16*)x_lo);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -287,6 +306,8 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if ((c.prenorm != 0 && c.prenorm != 1) || (c.embed_tables != 0 && c.embed_tables != 1)) return fail(-1, "prenorm / embed_tables must be 0 or 1");
   if (c.embed_tables && c.weight_split) return fail(-1, "weight_split is not supported with embed_tables (the tied head spans one table per group)");
   if (c.embed_tables && c.splits > 8) return fail(-1, "embed_tables supports up to 8 token groups");
+  if (c.act_split != 0 && c.act_split != 1) return fail(-1, "act_split must be 0 or 1");
+  if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
@@ -310,6 +331,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   rc |= galloc(g, &g->wl, ws * d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
   rc |= galloc(g, &g->wp, ws * c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
   rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->ln_stats, M * 2); rc |= galloc(g, &g->x_h16, M * d);
+  if (c.act_split) rc |= galloc(g, &g->x_lo, M * d);
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
   rc |= galloc(g, &g->tok_a, B * P); rc |= galloc(g, &g->tok_b, B * P); rc |= galloc(g, &g->tok_cfg, B * P);

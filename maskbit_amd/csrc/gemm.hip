@@ -28,18 +28,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   const int tiles_m = (a.M + BM - 1) / BM;
   const int L = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
-  const int K = a.K, KA = a.ka ? a.ka : a.K, nka = KA / BK;
+  const int K = a.K, KA = a.ka ? a.ka : (a.kw ? a.kw : a.K), nka = KA / BK;
+  const int KW = a.kw ? a.kw : a.K, nkw = KW / BK;   // split activations: W has kw columns and is swept twice, A2 takes over from A
 
   // ---- staging: wave w owns rows [32w, 32w+32) of both tiles; 4 DMA instructions of 8 rows each
   const h16* xsrc[4];
   const h16* wsrc[4];
+  const ptrdiff_t a2 = a.A2 ? a.A2 - a.A : 0;       // second sweep of A: the lo halves (split activations) or A itself (split weights)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = wave * 32 + j * 8 + (lane >> 3);
     const int slot = (lane & 7) ^ ((row >> 1) & 7);
     const int mr = min(m0 + row, a.M - 1), nr = min(n0 + row, a.N - 1);
     xsrc[j] = a.A + (size_t)mr * KA + slot * 8;
-    wsrc[j] = a.W + (size_t)nr * K + slot * 8;
+    wsrc[j] = a.W + (size_t)nr * KW + slot * 8;
   }
   auto stage = [&](int t, int buf) {
     const int ta = t < nka ? t : t - nka;          // split weights: A is swept once per weight half
@@ -47,8 +49,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     char* wb = xb + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      MB_GLDS16(xsrc[j] + ta * BK, xb + j * 8 * 128);
-      MB_GLDS16(wsrc[j] + t * BK, wb + j * 8 * 128);
+      MB_GLDS16(xsrc[j] + (t < nka ? 0 : a2) + ta * BK, xb + j * 8 * 128);
+      MB_GLDS16(wsrc[j] + (t < nkw ? t : t - nkw) * BK, wb + j * 8 * 128);
     }
   };
 

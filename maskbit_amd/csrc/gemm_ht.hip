@@ -64,7 +64,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
   const int K = a.K, nk = K / 64;
-  const int KA = a.ka ? a.ka : K, nka = KA / 64;      // split weights: A has KA = K/2 columns and is swept twice
+  const int KA = a.ka ? a.ka : (a.kw ? a.kw : K), nka = KA / 64;   // split weights: A has KA = K/2 columns and is swept twice
+  const int KW = a.kw ? a.kw : K, nkw = KW / 64;       // split activations: W has K/2 columns and is swept twice, A2 (lo halves) takes over from A
+  const h16* const Alo = a.A2 ? a.A2 : a.A;
   const int ntiles = tiles_m * tiles_n;
 
   // ---- per-tile DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
@@ -98,24 +100,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         const int gm = min(p.m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
         p.offA[h][j] = (uint32_t)gm * (uint32_t)KA + slot_a * 8;
         const int gn = min(p.n0 + wns * 64 + h * 32 + c, a.N - 1);
-        p.offB[h][j] = (uint32_t)gn * (uint32_t)K + slot_b * 8;
+        p.offB[h][j] = (uint32_t)gn * (uint32_t)KW + slot_b * 8;
       }
     }
     // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
     p.offX = (uint32_t)min(p.m0 + 256, a.M - 1) * (uint32_t)KA + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
   };
   auto dma_x = [&](const Plan& p, int t) {
-    if (SEQ && wave == 7) MB_GLDS16_AUX(a.A + p.offX + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
+    if (SEQ && wave == 7) MB_GLDS16_AUX((t < nka ? a.A : Alo) + p.offX + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
   };
   auto dma_a = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + h * AH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.A + p.offA[h][j] + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
+    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX((t < nka ? a.A : Alo) + p.offA[h][j] + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
   };
   auto dma_b = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.W + p.offB[h][j] + t * 64, buf + dstB[j], AUX);
+    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.W + p.offB[h][j] + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
   };
   // all of K-tiles 0 and 1 of a tile (both LDS parities must be free)
   // (nk >= 2 is a precondition of this kernel: gemm_ht_supported)

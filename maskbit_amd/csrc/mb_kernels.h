@@ -33,6 +33,11 @@ struct GemmArgs {
   const float* ln_b = nullptr;
   // EPI_LOGITS_F32: bias is [period - 1][N] (one row per position: Bert's per-position output bias, bert.py:262,332) when set
   int bias_per_pos = 0;
+  // Split-activation ("fp16 hi+lo") GEMMs: A2 = the lo halves x - fp16(x) of the activations whose fp16 hi halves are A, both
+  // [M, kw]; W has kw = K/2 columns and is swept twice (K-tiles below K/2 pair A with W, the others A2 with W), so both
+  // products land in the same fp32 accumulator.  A2 = null / kw = 0: plain GEMM.  Not combined with ka.
+  const h16* A2 = nullptr;
+  int kw = 0;
 };
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -41,7 +46,7 @@ void gemm_w4(hipStream_t s, GemmEpi epi, const GemmArgs& a);   // 4-wave 128x128
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d);
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr);   // x_lo: fp16(x - fp16(x)), optional
 
 // ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------
 struct EmbedArgs {
@@ -57,6 +62,7 @@ struct EmbedArgs {
   int nb, seq, m, gbits, d, nclass;
   // Bert (modeling/bert.py:313-315): per-group embedding tables [m][2^gbits + 1][d] summed instead of the bit projection
   const float* tables = nullptr;
+  h16* x_lo = nullptr;     // optional: lo halves of x_h16 (split-activation GEMMs)
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);

@@ -15,7 +15,8 @@ constexpr int MAXS = 32;  // scalar fallback path: d <= 64 * MAXS = 2048
 template <int NV>
 __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          float eps, float* xo, h16* xb, float* st = nullptr) {
+                                          float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr) {
+  // xl (optional): the fp16 lo halves o - fp16(o) of the same row, for the split-activation GEMMs
   constexpr bool VEC = NV > 0;
   constexpr int nv = NV;
   float s = 0.f;
@@ -46,7 +47,9 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
       o.x = ln_affine(v[q].x, mean, rstd, g.x, b.x); o.y = ln_affine(v[q].y, mean, rstd, g.y, b.y);
       o.z = ln_affine(v[q].z, mean, rstd, g.z, b.z); o.w = ln_affine(v[q].w, mean, rstd, g.w, b.w);
       if (xo) *(float4*)(xo + c) = o;
-      if (xb) *(h16x4*)(xb + c) = h16x4{to_h(o.x), to_h(o.y), to_h(o.z), to_h(o.w)};
+      const h16x4 hi = {to_h(o.x), to_h(o.y), to_h(o.z), to_h(o.w)};
+      if (xb) *(h16x4*)(xb + c) = hi;
+      if (xl) *(h16x4*)(xl + c) = h16x4{to_h(o.x - (float)hi[0]), to_h(o.y - (float)hi[1]), to_h(o.z - (float)hi[2]), to_h(o.w - (float)hi[3])};
     }
   } else {
     for (int q = 0; q < ns; ++q) {
@@ -55,6 +58,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
         const float o = ln_affine(sc[q], mean, rstd, gamma[c], beta[c]);
         if (xo) xo[c] = o;
         if (xb) xb[c] = to_h(o);
+        if (xl) xl[c] = to_h(o - (float)to_h(o));
       }
     }
   }
@@ -63,7 +67,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* x_f32,
-                                                      h16* x_h16, float* stats, int M, int d) {
+                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -77,15 +81,16 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   }
   else     { for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; sc[q] = c < d ? yr[c] : 0.f; } }
   ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
-                 x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr);
+                 x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr,
+                 x_lo ? x_lo + (size_t)row * d : nullptr);
 }
 
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d) {
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo) {
   dim3 grid((M + 3) / 4), block(256);
-  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d);
-  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d);
-  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d);
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo);
 }
 
 // One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,
@@ -169,7 +174,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
       sc[q] = e;
     }
   }
-  ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d);
+  ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d, nullptr,
+                 a.x_lo ? a.x_lo + (size_t)row * d : nullptr);
 }
 
 void embed_ln(hipStream_t s, const EmbedArgs& a) {

@@ -149,8 +149,10 @@ def main():
         O.sample_loop(fwd, B, y, num_steps=N, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0,
                       randomize_temperature=8.2, mask_schedule_strategy="arccos", mask_token=64, codebook_splits=2, record=rec)
         print(f"  oracle loop {time.time() - t0:.1f}s on {torch.get_num_threads()} threads", flush=True)
-        for split in [int(v) for v in os.environ.get("TF_SPLITS", "0").split(",")]:
-            m.weight_split = split
+        modes = [(int(v), 0) for v in os.environ.get("TF_SPLITS", "0").split(",")] + [(0, 1)] * int(os.environ.get("TF_ACT", "0"))
+        quiet = bool(int(os.environ.get("TF_QUIET", "0")))
+        for split, act in modes:
+            m.weight_split, m.act_split = split, act
             tot_m = tot_n = 0
             for i, r in enumerate(rec):
                 tin = r.tokens_in.to(dev).contiguous()
@@ -166,9 +168,10 @@ def main():
                 mm = int((pred.cpu() != r.pred)[msk].sum()); nn_ = int(msk.sum())
                 tot_m += mm; tot_n += nn_
                 pmax = torch.softmax(r.logits_c + r.scale * (r.logits_c - r.logits_u), -1).max(-1).values[msk].mean()
-                print(f"  step {i}: scale={r.scale:.3f} masked={nn_} pred mismatch={mm} ({mm / max(nn_, 1):.5f}) remask diff={int((tout.cpu() != r.tokens_out).sum())} "
+                if not quiet:
+                  print(f"  step {i}: scale={r.scale:.3f} masked={nn_} pred mismatch={mm} ({mm / max(nn_, 1):.5f}) remask diff={int((tout.cpu() != r.tokens_out).sum())} "
                       f"logit err max={float((lc.cpu() - r.logits_c).abs().max()):.3f} mean max-prob={float(pmax):.3f}", flush=True)
-            print(f"[tf_full] weight_split={split}: teacher-forced token mismatch over masked positions: {tot_m}/{tot_n} = {tot_m / tot_n:.6f}", flush=True)
+            print(f"[tf_full] weight_split={split} act_split={act}: teacher-forced token mismatch over masked positions: {tot_m}/{tot_n} = {tot_m / tot_n:.6f}", flush=True)
         del m
 
     if "time" in what:

@@ -158,7 +158,7 @@ def test_layernorm_residual_epilogue(variant, M, N, K):
     g = torch.rand(N, device=DEV) + 0.5
     b = torch.randn(N, device=DEV) * 0.2
     x32 = torch.empty_like(y); x16 = torch.empty(M, N, device=DEV, dtype=torch.float16); stats = torch.empty(M, 2, device=DEV)
-    _lib.check(lib.mb_layernorm(y.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-12, x32.data_ptr(), x16.data_ptr(), stats.data_ptr(), M, N, st))
+    _lib.check(lib.mb_layernorm(y.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-12, x32.data_ptr(), x16.data_ptr(), None, stats.data_ptr(), M, N, st))
     torch.cuda.synchronize()
     ref_ln = torch.nn.functional.layer_norm(y, (N,), g, b, 1e-12)
     assert float((x32 - ref_ln).abs().max()) < 2e-5
@@ -183,3 +183,52 @@ def test_four_wave_variant_matches_half_tile_kernel(epi, M, N, K):
     bias = torch.randn(N, device=DEV) * 0.1
     res = torch.randn(M, N, device=DEV) if epi == 2 else None
     assert torch.equal(_run(epi, A, W, bias, res, 4), _run(epi, A, W, bias, res, 8))
+
+
+@pytest.mark.parametrize("variant", [-1, 8, 257, 0])
+@pytest.mark.parametrize("epi,M,N,K", [(2, 1028, 512, 1024), (0, 771, 256, 128), (1, 1028, 1024, 256), (2, 200, 128, 192)])
+def test_split_activation_gemm(variant, epi, M, N, K):
+    """fp16 hi+lo activation pairs (mb_gen_cfg.act_split): mb_layernorm writes x_hi and x_lo = fp16(x - x_hi); the GEMM over the pair
+    sweeps W twice (K-tiles 0..K/64-1 take x_hi, the rest x_lo) and must track the fp32 LayerNorm rows far better than x_hi alone."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    if variant == 257 and M % 257:
+        pytest.skip("sequence-aligned tiles need M % 257 == 0")
+    if variant in (8, 257) and (M < 512 or N % 256 or 2 * K < 128):
+        pytest.skip("half-tile kernel shape limits")
+    torch.manual_seed(epi * 11 + (variant & 7))
+    y = torch.randn(M, K, device=DEV) * 3.0
+    g = torch.rand(K, device=DEV) + 0.5
+    b = torch.randn(K, device=DEV) * 0.2
+    st = torch.cuda.current_stream().cuda_stream
+    x32 = torch.empty(M, K, device=DEV)
+    xh = torch.empty(M, K, device=DEV, dtype=torch.float16)
+    xl = torch.empty(M, K, device=DEV, dtype=torch.float16)
+    _lib.check(lib.mb_layernorm(y.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-12, x32.data_ptr(), xh.data_ptr(), xl.data_ptr(), None, M, K, st))
+    torch.cuda.synchronize()
+    assert torch.equal(xh, x32.half()) and torch.equal(xl, (x32 - xh.float()).half())           # exactly the hi / lo halves of the fp32 rows
+    assert float((xh.double() + xl.double() - x32.double()).abs().max()) < 2.0 ** -20
+    W = (torch.randn(N, K, device=DEV) * 0.05).half()
+    bias = torch.randn(N, device=DEV) * 0.1
+    res = torch.randn(M, N, device=DEV) if epi == 2 else None
+    out32 = torch.full((M, N), float("nan"), device=DEV) if epi == 2 else None
+    out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16) if epi != 2 else None
+    _lib.check(lib.mb_gemm_act_split(epi, xh.data_ptr(), xl.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None,
+                                     out32.data_ptr() if out32 is not None else None, out16.data_ptr() if out16 is not None else None,
+                                     M, N, K, variant, st))
+    torch.cuda.synchronize()
+    ref = x32.double() @ W.double().t() + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    got = (out32 if out32 is not None else out16).double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    if epi == 2:
+        single = _run(epi, xh, W, bias, res, variant if variant != 257 else 0, 0).double()
+        err_single = float((single - ref).abs().max())
+        print(f"max err vs fp32 rows: hi+lo {err:.2e}, hi only {err_single:.2e}")
+        assert err < 3e-5 and err < err_single / 8
+    else:
+        assert err < 2e-3 * max(1.0, float(ref.abs().max()))       # one fp16 rounding of the result

@@ -24,13 +24,13 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mb_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.mb_abi_version() == _lib.ABI_VERSION == 3
     assert isinstance(lib.mb_last_error(), bytes)
 
 
 def test_struct_layouts_match_header():
     from maskbit_amd import _lib
-    assert ctypes.sizeof(_lib.GenCfg) == 11 * 4
+    assert ctypes.sizeof(_lib.GenCfg) == 12 * 4
     assert ctypes.sizeof(_lib.DecCfg) == (5 + 8 + 1 + 3) * 4
     assert ctypes.sizeof(_lib.SamplePlan) == 8 + 3 * 8
 
