@@ -147,7 +147,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       wb[H][i][ks] = *(const h16x8*)(par + wbase + (H) * BH_BYTES + i * 16 * 128 + foff[ks]);
 #define MB_SYNC_L()                                     \
   __builtin_amdgcn_s_barrier();                         \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
   __builtin_amdgcn_sched_barrier(0);                    \
   __builtin_amdgcn_s_setprio(1);
 #define MB_MMA(AH, BH)                                                                              \
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       // K-tile t+1 is staged by phases 0/1 (except K-tile 1: part of the prologue), K-tile t+2 by phases 2/3
       const bool n1 = XP != 2 && t >= 1 && t + 1 < nk, n2 = XP != 2 && t + 2 < nk;
       // ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0]; refill A1 of the other parity
-      MB_LOAD_A(0) MB_LOAD_B(0)
+      MB_LOAD_B(0) MB_LOAD_A(0)                          // B first: the first MFMAs need both B fragments and only xa[0]
       h16x8 xe[2];
       if (SEQ && wm == 0) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
       if (n1) dma_a(cur, t + 1, 1);
