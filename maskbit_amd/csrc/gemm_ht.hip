@@ -176,13 +176,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
     for (int t = 0; t < nk; ++t) {
       const char* par = smem + (t & 1) * PAR_BYTES;
-      // K-tile t+1 is staged by phases 0/1 (except K-tile 1: part of the prologue), K-tile t+2 by phases 2/3
+      // DMA issue is placed where the read phase is short (a global_load_lds blocks the issuing wave until the address unit takes
+      // it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3
+      // (no reads).  Every half-tile is re-filled >= 2 phases after its last reader; K-tile 1 came with the prologue.
       const bool n1 = XP != 2 && t >= 1 && t + 1 < nk, n2 = XP != 2 && t + 2 < nk;
-      // ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0]; refill A1 of the other parity
+      // ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0]
       MB_LOAD_B(0) MB_LOAD_A(0)                          // B first: the first MFMAs need both B fragments and only xa[0]
       h16x8 xe[2];
       if (SEQ && wm == 0) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
-      if (n1) dma_a(cur, t + 1, 1);
       MB_SYNC_L()
       if (SEQ && wm == 0) {
 #pragma unroll
@@ -191,10 +192,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[0][n][ks], xe[ks], acce[n]);
       }
       MB_MMA(0, 0)
-      // ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill B0 of the other parity
+      // ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1
       MB_LOAD_B(1)
       if (SEQ && wm == 1) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
-      if (n1) dma_b(cur, t + 1, 0);
+      if (n1) dma_a(cur, t + 1, 1);
       MB_SYNC_L()
       if (SEQ && wm == 1) {
 #pragma unroll
@@ -207,14 +208,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       MB_LOAD_A(1)
       if (n2) dma_a(cur, t + 2, 0);
       MB_SYNC_L() MB_MMA(1, 1)
-      // ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1 (and X) of this parity with K-tile t+2; K-tile t+1 must have landed.
+      // ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed.
       // In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output
       // stores stay in flight until the wait of K-tile 1.
-      if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); }
+      if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); dma_b(cur, t + 2, 0); }
       if (t >= 1 || XP == 2) {
-        if (n2) {
-          if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (n2) {                                        // A0, B1, (X,) B0 of K-tile t+2 may stay in flight
+          if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       MB_SYNC_L() MB_MMA(1, 0)
