@@ -50,8 +50,9 @@ typedef struct {
   /* Activation precision of the GEMMs that consume a LayerNorm output (QKV projection and FFN up-projection): 0 = one fp16
    * value per element; 1 = fp16 hi + lo pairs (x = hi + lo, |x - hi - lo| <= 2^-22 |x|): the LayerNorm kernels store both
    * halves and those two GEMMs sweep the weight twice (hi.W + lo.W in the same fp32 accumulator; twice their work).  With
-   * classifier-free guidance this rounding point decides the token parity: see DESIGN.md, "Precision".  Not combined with
-   * weight_split. */
+   * classifier-free guidance this rounding point decides the token parity: see DESIGN.md, "Precision".  2 = additionally the
+   * attention output and the FFN hidden are hi + lo pairs (written by the attention kernel and the FFN-up epilogue), so all four
+   * trunk GEMMs of a layer do twice their work.  Not combined with weight_split. */
   int act_split;
 } mb_gen_cfg;
 

@@ -111,6 +111,7 @@ struct mb_gen {
   // workspace
   float *y_f32 = nullptr, *ln_stats = nullptr;       // fp32 residual stream (pre-LayerNorm rows) and {mean, rstd} per row
   h16 *x_h16 = nullptr, *x_lo = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;   // x_lo: lo halves of x_h16 (cfg.act_split)
+  h16 *att_lo = nullptr, *h_lo = nullptr;                                                // cfg.act_split == 2: lo halves of att and h
   // loop state for mb_sample
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
   uint8_t* drop_cfg = nullptr;
@@ -138,20 +139,24 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     return attn ? attention_probs(s, g->qkv, attn + (size_t)l * nb * N * N, nb, N, d, c.heads) : 0;
   };
   int attn_rc = 0;
+  h16* const xlo_trunk = c.act_split ? g->x_lo : nullptr;   // LayerNorms that feed trunk GEMMs write lo halves only when those GEMMs use them
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
   // K = 2d K-tiles, the first d columns pairing x_h16 with W, the second d columns x_lo with the same W
-  auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc) {
+  auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc, h16* out_lo = nullptr) {
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
-    if (g->x_lo) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
+    if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
+    ga.out_lo = out_lo;
     gemm_tn(s, epi, ga);
   };
+  // act_split == 2: the attention output and the FFN hidden also exist as hi + lo pairs, so the two residual GEMMs sweep their weight twice as well
+  auto split2 = [&](GemmArgs& ga, const h16* lo, int kw) { if (lo) { ga.K = 2 * kw; ga.ka = 0; ga.A2 = lo; ga.kw = kw; } };
   {
     ProfScope p("embed_ln", s, true);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
-    e.x_lo = g->x_lo;
+    e.x_lo = c.depth ? xlo_trunk : g->x_lo;
     embed_ln(s, e);
   }
   if (c.prenorm) {
@@ -159,26 +164,30 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
     for (int l = 0; l < c.depth; ++l) {
       const mb_gen::Layer& L = g->layers[l];
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk); }
       { ProfScope p("gemm_qkv", s, true);
         xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l)); }
-      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo); }
       attn_rc |= attn_maps(l);
       { ProfScope p("gemm_attn_out", s, true);
-        gemm_tn(s, EPI_RES_F32, GemmArgs{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)}); }
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
+        GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
+        split2(ga, g->att_lo, d);
+        gemm_tn(s, EPI_RES_F32, ga); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk); }
       { ProfScope p("gemm_ffn_up", s, true);
-        xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2)); }
+        xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo); }
       { ProfScope p("gemm_ffn_down", s, true);
-        gemm_tn(s, EPI_RES_F32, GemmArgs{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)}); }
+        GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
+        split2(ga, g->h_lo, f);
+        gemm_tn(s, EPI_RES_F32, ga); }
     }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }   // norm_after_transformer
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }   // norm_after_transformer
   } else {
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     { ProfScope p("gemm_qkv", s, true);
       xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l)); }
-    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads); }
+    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo); }
     attn_rc |= attn_maps(l);
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
     // GEMM operand and {mean, rstd}; the next residual GEMM re-derives the normalised rows in its epilogue and updates
@@ -186,22 +195,29 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     { ProfScope p("gemm_attn_out", s, true);
       GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
+      split2(ga, g->att_lo, d);
       gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk); }
     { ProfScope p("gemm_ffn_up", s, true);
-      xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2)); }
+      xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo); }
     { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
+      split2(ga, g->h_lo, f);
       gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk); }   // the last one feeds the head
   }
   }
   { ProfScope p("gemm_head", s, true);
-    gemm_tn(s, EPI_GELU_F32, GemmArgs{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)}); }
-  { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d); }
+    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)};
+    split2(ga, g->x_lo, d);   // the two head GEMMs always take their LayerNorm inputs as hi + lo pairs: their rounding lands on the logits
+                              // un-averaged and is amplified by the guidance scale, and the two GEMMs are 0.4 % of a forward (DESIGN.md "Precision")
+    gemm_tn(s, EPI_GELU_F32, ga); }
+  { ProfScope p("layernorm", s, true);
+    layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
   { ProfScope p("gemm_head", s, true);
     GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)};
+    split2(ga, g->x_lo, d);
     ga.bias_per_pos = c.embed_tables;
     gemm_tn(s, EPI_LOGITS_F32, ga); }
   hipError_t e = hipGetLastError();
@@ -306,7 +322,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if ((c.prenorm != 0 && c.prenorm != 1) || (c.embed_tables != 0 && c.embed_tables != 1)) return fail(-1, "prenorm / embed_tables must be 0 or 1");
   if (c.embed_tables && c.weight_split) return fail(-1, "weight_split is not supported with embed_tables (the tied head spans one table per group)");
   if (c.embed_tables && c.splits > 8) return fail(-1, "embed_tables supports up to 8 token groups");
-  if (c.act_split != 0 && c.act_split != 1) return fail(-1, "act_split must be 0 or 1");
+  if (c.act_split < 0 || c.act_split > 2) return fail(-1, "act_split must be 0, 1 or 2");
   if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
@@ -331,7 +347,8 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   rc |= galloc(g, &g->wl, ws * d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
   rc |= galloc(g, &g->wp, ws * c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
   rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->ln_stats, M * 2); rc |= galloc(g, &g->x_h16, M * d);
-  if (c.act_split) rc |= galloc(g, &g->x_lo, M * d);
+  if (!c.weight_split) rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, act_split >= 1 for the trunk
+  if (c.act_split == 2) { rc |= galloc(g, &g->att_lo, M * d); rc |= galloc(g, &g->h_lo, M * f); }
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
   rc |= galloc(g, &g->tok_a, B * P); rc |= galloc(g, &g->tok_b, B * P); rc |= galloc(g, &g->tok_cfg, B * P);

@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
       if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
         h16x4 o = {to_h(v0), to_h(v1), to_h(v2), to_h(v3)};
         *(h16x4*)(a.out_h16 + orow * a.N + n) = o;
+        if (a.out_lo)
+          *(h16x4*)(a.out_lo + orow * a.N + n) = h16x4{to_h(v0 - (float)o[0]), to_h(v1 - (float)o[1]), to_h(v2 - (float)o[2]), to_h(v3 - (float)o[3])};
       } else {
         *(float4*)(a.out_f32 + orow * a.N + n) = make_float4(v0, v1, v2, v3);
       }

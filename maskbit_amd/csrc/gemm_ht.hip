@@ -354,9 +354,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta0), __builtin_bit_cast(uint32_t, tb0), false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ta1), __builtin_bit_cast(uint32_t, tb1), false, false);
             // even g: 8 columns of n-tile 2pr starting at (g/2)*8;  odd g: the same 8 columns of n-tile 2pr+1
-            if (ok) {
-              const int n = col_of(r, 2 * pr + (ge & 1)) - (ge & 1) * 4;
-              *(uint4*)((char*)out16 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)n) * 2u)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            const int n = col_of(r, 2 * pr + (ge & 1)) - (ge & 1) * 4;
+            const size_t ob = (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)n) * 2u);
+            if (ok) *(uint4*)((char*)out16 + ob) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (a.out_lo) {                                // split activations for the consumer: the lo halves c - fp16(c), same layout
+              const h16x2 la0 = {to_h(ca[0] - (float)ta0[0]), to_h(ca[1] - (float)ta0[1])}, la1 = {to_h(ca[2] - (float)ta1[0]), to_h(ca[3] - (float)ta1[1])};
+              const h16x2 lb0 = {to_h(cb[0] - (float)tb0[0]), to_h(cb[1] - (float)tb0[1])}, lb1 = {to_h(cb[2] - (float)tb1[0]), to_h(cb[3] - (float)tb1[1])};
+              const auto l0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, la0), __builtin_bit_cast(uint32_t, lb0), false, false);
+              const auto l1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, la1), __builtin_bit_cast(uint32_t, lb1), false, false);
+              if (ok) *(uint4*)((char*)a.out_lo + ob) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
             }
           }
         } else if (ok) {

@@ -38,6 +38,9 @@ struct GemmArgs {
   // products land in the same fp32 accumulator.  A2 = null / kw = 0: plain GEMM.  Not combined with ka.
   const h16* A2 = nullptr;
   int kw = 0;
+  // fp16 epilogues only: also store the lo halves v - fp16(v) of the results ([M,N] like out_h16), so that the consumer GEMM can
+  // take this output as a split-activation pair
+  h16* out_lo = nullptr;
 };
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -68,7 +71,7 @@ void embed_ln(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
-void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads);
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo = nullptr);   // out_lo: optional lo halves (split activations)
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 

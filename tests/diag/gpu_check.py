@@ -149,7 +149,7 @@ def main():
         O.sample_loop(fwd, B, y, num_steps=N, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0,
                       randomize_temperature=8.2, mask_schedule_strategy="arccos", mask_token=64, codebook_splits=2, record=rec)
         print(f"  oracle loop {time.time() - t0:.1f}s on {torch.get_num_threads()} threads", flush=True)
-        modes = [(int(v), 0) for v in os.environ.get("TF_SPLITS", "0").split(",")] + [(0, 1)] * int(os.environ.get("TF_ACT", "0"))
+        modes = [(int(v), 0) for v in os.environ.get("TF_SPLITS", "0").split(",")] + [(0, int(v)) for v in os.environ.get("TF_ACT", "").split(",") if v and v != "0"]
         quiet = bool(int(os.environ.get("TF_QUIET", "0")))
         for split, act in modes:
             m.weight_split, m.act_split = split, act
