@@ -34,7 +34,7 @@ constexpr int ATT_MAXQT = (ATT_NKT + ATT_NW - 1) / ATT_NW;   // q-tiles per wave
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int DH>
-__global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo,
+__global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
                                                           int N, int d, int heads, float scale_log2e) {
   constexpr int ROW = DH * 2;            // bytes per K / V row
   constexpr int SL = DH / 8;             // 16-byte slots per row (8 or 4)
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         if (out_lo)                                             // split activations: the fp16 lo halves v - fp16(v)
           *(h16x4*)(out_lo + ooff + nt * 16 + g * 4) =
               h16x4{to_h(v[0] - (float)hi[0]), to_h(v[1] - (float)hi[1]), to_h(v[2] - (float)hi[2]), to_h(v[3] - (float)hi[3])};
+        if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4(v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 // (Milakov-Gimelshein / FlashAttention-style streaming softmax).  K/V blocks are double-buffered through LDS by LDS-DMA.
 constexpr int ATTL_KB = 128;             // keys per block
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo,
+__global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
                                                                int N, int d, int heads, int nchunk, float scale_log2e) {
   constexpr int ROW = DH * 2, SL = DH / 8, KS = DH / 32, NT = DH / 16, RPI = 64 / SL;
   constexpr int BLK_BYTES = ATTL_KB * ROW;                 // one operand block
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
       if (out_lo)
         *(h16x4*)(out_lo + ooff + nt * 16 + g * 4) =
             h16x4{to_h(v[0] - (float)hi[0]), to_h(v[1] - (float)hi[1]), to_h(v[2] - (float)hi[2]), to_h(v[3] - (float)hi[3])};
+      if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -417,19 +419,19 @@ int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, in
   return 0;
 }
 
-void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo) {
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo, uint8_t* out_lo8) {
   const int dh = d / heads;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   if (N > ATT_NP) {                                           // longer than one head's K/V fits in LDS: streaming kernel
     const int nchunk = (N + 63) / 64;
     dim3 grid(nb * heads * nchunk), block(256);
-    if (dh == 64) hipLaunchKernelGGL(attention_long_kernel<64>, grid, block, 0, s, qkv, out, out_lo, N, d, heads, nchunk, scale_log2e);
-    else hipLaunchKernelGGL(attention_long_kernel<32>, grid, block, 0, s, qkv, out, out_lo, N, d, heads, nchunk, scale_log2e);
+    if (dh == 64) hipLaunchKernelGGL(attention_long_kernel<64>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, nchunk, scale_log2e);
+    else hipLaunchKernelGGL(attention_long_kernel<32>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, nchunk, scale_log2e);
     return;
   }
   dim3 grid(nb * heads), block(64 * ATT_NW);
-  if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, out_lo, N, d, heads, scale_log2e);
-  else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, out_lo, N, d, heads, scale_log2e);
+  if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
+  else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
 }
 
 }  // namespace mb

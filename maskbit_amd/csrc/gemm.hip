@@ -12,6 +12,9 @@
 // on the per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment
 // read -- which makes every ds_read_b128 lane group hit 16 distinct slots.
 // Double-buffered: the DMA for K-tile t+1 is in flight while tile t is multiplied.
+#include <cstdio>
+#include <cstdlib>
+
 #include "mb_kernels.h"
 
 namespace mb {
@@ -137,12 +140,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
   // variant: 0 auto; -1 this 128x128 kernel; 6 / 8 the half-tile kernel with that MT; 257 its sequence-aligned tiles;
   // 16/26 (MT 6) and 18/28 (MT 8): DMA-only / compute-only ablations of the half-tile kernel (timing experiments)
-  if (variant == 4 && gemm_ht_supported(epi, a)) { gemm_w4(s, epi, a); return; }
+  if (variant == 4 && !a.A8 && gemm_ht_supported(epi, a)) { gemm_w4(s, epi, a); return; }
+  if (a.A8 && variant < 0) variant = 0;               // the e4m3 lo pass exists in the half-tile kernel only
   if (variant >= 0 && gemm_ht_supported(epi, a)) {
     if (variant % 1000 == 257 && a.M % 257) variant = variant - variant % 1000;
     gemm_ht(s, epi, a, variant);
     return;
   }
+  if (a.A8) { fprintf(stderr, "maskbit_hip: e4m3 lo pass requested for a GEMM shape the half-tile kernel does not take (M=%d N=%d K=%d)\n", a.M, a.N, a.K); abort(); }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles), block(256);
   switch (epi) {
@@ -169,6 +174,24 @@ void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n) {
   hipLaunchKernelGGL(cast_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
 }
 
+
+// ---- e4m3 copy of a weight for the fp8 correction pass: W8[n][2K bytes] (first K used) = e4m3(W * 2^e), e = 7 - floor(log2(absmax)) ----
+__global__ void w8_kernel(const float* __restrict__ W, uint8_t* __restrict__ out, int N, int K, const unsigned* __restrict__ absmax_bits, int* __restrict__ exp_out) {
+  const float amax = __uint_as_float(*absmax_bits);
+  int e = 0;
+  if (amax > 0.f) { int ex; (void)frexpf(amax, &ex); e = 8 - ex; }           // amax = m * 2^ex, m in [0.5, 1) -> amax * 2^e in [128, 256)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *exp_out = e;
+  const float sc = ldexpf(1.0f, e);
+  const size_t total = (size_t)N * (K / 4);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / (K / 4); const int c = (int)(i % (K / 4)) * 4;
+    const float4 v = *(const float4*)(W + n * K + c);
+    // the fp16 engine multiplies by fp16(W): quantise THAT value, so that hi.W16 + lo.W8 approximates (hi + lo).W16
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32((float)(h16)v.x * sc, (float)(h16)v.y * sc, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32((float)(h16)v.z * sc, (float)(h16)v.w * sc, w, true);
+    *(int*)(out + n * 2 * (size_t)K + c) = w;
+  }
+}
 
 // ---- split-weight repack ----------------------------------------------------------------------
 __global__ void absmax_kernel(const float* __restrict__ src, size_t n, unsigned* __restrict__ out) {
@@ -199,6 +222,14 @@ void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K,
   (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
   hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K, tmp, scale_out);
+}
+void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp) {
+  const size_t n = (size_t)N * K;
+  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+  (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
+  (void)hipMemsetAsync(dst8, 0, 2 * n, s);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
+  hipLaunchKernelGGL(w8_kernel, dim3(blocks), dim3(256), 0, s, src, dst8, N, K, tmp, exp_out);
 }
 
 }  // namespace mb

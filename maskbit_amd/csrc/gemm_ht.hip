@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
   // inside the K loop): those GEMMs run one tile per workgroup, everything else walks the tile list persistently.
-  constexpr bool PERSIST = EPI != EPI_RES_F32;
+  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4;   // (the e4m3 kernels, XP = 4, have no registers left for the next-tile state either)
   constexpr int AUX = 0;   // DMA cache policy: default beats nt (-14 %) and sc1 (-6 %) here, sc0 is equal (measured)
   constexpr int BM = 32 * MT, MH = MT / 2;
   constexpr int AH_ROWS = BM / 2;
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int K = a.K, nk = K / 64;
   const int KA = a.ka ? a.ka : (a.kw ? a.kw : K), nka = KA / 64;   // split weights: A has KA = K/2 columns and is swept twice
   const int KW = a.kw ? a.kw : K, nkw = KW / 64;       // split activations: W has K/2 columns and is swept twice, A2 (lo halves) takes over from A
-  const h16* const Alo = a.A2 ? a.A2 : a.A;
+  constexpr bool F8 = XP == 4;                         // e4m3 lo pass: K-tiles >= nka come from (A8, W8), 128 K-elements per tile
+  const h16* const Alo = F8 ? (const h16*)a.A8 : (a.A2 ? a.A2 : a.A);
+  const h16* const Wlo = F8 ? (const h16*)a.W8 : a.W;
   const int ntiles = tiles_m * tiles_n;
 
   // ---- per-tile DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
@@ -112,12 +114,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   auto dma_a = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + h * AH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX((t < nka ? a.A : Alo) + p.offA[h][j] + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
+    for (int j = 0; j < 2; ++j) {
+      // sequence-aligned tiles never clamp a row, so the four half-tile instructions of a wave differ by whole rows only:
+      // one per-lane offset + a uniform (h * 64 + j * 128) * KA (6 VGPRs less than a table; used where VGPRs are the limit: the e4m3 kernels)
+      uint32_t o = (SEQ && F8) ? p.offA[0][0] : p.offA[h][j];
+      if (F8) asm volatile("" : "+v"(o));               // keeps the 64-bit address arithmetic at the use (it was hoisted out of the two K loops and spilled)
+      const uint32_t u = (SEQ && F8) ? (uint32_t)(h * 64 + j * 128) * (uint32_t)KA : 0u;
+      MB_GLDS16_AUX((t < nka ? a.A : Alo) + u + o + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
+    }
   };
   auto dma_b = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) MB_GLDS16_AUX(a.W + p.offB[h][j] + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
+    for (int j = 0; j < 2; ++j) {
+      uint32_t o = (SEQ && F8) ? p.offB[0][0] : p.offB[h][j];
+      if (F8) asm volatile("" : "+v"(o));
+      const uint32_t u = (SEQ && F8) ? (uint32_t)(h * 32 + j * 128) * (uint32_t)KW : 0u;
+      MB_GLDS16_AUX((t < nkw ? a.W : Wlo) + u + o + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
+    }
   };
   // all of K-tiles 0 and 1 of a tile (both LDS parities must be free)
   // (nk >= 2 is a precondition of this kernel: gemm_ht_supported)
@@ -136,23 +150,51 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     // A-fragment addresses instead of the X buffer -- 16 lanes on the 8 X rows was a 2-way bank conflict on every read
     xoffe[ks] = l15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + (ks * 4 + g) * 16 : foff[ks];
   }
+  // e4m3 K-tile of 128: lane group g owns K bytes 32g .. 32g+31 of its row = slots 2g and 2g+1 (tools/micro/mfma_f8_probe.hip); the F8
+  // kernels recompute their fragment offsets per K-tile instead of holding a second set in registers
+  int sc_a = 127 - LO8_EXP, sc_b = 127;                // E8M0 scales of the e4m3 pass: products * 2^-(LO8_EXP + w8_exp)
+  if (F8) sc_b = 127 - *a.w8_exp;
+  // Both scales live in VGPRs of their own for the whole kernel (opaque here, used again after every K-tile): a rematerialised copy
+  // was allocated INSIDE the destination registers of the class-row v_mfma_scale (dst v[78:81], scales v79 / v78) and produced garbage.
+  if (F8) asm volatile("" : "+v"(sc_a), "+v"(sc_b));
   const int xbase = wm * (8 * MT) * 128;              // this wave's rows inside an A half-tile
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
 
 #define MB_LOAD_A(H)                                                                            \
   if (XP != 1) _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
-      xa[i][ks] = *(const h16x8*)(par + (H) * AH_BYTES + xbase + i * 16 * 128 + foff[ks]);
+      xa[i] = frag_set(xa[i], *(const h16x8*)(par + (H) * AH_BYTES + xbase + i * 16 * 128 + fo[ks]), ks);
 #define MB_LOAD_B(H)                                                                            \
   if (XP != 1) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
-      wb[H][i][ks] = *(const h16x8*)(par + wbase + (H) * BH_BYTES + i * 16 * 128 + foff[ks]);
+      wb[H][i] = frag_set(wb[H][i], *(const h16x8*)(par + wbase + (H) * BH_BYTES + i * 16 * 128 + fo[ks]), ks);
 #define MB_SYNC_L()                                     \
   __builtin_amdgcn_s_barrier();                         \
   __builtin_amdgcn_sched_barrier(0);                    \
   __builtin_amdgcn_s_setprio(1);
+  // one 16x16 output tile x one K-tile: two f16 MFMAs of K = 32, or (e4m3 K-tile) one scaled MFMA of K = 128 over the same 2 x 16 bytes per lane
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  // A fragment pair (two 16-byte LDS reads of one lane) lives in ONE 8-VGPR tuple: the e4m3 MFMA takes it whole, the f16 MFMAs its halves
+  typedef h16 h16x16 __attribute__((ext_vector_type(16)));
+  auto frag_set = [](h16x16 f, h16x8 v, int ks) -> h16x16 {
+    return ks == 0 ? __builtin_shufflevector(__builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7), f, 0, 1, 2, 3, 4, 5, 6, 7, 24, 25, 26, 27, 28, 29, 30, 31)
+                   : __builtin_shufflevector(f, __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23);
+  };
+  auto mma_tile = [&](f32x4 c, const h16x16& w, const h16x16& x, bool f8t) -> f32x4 {
+    if (F8 && f8t) return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8, w), __builtin_bit_cast(i32x8, x), c, 0, 0, 0, sc_b, 0, sc_a);
+    c = MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(x, x, 0, 1, 2, 3, 4, 5, 6, 7), c);
+    return MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 8, 9, 10, 11, 12, 13, 14, 15), __builtin_shufflevector(x, x, 8, 9, 10, 11, 12, 13, 14, 15), c);
+  };
 #define MB_MMA(AH, BH)                                                                              \
-  if (XP != 1) _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)       \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
-          acc[(BH) * 2 + n][(AH) * MH + i] = MB_MFMA_16x16x32(wb[BH][n][ks], xa[i][ks], acc[(BH) * 2 + n][(AH) * MH + i]); \
+  if (XP != 1) {                                                                                    \
+    if (F8 && f8t) {                                                                                \
+      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
+        acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], true);  \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
+        acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], false); \
+    }                                                                                               \
+  }                                                                                                 \
   __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();
@@ -171,55 +213,76 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acce[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // SEQ: class row x this wave row's 2 n-tiles
-    h16x8 xa[MH][2], wb[2][2][2];       // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
+    h16x16 xa[MH], wb[2][2];      // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
     if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
-    for (int t = 0; t < nk; ++t) {
-      const char* par = smem + (t & 1) * PAR_BYTES;
-      // DMA issue is placed where the read phase is short (a global_load_lds blocks the issuing wave until the address unit takes
-      // it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3
-      // (no reads).  Every half-tile is re-filled >= 2 phases after its last reader; K-tile 1 came with the prologue.
-      const bool n1 = XP != 2 && t >= 1 && t + 1 < nk, n2 = XP != 2 && t + 2 < nk;
-      // ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0]
-      MB_LOAD_B(0) MB_LOAD_A(0)                          // B first: the first MFMAs need both B fragments and only xa[0]
-      h16x8 xe[2];
-      if (SEQ && wm == 0) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
-      MB_SYNC_L()
-      if (SEQ && wm == 0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[0][n][ks], xe[ks], acce[n]);
-      }
-      MB_MMA(0, 0)
-      // ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1
-      MB_LOAD_B(1)
-      if (SEQ && wm == 1) { xe[0] = *(const h16x8*)(par + xoffe[0]); xe[1] = *(const h16x8*)(par + xoffe[1]); }
-      if (n1) dma_a(cur, t + 1, 1);
-      MB_SYNC_L()
-      if (SEQ && wm == 1) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) acce[n] = MB_MFMA_16x16x32(wb[1][n][ks], xe[ks], acce[n]);
-      }
-      MB_MMA(0, 1)
-      // ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2
-      MB_LOAD_A(1)
-      if (n2) dma_a(cur, t + 2, 0);
-      MB_SYNC_L() MB_MMA(1, 1)
-      // ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed.
-      // In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output
-      // stores stay in flight until the wait of K-tile 1.
-      if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); dma_b(cur, t + 2, 0); }
-      if (t >= 1 || XP == 2) {
-        if (n2) {                                        // A0, B1, (X,) B0 of K-tile t+2 may stay in flight
-          if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      MB_SYNC_L() MB_MMA(1, 0)
+#define MB_KTILE(F8T)                                                                                  \
+    {                                                                                                    \
+      const char* par = smem + (t & 1) * PAR_BYTES; \
+      constexpr bool f8t = F8 && (F8T);                 /* this K-tile holds e4m3 operands */ \
+      int fo[2], xo[2]; \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+        if (F8) { \
+          int lo_ = lane; \
+          asm volatile("" : "+v"(lo_));                  /* opaque: keeps this arithmetic inside the loop (VGPR budget) */ \
+          const int r15 = lo_ & 15, gg = lo_ >> 4, sl = f8t ? 2 * gg + ks : ks * 4 + gg; \
+          fo[ks] = r15 * 128 + ((sl ^ (r15 >> 1)) * 16); \
+          xo[ks] = r15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + sl * 16 : fo[ks]; \
+        } else { fo[ks] = foff[ks]; xo[ks] = xoffe[ks]; } \
+      } \
+      /* DMA issue is placed where the read phase is short (a global_load_lds blocks the issuing wave until the address unit takes */ \
+      /* it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3 */ \
+      /* (no reads).  Every half-tile is re-filled >= 2 phases after its last reader; K-tile 1 came with the prologue. */ \
+      const bool n1 = XP != 2 && t >= 1 && t + 1 < nk, n2 = XP != 2 && t + 2 < nk; \
+      /* ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0] */ \
+      MB_LOAD_B(0) MB_LOAD_A(0)                          /* B first: the first MFMAs need both B fragments and only xa[0] */ \
+      h16x16 xe; \
+      if (SEQ && wm == 0) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
+      MB_SYNC_L() \
+      if (SEQ && wm == 0) { \
+        if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, true); } \
+        else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, false); } \
+        /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
+        /* cover this pair here): pad before the register moves that end this block */ \
+        if (F8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
+      } \
+      MB_MMA(0, 0) \
+      /* ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1 */ \
+      MB_LOAD_B(1) \
+      if (SEQ && wm == 1) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
+      if (n1) dma_a(cur, t + 1, 1); \
+      MB_SYNC_L() \
+      if (SEQ && wm == 1) { \
+        if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, true); } \
+        else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, false); } \
+        /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
+        /* cover this pair here): pad before the register moves that end this block */ \
+        if (F8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
+      } \
+      MB_MMA(0, 1) \
+      /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
+      MB_LOAD_A(1) \
+      if (n2) dma_a(cur, t + 2, 0); \
+      MB_SYNC_L() MB_MMA(1, 1) \
+      /* ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed. */ \
+      /* In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output */ \
+      /* stores stay in flight until the wait of K-tile 1. */ \
+      if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); dma_b(cur, t + 2, 0); } \
+      if (t >= 1 || XP == 2) { \
+        if (n2) {                                        /* A0, B1, (X,) B0 of K-tile t+2 may stay in flight */ \
+          if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
+          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+      } \
+      MB_SYNC_L() MB_MMA(1, 0) \
+      if (F8) asm volatile("" :: "v"(sc_a), "v"(sc_b)); \
     }
+    {
+      int t = 0;
+      for (; t < (F8 ? nka : nk); ++t) MB_KTILE(false)
+      if (F8) for (; t < nk; ++t) MB_KTILE(true)
+    }
+#undef MB_KTILE
     if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the two groups
 
     const float* __restrict__ resp = a.residual;
@@ -243,6 +306,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     Plan nxt;
     if (has_next) { make_plan(nvb, nxt); dma_x(nxt, 0); dma_x(nxt, 1); }
     f32x4 bias4[4], bcls[2];           // bcls: class-token row (indexing bias4 by wave id would put the array in scratch)
+    if constexpr (F8) {
+      // The e4m3 kernels run at the 256-VGPR limit, where the allocator may move registers around: an asm load whose result it does
+      // not track could be copied while still in flight.  Plain loads here (the compiler waits for them; the overlap with the next
+      // tile's prologue DMA is given up in this mode).
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bias4[nt] = *(const f32x4*)(a.bias + col_of(0, nt));
+      if (SEQ) { bcls[0] = *(const f32x4*)(a.bias + col_of(MT, 0)); bcls[1] = *(const f32x4*)(a.bias + col_of(MT, 1)); }
+      else { bcls[0] = bias4[0]; bcls[1] = bias4[1]; }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]), "+v"(bcls[0]), "+v"(bcls[1]) :: "memory");
+      if (has_next) prologue_rest(nxt);
+    } else {
 #define MB_LDG16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) MB_LDG16(bias4[nt], a.bias + col_of(0, nt));
@@ -257,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       asm volatile("s_cmp_lg_u32 %[hn], 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n1:\n\ts_waitcnt vmcnt(16)"
                    : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]), "+v"(bcls[0]), "+v"(bcls[1])
                    : [hn] "s"(hn) : "memory", "scc");
+    }
     }
 
     // ---- epilogue: acc[nt][mt] holds out[m][n..n+3] (m = ..+l15, n = ..+g*4); wave rows: half h = mt / MH, tile i = mt % MH.
@@ -364,6 +439,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
               const auto l1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, la1), __builtin_bit_cast(uint32_t, lb1), false, false);
               if (ok) *(uint4*)((char*)a.out_lo + ob) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
             }
+            if (a.out_lo8) {                               // e4m3 lo halves: 4 columns per dword, the swap gives a lane its 8 columns (row stride 2N bytes)
+              const auto q = __builtin_amdgcn_permlane16_swap(lo8_pack4(ca[0], ca[1], ca[2], ca[3]), lo8_pack4(cb[0], cb[1], cb[2], cb[3]), false, false);
+              if (ok) *(uint2*)(a.out_lo8 + (size_t)((uint32_t)row_of(r) * (uint32_t)a.N * 2u + (uint32_t)n)) = make_uint2(q[0], q[1]);
+            }
           }
         } else if (ok) {
 #pragma unroll
@@ -406,12 +485,13 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
     configured = true;
   }
   const int tiles_m = SEQ ? a.M / 257 : (a.M + BM - 1) / BM, tiles_n = a.N / 256;
-  const int grid = (EPI != EPI_RES_F32 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
+  const int grid = (EPI != EPI_RES_F32 && XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
   hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
-  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && a.M >= 512 &&
+  if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
+  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8) &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
          (uint64_t)a.M * a.N * 4 < (1ull << 32);      // 32-bit element / byte offsets inside the kernel
 }
@@ -435,6 +515,16 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
       const long tiles = (long)(a.M / 257) * (a.N / 256);
       if ((double)((tiles + num_cu - 1) / num_cu) * 272 < cost(mt)) mt = 257;
     }
+  }
+  if (a.A8) {                                                              // e4m3 lo pass (XP = 4 instantiations)
+    const bool seq = a.M % 257 == 0 && mt != 8;
+    switch (epi) {
+      case EPI_H16: if (seq) launch_ht<8, EPI_H16, 4, true>(s, a, persistent); else launch_ht<8, EPI_H16, 4>(s, a, persistent); break;
+      case EPI_GELU_H16: if (seq) launch_ht<8, EPI_GELU_H16, 4, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 4>(s, a, persistent); break;
+      case EPI_RES_F32: if (seq) launch_ht<8, EPI_RES_F32, 4, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 4>(s, a, persistent); break;
+      default: break;
+    }
+    return;
   }
 #define MB_HT_CASE(E)                                                      \
   case E:                                                                  \

@@ -69,6 +69,15 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x}).x; }
 
+// e4m3 "lo halves" for the strict-parity mode's fp8 correction pass: e4m3((v - fp16(v)) * 2^15), four per dword (byte i = column i)
+__device__ __forceinline__ uint32_t lo8_pack4(float v0, float v1, float v2, float v3) {
+  const float s = 32768.0f;
+  const float l0 = (v0 - (float)(h16)v0) * s, l1 = (v1 - (float)(h16)v1) * s, l2 = (v2 - (float)(h16)v2) * s, l3 = (v3 - (float)(h16)v3) * s;
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(l2, l3, w, true);
+  return (uint32_t)w;
+}
+
 // LayerNorm affine of one element, written with explicit roundings: the LayerNorm kernel and the GEMM epilogue that
 // re-derives the normalised residual from (y, mean, rstd) must produce the same bits.
 __device__ __forceinline__ float ln_affine(float v, float mean, float rstd, float g, float b) {

@@ -12,6 +12,7 @@ enum GemmEpi {
   EPI_GELU_F32 = 3,     // f32 out  = gelu_erf(acc + bias)            (last_layer.0)
   EPI_LOGITS_F32 = 4,   // f32 out, rows with (m % period)==period-1 dropped, rest compacted (head)
 };
+constexpr int LO8_EXP = 15;   // lo halves are <= 2^-11 |x|: 2^15 puts them in e4m3's normal range for |x| up to 2^12
 struct GemmArgs {
   const h16* A;        // [M,K] row-major
   const h16* W;        // [N,K] row-major (torch Linear layout)
@@ -41,15 +42,26 @@ struct GemmArgs {
   // fp16 epilogues only: also store the lo halves v - fp16(v) of the results ([M,N] like out_h16), so that the consumer GEMM can
   // take this output as a split-activation pair
   h16* out_lo = nullptr;
+  // e4m3 "lo pass" of a split-activation GEMM (half-tile kernel only): A8 = e4m3(lo * 2^LO8_EXP) of the activations whose hi halves are A,
+  // W8 = e4m3(W * 2^(*w8_exp)); both with the SAME row stride in bytes as their fp16 siblings (2*kw, first kw bytes used).  K-tiles
+  // below kw/64 are fp16 (A, W), the following kw/128 K-tiles are e4m3 tiles of 128 (v_mfma_scale_f32_16x16x128_f8f6f4, the E8M0 scales
+  // undo the two power-of-two factors); K = kw + kw/2.  out_lo8: fp16 epilogues also store e4m3(lo * 2^LO8_EXP) of their results (row
+  // stride 2*N bytes).
+  const uint8_t* A8 = nullptr;
+  const uint8_t* W8 = nullptr;
+  const int* w8_exp = nullptr;
+  uint8_t* out_lo8 = nullptr;
 };
 void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
+// e4m3 copy of a weight (row stride 2K bytes, first K used) for the fp8 correction pass; *exp_out = the power of two it was scaled by
+void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp);
 void gemm_w4(hipStream_t s, GemmEpi epi, const GemmArgs& a);   // 4-wave 128x128-per-wave variant (gemm_w4.hip)
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr);   // x_lo: fp16(x - fp16(x)), optional
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr, uint8_t* x8 = nullptr);   // x8: e4m3(lo * 2^15), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
 
 // ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------
 struct EmbedArgs {
@@ -66,12 +78,13 @@ struct EmbedArgs {
   // Bert (modeling/bert.py:313-315): per-group embedding tables [m][2^gbits + 1][d] summed instead of the bit projection
   const float* tables = nullptr;
   h16* x_lo = nullptr;     // optional: lo halves of x_h16 (split-activation GEMMs)
+  uint8_t* x8 = nullptr;   // optional: e4m3 lo halves, row stride 2d bytes
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
-void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo = nullptr);   // out_lo: optional lo halves (split activations)
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo = nullptr, uint8_t* out_lo8 = nullptr);   // out_lo: optional lo halves (split activations)
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 

@@ -15,7 +15,7 @@ constexpr int MAXS = 32;  // scalar fallback path: d <= 64 * MAXS = 2048
 template <int NV>
 __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr) {
+                                          float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr, uint8_t* x8 = nullptr) {
   // xl (optional): the fp16 lo halves o - fp16(o) of the same row, for the split-activation GEMMs
   constexpr bool VEC = NV > 0;
   constexpr int nv = NV;
@@ -50,6 +50,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
       const h16x4 hi = {to_h(o.x), to_h(o.y), to_h(o.z), to_h(o.w)};
       if (xb) *(h16x4*)(xb + c) = hi;
       if (xl) *(h16x4*)(xl + c) = h16x4{to_h(o.x - (float)hi[0]), to_h(o.y - (float)hi[1]), to_h(o.z - (float)hi[2]), to_h(o.w - (float)hi[3])};
+      if (x8) *(uint32_t*)(x8 + c) = lo8_pack4(o.x, o.y, o.z, o.w);
     }
   } else {
     for (int q = 0; q < ns; ++q) {
@@ -67,7 +68,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* x_f32,
-                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo) {
+                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -82,15 +83,15 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   else     { for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; sc[q] = c < d ? yr[c] : 0.f; } }
   ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
                  x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr,
-                 x_lo ? x_lo + (size_t)row * d : nullptr);
+                 x_lo ? x_lo + (size_t)row * d : nullptr, x8 ? x8 + (size_t)row * 2 * d : nullptr);
 }
 
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo) {
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8) {
   dim3 grid((M + 3) / 4), block(256);
-  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo);
-  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo);
-  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo);
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8);
 }
 
 // One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
     }
   }
   ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d, nullptr,
-                 a.x_lo ? a.x_lo + (size_t)row * d : nullptr);
+                 a.x_lo ? a.x_lo + (size_t)row * d : nullptr, a.x8 ? a.x8 + (size_t)row * 2 * d : nullptr);
 }
 
 void embed_ln(hipStream_t s, const EmbedArgs& a) {

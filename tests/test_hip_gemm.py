@@ -232,3 +232,54 @@ def test_split_activation_gemm(variant, epi, M, N, K):
         assert err < 3e-5 and err < err_single / 8
     else:
         assert err < 2e-3 * max(1.0, float(ref.abs().max()))       # one fp16 rounding of the result
+
+
+@pytest.mark.parametrize("variant", [8, 257, 0])
+@pytest.mark.parametrize("epi,M,N,K", [(2, 1028, 512, 1024), (0, 771, 256, 128), (1, 1028, 1024, 256), (2, 257, 256, 384)])
+def test_f8_lo_pass_gemm(variant, epi, M, N, K):
+    """The e4m3 lo pass of a split-activation GEMM (mb_gen_cfg.act_split == 3): K-tiles of the fp16 pair (x_hi, W), then K/128 e4m3 K-tiles of
+    (e4m3(x_lo * 2^15), e4m3(W * 2^e)) on v_mfma_scale_f32_16x16x128_f8f6f4, whose E8M0 scales undo the two powers of two.  Checked
+    (a) against the exact value of what the kernel is asked to compute (decoded e4m3 operands, fp64) and (b) against the fp32 rows:
+    the result must be far closer to them than the hi halves alone."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    if variant == 257 and M % 257:
+        pytest.skip("sequence-aligned tiles need M % 257 == 0")
+    torch.manual_seed(epi * 13 + (variant & 7))
+    x32 = torch.randn(M, K, device=DEV) * 1.5
+    xh = x32.half()
+    lo = x32 - xh.float()
+    a8 = torch.zeros(M, 2 * K, device=DEV, dtype=torch.uint8)
+    a8[:, :K] = (lo * 2.0 ** 15).to(torch.float8_e4m3fn).view(torch.uint8)
+    W32 = torch.randn(N, K, device=DEV) * 0.05
+    W = W32.half()
+    e = 10                                                       # |W| < 0.25 -> |W * 2^10| < 256
+    w8 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8)
+    w8[:, :K] = (W.float() * 2.0 ** e).to(torch.float8_e4m3fn).view(torch.uint8)
+    wexp = torch.tensor([e], device=DEV, dtype=torch.int32)
+    bias = torch.randn(N, device=DEV) * 0.1
+    res = torch.randn(M, N, device=DEV) if epi == 2 else None
+    out32 = torch.full((M, N), float("nan"), device=DEV) if epi == 2 else None
+    out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16) if epi != 2 else None
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.mb_gemm_f8lo(epi, xh.data_ptr(), a8.data_ptr(), W.data_ptr(), w8.data_ptr(), wexp.data_ptr(), bias.data_ptr(),
+                                res.data_ptr() if res is not None else None, out32.data_ptr() if out32 is not None else None,
+                                out16.data_ptr() if out16 is not None else None, M, N, K, variant, st))
+    torch.cuda.synchronize()
+    lo_dec = a8[:, :K].view(torch.float8_e4m3fn).double() / 2.0 ** 15
+    w_dec = w8[:, :K].view(torch.float8_e4m3fn).double() / 2.0 ** e
+    asked = xh.double() @ W.double().t() + lo_dec @ w_dec.t() + bias.double()
+    true = x32.double() @ W.double().t() + bias.double()
+    if epi == 1:
+        asked, true = torch.nn.functional.gelu(asked), torch.nn.functional.gelu(true)
+    if res is not None:
+        asked, true = asked + res.double(), true + res.double()
+    got = (out32 if out32 is not None else out16).double()
+    assert torch.isfinite(got).all()
+    if epi == 2:
+        hi_only = (xh.double() @ W.double().t() + bias.double() + res.double())
+        e_asked, e_true, e_hi = (float((got - r).abs().max()) for r in (asked, true, hi_only))
+        print(f"max err vs the asked value {e_asked:.2e}, vs the fp32 rows {e_true:.2e}; hi halves alone are {float((hi_only - true).abs().max()):.2e} away")
+        assert e_asked < 3e-5 and e_true < float((hi_only - true).abs().max()) / 8
+    else:
+        assert float((got - asked).abs().max()) < 2e-3 * max(1.0, float(asked.abs().max()))

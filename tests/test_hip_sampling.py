@@ -60,8 +60,9 @@ def test_teacher_forced_token_parity_full_size():
     (masked) at that step.  Two engine modes against the same oracle run:
       * default (fp16 operands -- the 10-bit mantissa of the TF32 matmuls the reference's configs enable): ~1.2e-3 on this 8-step
         stress schedule (CFG scale up to 5.4 while 30% of the tokens are still masked); bound 3e-3;
-      * act_split = 2 (every GEMM activation as an fp16 hi+lo pair): must meet the north star's 1e-3 (measured 6.0e-4 over 84 284 tokens
-        of a 64-step run, tests/diag/gpu_check.py tf_full).
+      * act_split = 2 (every GEMM activation as an fp16 hi+lo pair) and act_split = 3 (the lo halves and a copy of the weights as e4m3, a
+        half-cost correction pass on the scaled fp8 MFMA): must meet the north star's 1e-3 (measured 6.0e-4 / 5.8e-4 over 84 284 tokens of
+        a 64-step run, tests/diag/gpu_check.py tf_full).
     The per-step logit error is bounded too."""
     from maskbit_amd import _lib
     lib = _lib.load()
@@ -76,7 +77,7 @@ def test_teacher_forced_token_parity_full_size():
                   guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2, mask_schedule_strategy="arccos",
                   mask_token=64, codebook_splits=2, record=rec)
     drop = torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(DEV)
-    for act_split, bound in ((0, 3e-3), (2, 1e-3)):
+    for act_split, bound in ((0, 3e-3), (2, 1e-3), (3, 1e-3)):
         m.act_split = act_split
         bad = tot = 0
         for r in rec:

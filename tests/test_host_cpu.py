@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     """include/maskbit_hip.h <-> libmaskbit_hip.so <-> ctypes signatures stay in sync."""
     from maskbit_amd import _lib
     header = open(os.path.join(ROOT, "include", "maskbit_hip.h")).read()
-    declared = set(re.findall(r"\b(mb_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mb_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()
     for name in declared:
