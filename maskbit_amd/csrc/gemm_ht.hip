@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, false); } \
         /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
         /* cover this pair here): pad before the register moves that end this block */ \
-        if (F8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
+        if (f8t) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
       } \
       MB_MMA(0, 0) \
       /* ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1 */ \
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, false); } \
         /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
         /* cover this pair here): pad before the register moves that end this block */ \
-        if (F8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
+        if (f8t) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
       } \
       MB_MMA(0, 1) \
       /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
