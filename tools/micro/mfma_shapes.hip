@@ -6,6 +6,7 @@
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 template <int SHAPE>
 __global__ __launch_bounds__(512, 2) void mfma_kernel(float* out, int iters, long long* clk) {
@@ -16,6 +17,9 @@ __global__ __launch_bounds__(512, 2) void mfma_kernel(float* out, int iters, lon
       s = s * 1664525u + 1013904223u; a[q][i] = (_Float16)(((int)(s >> 16) - 32768) * (1.0f / 65536.0f));
       s = s * 1664525u + 1013904223u; b[q][i] = (_Float16)(((int)(s >> 16) - 32768) * (1.0f / 65536.0f));
     }
+  i32x8 a8[2], b8[2];
+  for (int q = 0; q < 2; ++q)
+    for (int i = 0; i < 8; ++i) { s = s * 1664525u + 1013904223u; a8[q][i] = (int)(s & 0x77777777u); s = s * 1664525u + 1013904223u; b8[q][i] = (int)(s & 0x77777777u); }
   f32x4 acc4[16];
   f32x16 acc16[4];
   for (int i = 0; i < 16; ++i) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -25,6 +29,9 @@ __global__ __launch_bounds__(512, 2) void mfma_kernel(float* out, int iters, lon
     if (SHAPE == 16) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 1], b[(i >> 1) & 1], acc4[i], 0, 0, 0);
+    } else if (SHAPE == 128) {                          // e4m3 x e4m3, K = 128: 4x the flops of one 16x16x32 f16 MFMA
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc4[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc4[i], 0, 0, 0, 127, 0, 127);
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
@@ -47,10 +54,11 @@ int main() {
   long long* clk; hipMalloc(&clk, (size_t)ncu * 16);
   std::vector<long long> h(2 * ncu);
   for (int rep = 0; rep < 3; ++rep)
-    for (int shape : {16, 32}) {
+    for (int shape : {16, 32, 128}) {
       const int iters = 20000;                        // x 16 (or 8) MFMAs: 262144 flop-units per wave either way
       auto launch = [&](int n) {
         if (shape == 16) hipLaunchKernelGGL(mfma_kernel<16>, dim3(ncu), dim3(512), 0, 0, out, n, clk);
+        else if (shape == 128) hipLaunchKernelGGL(mfma_kernel<128>, dim3(ncu), dim3(512), 0, 0, out, n, clk);
         else hipLaunchKernelGGL(mfma_kernel<32>, dim3(ncu), dim3(512), 0, 0, out, n, clk);
       };
       launch(1000);
@@ -58,9 +66,9 @@ int main() {
       float ms; hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
       hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
       double mhz = 0; for (int i = 0; i < ncu; ++i) mhz += (double)h[2 * i] / ((double)h[2 * i + 1] / 100.0); mhz /= ncu;
-      const double flops = (double)ncu * 8 * iters * 16 * 2.0 * 16 * 16 * 32;
+      const double flops = (double)ncu * 8 * iters * 16 * 2.0 * 16 * 16 * (shape == 128 ? 128 : 32);
       printf("%s: %8.3f ms  %7.1f TFLOP/s  shader clock %6.0f MHz  (peak at that clock %.0f TFLOP/s)\n",
-             shape == 16 ? "v_mfma_f32_16x16x32_f16" : "v_mfma_f32_32x32x16_f16", ms, flops / ms / 1e9, mhz, ncu * 4 * 1024.0 * mhz * 1e6 / 1e12);
+             shape == 16 ? "v_mfma_f32_16x16x32_f16" : shape == 128 ? "v_mfma_scale_f32_16x16x128 e4m3" : "v_mfma_f32_32x32x16_f16", ms, flops / ms / 1e9, mhz, ncu * 4 * 1024.0 * mhz * 1e6 / 1e12);
     }
   return 0;
 }
