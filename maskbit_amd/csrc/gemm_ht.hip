@@ -67,6 +67,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int KA = a.ka ? a.ka : (a.kw ? a.kw : K), nka = KA / 64;   // split weights: A has KA = K/2 columns and is swept twice
   const int KW = a.kw ? a.kw : K, nkw = KW / 64;       // split activations: W has K/2 columns and is swept twice, A2 (lo halves) takes over from A
   constexpr bool F8 = XP == 4;                         // e4m3 lo pass: K-tiles >= nka come from (A8, W8), 128 K-elements per tile
+  // Sequence-aligned e4m3 kernels: the DMA of an e4m3 K-tile permutes the 16-byte chunks of a row on the way into LDS (position ks*4+g
+  // receives chunk 2g+ks, the 32 bytes lane group g feeds to the K = 128 MFMA), so the fragment reads are the fp16 ones -- reading
+  // chunks 2g+ks in place was a 2-way LDS bank conflict on every read (PMC: 10.2 M conflict cycles of 40.9 M active, fp16 tiles: 0)
+  constexpr bool PERM = F8 && SEQ;
   const h16* const Alo = F8 ? (const h16*)a.A8 : (a.A2 ? a.A2 : a.A);
   const h16* const Wlo = F8 ? (const h16*)a.W8 : a.W;
   const int ntiles = tiles_m * tiles_n;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // ---- per-tile DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
   struct Plan {
     uint32_t offA[2][2], offB[2][2], offX;   // element offsets into A / W
+    int d8;                                  // PERM: added to offA / offB for e4m3 K-tiles (permuted source chunk)
     int m0, n0;
   };
   int dstA[2], dstB[2];                       // byte offset of the instruction inside its half-tile buffer
@@ -107,9 +112,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
     // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
     p.offX = (uint32_t)min(p.m0 + 256, a.M - 1) * (uint32_t)KA + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
+    if (PERM) {
+      const int ra = wave * 8 + (lane_o >> 3);                           // row of instruction j = 0 inside its half-tile (A and B alike)
+      const int qa = (lane_o & 7) ^ ((ra >> 1) & 7);
+      p.d8 = (2 * (qa & 3) + (qa >> 2) - qa) * 8;
+    }
   };
   auto dma_x = [&](const Plan& p, int t) {
-    if (SEQ && wave == 7) MB_GLDS16_AUX((t < nka ? a.A : Alo) + p.offX + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
+    int dx = 0;
+    if (PERM && t >= nka) { int lo_ = lane; asm volatile("" : "+v"(lo_)); const int qx = (lo_ & 7) ^ (((lo_ >> 3) >> 1) & 7); dx = (2 * (qx & 3) + (qx >> 2) - qx) * 8; }
+    if (SEQ && wave == 7) MB_GLDS16_AUX((t < nka ? a.A : Alo) + (p.offX + dx) + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
   };
   auto dma_a = [&](const Plan& p, int t, int h) {
     char* buf = smem + (t & 1) * PAR_BYTES + h * AH_BYTES;
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     for (int j = 0; j < 2; ++j) {
       // sequence-aligned tiles never clamp a row, so the four half-tile instructions of a wave differ by whole rows only:
       // one per-lane offset + a uniform (h * 64 + j * 128) * KA (6 VGPRs less than a table; used where VGPRs are the limit: the e4m3 kernels)
-      uint32_t o = (SEQ && F8) ? p.offA[0][0] : p.offA[h][j];
+      uint32_t o = (SEQ && F8) ? p.offA[0][0] + (t < nka ? 0 : p.d8) : p.offA[h][j];
       if (F8) asm volatile("" : "+v"(o));               // keeps the 64-bit address arithmetic at the use (it was hoisted out of the two K loops and spilled)
       const uint32_t u = (SEQ && F8) ? (uint32_t)(h * 64 + j * 128) * (uint32_t)KA : 0u;
       MB_GLDS16_AUX((t < nka ? a.A : Alo) + u + o + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      uint32_t o = (SEQ && F8) ? p.offB[0][0] : p.offB[h][j];
+      uint32_t o = (SEQ && F8) ? p.offB[0][0] + (t < nkw ? 0 : p.d8) : p.offB[h][j];
       if (F8) asm volatile("" : "+v"(o));
       const uint32_t u = (SEQ && F8) ? (uint32_t)(h * 32 + j * 128) * (uint32_t)KW : 0u;
       MB_GLDS16_AUX((t < nkw ? a.W : Wlo) + u + o + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
@@ -143,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 
   // ---- fragment read offsets inside a half-tile (rows 128 B, slot swizzled with (row>>1)&7)
   int foff[2], xoffe[2];
+  const int xadd = l15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES : 0;   // F8 kernels: xoffe[ks] == foff[ks] + xadd (lane row 0's foff is its slot offset), one VGPR less
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     foff[ks] = l15 * 128 + (((ks * 4 + g) ^ (l15 >> 1)) * 16);
@@ -152,11 +165,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   }
   // e4m3 K-tile of 128: lane group g owns K bytes 32g .. 32g+31 of its row = slots 2g and 2g+1 (tools/micro/mfma_f8_probe.hip); the F8
   // kernels recompute their fragment offsets per K-tile instead of holding a second set in registers
-  int sc_a = 127 - LO8_EXP, sc_b = 127;                // E8M0 scales of the e4m3 pass: products * 2^-(LO8_EXP + w8_exp)
-  if (F8) sc_b = 127 - *a.w8_exp;
+  // E8M0 scales of the e4m3 pass (products * 2^-(LO8_EXP + w8_exp)), both in ONE VGPR: byte 0 = the weights' scale, byte 1 = the
+  // activations' (the instruction's op_sel picks the byte)
+  int sc_ab = ((127 - LO8_EXP) << 8) | 127;
+  if (F8) sc_ab = ((127 - LO8_EXP) << 8) | ((127 - *a.w8_exp) & 0xff);
   // Both scales live in VGPRs of their own for the whole kernel (opaque here, used again after every K-tile): a rematerialised copy
   // was allocated INSIDE the destination registers of the class-row v_mfma_scale (dst v[78:81], scales v79 / v78) and produced garbage.
-  if (F8) asm volatile("" : "+v"(sc_a), "+v"(sc_b));
+  if (F8) asm volatile("" : "+v"(sc_ab));
   const int xbase = wm * (8 * MT) * 128;              // this wave's rows inside an A half-tile
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
 
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
                    : __builtin_shufflevector(f, __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23);
   };
   auto mma_tile = [&](f32x4 c, const h16x16& w, const h16x16& x, bool f8t) -> f32x4 {
-    if (F8 && f8t) return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8, w), __builtin_bit_cast(i32x8, x), c, 0, 0, 0, sc_b, 0, sc_a);
+    if (F8 && f8t) return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8, w), __builtin_bit_cast(i32x8, x), c, 0, 0, 0, sc_ab, 1, sc_ab);
     c = MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(x, x, 0, 1, 2, 3, 4, 5, 6, 7), c);
     return MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 8, 9, 10, 11, 12, 13, 14, 15), __builtin_shufflevector(x, x, 8, 9, 10, 11, 12, 13, 14, 15), c);
   };
@@ -222,13 +237,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       constexpr bool f8t = F8 && (F8T);                 /* this K-tile holds e4m3 operands */ \
       int fo[2], xo[2]; \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
-        if (F8) { \
+        if (F8 && !PERM) { \
           int lo_ = lane; \
           asm volatile("" : "+v"(lo_));                  /* opaque: keeps this arithmetic inside the loop (VGPR budget) */ \
           const int r15 = lo_ & 15, gg = lo_ >> 4, sl = f8t ? 2 * gg + ks : ks * 4 + gg; \
           fo[ks] = r15 * 128 + ((sl ^ (r15 >> 1)) * 16); \
           xo[ks] = r15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + sl * 16 : fo[ks]; \
-        } else { fo[ks] = foff[ks]; xo[ks] = xoffe[ks]; } \
+        } else { fo[ks] = foff[ks]; xo[ks] = F8 ? foff[ks] + xadd : xoffe[ks]; } \
       } \
       /* DMA issue is placed where the read phase is short (a global_load_lds blocks the issuing wave until the address unit takes */ \
       /* it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3 */ \
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
       } \
       MB_SYNC_L() MB_MMA(1, 0) \
-      if (F8) asm volatile("" :: "v"(sc_a), "v"(sc_b)); \
+      if (F8) asm volatile("" :: "v"(sc_ab)); \
     }
     {
       int t = 0;
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int m0 = cur.m0, n0 = cur.n0;
     constexpr int NROWS = SEQ ? MT + 1 : MT;
     int l15e = l15, ge = g;                              // opaque copies (see make_plan): no per-row address tables
+    if (F8) { int lo_ = lane; asm volatile("" : "+v"(lo_)); l15e = lo_ & 15; ge = lo_ >> 4; }   // (recomputed: l15 / g need not live through the K loops)
     asm volatile("" : "+v"(l15e), "+v"(ge));             // carried in VGPRs through the main loop
     auto row_of = [&](int r) { return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256; };
     auto col_of = [&](int r, int nt) {

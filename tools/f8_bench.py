@@ -1,6 +1,6 @@
 """Timing of the three ways a trunk GEMM can treat its activation operand: fp16 only, fp16 hi+lo (2 K sweeps), fp16 hi + e4m3 lo (1.5 sweeps)."""
-import sys, time, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tools")
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maskbit_amd import _lib
 lib = _lib.load(); dev = "cuda"
 M = 128 * 257
