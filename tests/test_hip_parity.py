@@ -88,6 +88,12 @@ def test_generator_split_activations_full12_and_tiny():
     rep = m(args[0].repeat(9, 1, 1), args[1].repeat(9), args[2].repeat(9))                      # half-tile kernel (M >= 512)
     nb = args[0].shape[0]
     assert torch.equal(rep[:nb], rep[-nb:]) and rel_fro(rep[:nb], ref) < 0.98 * e0
+    for level in (2, 3):                                                                        # every trunk GEMM activation as a pair (fp16 / e4m3 lo halves)
+        m.act_split = level
+        e_l = rel_fro(m(*args), ref)
+        print(f"act_split = {level}: {e_l:.2e}")
+        assert e_l < e1 and torch.equal(m(args[0][1:2], args[1][1:2], args[2][1:2]), m(*args)[1:2])
+    m.act_split = 1
     m.weight_split = 1
     with pytest.raises(RuntimeError):
         m(*args)                                                                                # the two modes are not combined
@@ -98,6 +104,9 @@ def test_generator_split_activations_full12_and_tiny():
     t, y, d = torch.from_numpy(zt["tokens"]).to(DEV), torch.from_numpy(zt["labels"]).to(DEV), torch.from_numpy(zt["drop"]).to(DEV)
     rt = torch.from_numpy(zt["logits"])
     a0 = rel_fro(mt(t, y, d), rt)
+    mt.act_split = 3
+    with pytest.raises(RuntimeError):
+        mt(t, y, d)                                               # the e4m3 lo pass needs hidden and mlp to be multiples of 256: loud, no silent fallback
     mt.act_split = 1
     a1 = rel_fro(mt(t, y, d), rt)
     print(f"tiny: {a0:.2e} -> {a1:.2e}")
