@@ -52,7 +52,7 @@ typedef struct {
    * halves and those two GEMMs sweep the weight twice (hi.W + lo.W in the same fp32 accumulator; twice their work).  With
    * classifier-free guidance this rounding point decides the token parity: see DESIGN.md, "Precision".  2 = additionally the
    * attention output and the FFN hidden are hi + lo pairs (written by the attention kernel and the FFN-up epilogue), so all four
-   * trunk GEMMs of a layer do twice their work.  3 = as 2, but the lo halves are stored as e4m3(lo * 2^15) and multiplied with an e4m3
+   * trunk GEMMs of a layer do twice their work.  3 = as 2, but the lo halves are stored as e4m3(lo * 2^12) and multiplied with an e4m3
    * copy of the weights on v_mfma_scale_f32_16x16x128_f8f6f4 (whose E8M0 scales undo the powers of two): the correction pass costs half
    * a sweep; needs hidden and mlp to be multiples of 256.  Not combined with weight_split. */
   int act_split;
@@ -154,7 +154,7 @@ int mb_layernorm(const float* y, const float* gamma, const float* beta, float ep
                  int M, int d, mb_stream stream);
 /* A GEMM with split activations: out = (A_hi + A_lo) . W^T + bias through the engine's kernels (A_hi, A_lo fp16 [M, kw], W fp16
  * [N, kw]; x_lo as written by mb_layernorm).  Diagnostic / test entry for mb_gen_cfg.act_split. */
-/* The same with an e4m3 lo pass: A8 = e4m3(lo * 2^15) and W8 = e4m3(W * 2^(*w8_exp)), both with the row stride of their fp16 siblings
+/* The same with an e4m3 lo pass: A8 = e4m3(lo * 2^12) and W8 = e4m3(W * 2^(*w8_exp)), both with the row stride of their fp16 siblings
  * (2*kw bytes, first kw used); kw % 128 == 0.  Diagnostic / test entry for mb_gen_cfg.act_split == 3. */
 int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const void* W8, const int* w8_exp, const float* bias,
                  const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);

@@ -69,10 +69,11 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x}).x; }
 
-// e4m3 "lo halves" for the strict-parity mode's fp8 correction pass: e4m3((v - fp16(v)) * 2^15), four per dword (byte i = column i)
+// e4m3 "lo halves" for the strict-parity mode's fp8 correction pass: e4m3((v - fp16(v)) * 2^12) (LO8_EXP in mb_kernels.h; clamped to +-448), four per dword (byte i = column i)
 __device__ __forceinline__ uint32_t lo8_pack4(float v0, float v1, float v2, float v3) {
-  const float s = 32768.0f;
-  const float l0 = (v0 - (float)(h16)v0) * s, l1 = (v1 - (float)(h16)v1) * s, l2 = (v2 - (float)(h16)v2) * s, l3 = (v3 - (float)(h16)v3) * s;
+  const float s = 4096.0f;
+  auto lo = [&](float v) { return __builtin_amdgcn_fmed3f((v - (float)to_h(v)) * s, -448.0f, 448.0f); };
+  const float l0 = lo(v0), l1 = lo(v1), l2 = lo(v2), l3 = lo(v3);
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(l2, l3, w, true);
   return (uint32_t)w;

@@ -12,7 +12,9 @@ enum GemmEpi {
   EPI_GELU_F32 = 3,     // f32 out  = gelu_erf(acc + bias)            (last_layer.0)
   EPI_LOGITS_F32 = 4,   // f32 out, rows with (m % period)==period-1 dropped, rest compacted (head)
 };
-constexpr int LO8_EXP = 15;   // lo halves are <= 2^-11 |x|: 2^15 puts them in e4m3's normal range for |x| up to 2^12
+// lo halves are <= 2^-11 |x|: scaled by 2^12 they are <= 2 |x|, inside e4m3's range (448) for |x| <= 224 and still normal numbers down to
+// |x| ~ 2^-6; larger values are clamped (their correction is then partial), never NaN
+constexpr int LO8_EXP = 12;
 struct GemmArgs {
   const h16* A;        // [M,K] row-major
   const h16* W;        // [N,K] row-major (torch Linear layout)

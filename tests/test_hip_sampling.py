@@ -61,7 +61,7 @@ def test_teacher_forced_token_parity_full_size():
       * default (fp16 operands -- the 10-bit mantissa of the TF32 matmuls the reference's configs enable): ~1.2e-3 on this 8-step
         stress schedule (CFG scale up to 5.4 while 30% of the tokens are still masked); bound 3e-3;
       * act_split = 2 (every GEMM activation as an fp16 hi+lo pair) and act_split = 3 (the lo halves and a copy of the weights as e4m3, a
-        half-cost correction pass on the scaled fp8 MFMA): must meet the north star's 1e-3 (measured 6.0e-4 / 5.8e-4 over 84 284 tokens of
+        half-cost correction pass on the scaled fp8 MFMA): must meet the north star's 1e-3 (measured 6.0e-4 / 5.9e-4 over 84 284 tokens of
         a 64-step run, tests/diag/gpu_check.py tf_full).
     The per-step logit error is bounded too."""
     from maskbit_amd import _lib

@@ -12,7 +12,7 @@ def timeit(fn, n=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 for name, epi, N, K in (("qkv", 0, 3072, 1024), ("attn_out", 2, 1024, 1024), ("ffn_up", 1, 4096, 1024), ("ffn_down", 2, 1024, 4096)):
     A = torch.randn(M, K, device=dev).half(); Alo = (torch.randn(M, K, device=dev) * 1e-4).half()
-    A8 = torch.zeros(M, 2 * K, device=dev, dtype=torch.uint8); A8[:, :K] = (Alo.float() * 2.0 ** 15).to(torch.float8_e4m3fn).view(torch.uint8)
+    A8 = torch.zeros(M, 2 * K, device=dev, dtype=torch.uint8); A8[:, :K] = (Alo.float() * 2.0 ** 12).to(torch.float8_e4m3fn).view(torch.uint8)
     W = (torch.randn(N, K, device=dev) * 0.05).half()
     W8 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); W8[:, :K] = (W.float() * 2.0 ** 10).to(torch.float8_e4m3fn).view(torch.uint8)
     we = torch.tensor([10], device=dev, dtype=torch.int32)
