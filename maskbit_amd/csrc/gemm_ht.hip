@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
   // inside the K loop): those GEMMs run one tile per workgroup, everything else walks the tile list persistently.
-  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4;   // (the e4m3 kernels, XP = 4, have no registers left for the next-tile state either)
+  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
   constexpr int AUX = 0;   // DMA cache policy: default beats nt (-14 %) and sc1 (-6 %) here, sc0 is equal (measured)
   constexpr int BM = 32 * MT, MH = MT / 2;
   constexpr int AH_ROWS = BM / 2;
@@ -205,6 +205,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     if (F8 && f8t) {                                                                                \
       _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
         acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], true);  \
+      /* pin: left alone, the compiler sank all 32 scaled MFMAs of a K-tile below the phase barriers into one burst at the loop end */ \
+      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
+        asm volatile("" : "+v"(acc[(BH) * 2 + n][(AH) * MH + i]));                                  \
     } else {                                                                                        \
       _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
         acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], false); \
