@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         if (out_lo)                                             // split activations: the fp16 lo halves v - fp16(v)
           *(h16x4*)(out_lo + ooff + nt * 16 + g * 4) =
               h16x4{to_h(v[0] - (float)hi[0]), to_h(v[1] - (float)hi[1]), to_h(v[2] - (float)hi[2]), to_h(v[3] - (float)hi[3])};
-        if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4(v[0], v[1], v[2], v[3]);
+        if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4h(v[0], v[1], v[2], v[3], hi);
       }
     }
   }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
       if (out_lo)
         *(h16x4*)(out_lo + ooff + nt * 16 + g * 4) =
             h16x4{to_h(v[0] - (float)hi[0]), to_h(v[1] - (float)hi[1]), to_h(v[2] - (float)hi[2]), to_h(v[3] - (float)hi[3])};
-      if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4(v[0], v[1], v[2], v[3]);
+      if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4h(v[0], v[1], v[2], v[3], hi);
     }
   }
 }

@@ -50,7 +50,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
       const h16x4 hi = {to_h(o.x), to_h(o.y), to_h(o.z), to_h(o.w)};
       if (xb) *(h16x4*)(xb + c) = hi;
       if (xl) *(h16x4*)(xl + c) = h16x4{to_h(o.x - (float)hi[0]), to_h(o.y - (float)hi[1]), to_h(o.z - (float)hi[2]), to_h(o.w - (float)hi[3])};
-      if (x8) *(uint32_t*)(x8 + c) = lo8_pack4(o.x, o.y, o.z, o.w);
+      if (x8) *(uint32_t*)(x8 + c) = lo8_pack4h(o.x, o.y, o.z, o.w, hi);
     }
   } else {
     for (int q = 0; q < ns; ++q) {
