@@ -139,9 +139,9 @@ def main():
         cfg = O.GenCfg(bits=12, splits=2)
         sd = O.make_generator_weights(cfg, seed=100, head_gain=12.0)
         m = hip_generator(cfg, sd)
-        B, N = 4, int(os.environ.get("TF_STEPS", "8"))
+        B, N = int(os.environ.get("TF_B", "4")), int(os.environ.get("TF_STEPS", "8"))
         torch.set_num_threads(min(16, torch.get_num_threads()))
-        y = torch.tensor([1, 7, 282, 604])
+        y = torch.tensor([1, 7, 282, 604, 724, 179, 751, 404, 850, 13, 999, 500][:B])
         rec = []
         torch.manual_seed(4321)
         t0 = time.time()
