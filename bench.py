@@ -43,6 +43,7 @@ F_DEC = 185.97e9                        # per decoded image
 DEC_BYTES_IDEAL = 426e6                  # per decoded image: 213.06 M elements x 2 B
 HBM_PEAK_GBS = 8000.0
 PROF_EVERY = 8                           # HIP-event timing of every 8th forward of the timed region (16 of 128 per batch)
+GEN_SEED, HEAD_GAIN, TOK_SEED = 100, 12.0, 200   # maskbit_amd/synth.py: the same synthetic checkpoints the golden fixtures were made with
 
 
 class Cfg(dict):
@@ -54,29 +55,13 @@ def tok_config():
                channel_mult=[1, 1, 2, 2, 4], num_resolutions=5, num_res_blocks=2, sample_with_conv=True)
 
 
-def seeded_fill(model: torch.nn.Module, seed: int) -> None:
-    """Random-init weights of the real shapes, seeded; norm gains ~1, everything else N(0, small)."""
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if p.dim() == 1 and ("norm" in name or "first_layer.0" in name or "last_layer.2" in name) and name.endswith("weight"):
-                p.copy_(1.0 + 0.02 * torch.randn(p.shape, generator=g))
-            elif p.dim() == 4:
-                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
-                p.copy_(torch.randn(p.shape, generator=g) / fan_in ** 0.5)
-            else:
-                p.copy_(0.02 * torch.randn(p.shape, generator=g))
-        if hasattr(model, "prediction_layer"):
-            model.prediction_layer.weight.mul_(12.0)       # peaky head: mean max-prob ~0.85 (SURVEY 7 "hard parts")
-
-
 def cpu_baseline():
     """Time the CPU oracle on a bounded sample of the same workload:
     2 complete CFG steps at B=8 (16 sequences) after 1 warm-up step, and one decode of 8 images."""
-    from oracle import maskbit_oracle as O
+    from oracle import maskbit_oracle as O          # the ONLY use of oracle/ in this file: the thing timed here is the CPU baseline itself
     gcfg, tcfg = O.GenCfg(bits=12, splits=2), O.TokCfg(token_size=12)
-    gsd = O.make_generator_weights(gcfg, seed=100, head_gain=12.0)
-    tsd = O.make_tokenizer_weights(tcfg, seed=200)
+    gsd = O.make_generator_weights(gcfg, seed=GEN_SEED, head_gain=HEAD_GAIN)
+    tsd = O.make_tokenizer_weights(tcfg, seed=TOK_SEED)
     B = 8
     labels = (torch.arange(B) * 37) % 1000
     times = []
@@ -119,23 +104,58 @@ def cpu_baseline():
             "host_cpus": os.cpu_count()}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run on
+    127.0.0.1) and pass their output through; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def build_models(dev):
+    from maskbit_amd import ConvVQModel, LFQBert, synth
+    gen = LFQBert(**GEN)
+    tok = ConvVQModel(tok_config())
+    gen.load_state_dict(synth.make_generator_weights(synth.GenCfg(bits=12, splits=2), seed=GEN_SEED, head_gain=HEAD_GAIN), strict=True)
+    tok.load_state_dict(synth.make_tokenizer_weights(synth.TokCfg(token_size=12), seed=TOK_SEED), strict=False)   # decoder half only
+    return gen.eval().requires_grad_(False).to(dev), tok.eval().requires_grad_(False).to(dev)
+
+
+def measured_parity(gen):
+    """Teacher-forced token mismatch of the engine's CURRENT precision mode against the real reference's full-size 64-step run
+    (tests/golden/sample_full12_64.npz, made by oracle/make_golden.py full64 with these same weights): 84 284 sampled positions."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_replay as R
+    bad, tot, _, _ = R.teacher_forced(gen)
+    return {"token_mismatch": bad / tot, "mismatches": bad, "positions": tot,
+            "against": "the reference's own sample() run, CPU fp32 (tests/golden/sample_full12_64.npz), teacher-forced per step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU per step (default: the C3 batch, 64)")
+    ap.add_argument("--mode", choices=("strict", "fp16"), default="strict",
+                    help="precision mode of the TIMED region: strict (default; the product default, meets <= 1e-3 token mismatch) or single fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
-    ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurement of the strict-parity engine mode")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurements: parity replay and the other precision mode")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # MB_BENCH_FORCE_DEVICE / MB_BENCH_BACKEND exist only to exercise the N>1 code path on a 1-GPU box
     # (tests/test_hip_bench.py: two ranks share cuda:0 over gloo); the driver's runs use one GPU per rank over RCCL.
     dev_index = int(os.environ.get("MB_BENCH_FORCE_DEVICE", local_rank))
@@ -151,17 +171,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from maskbit_amd import ConvVQModel, LFQBert, _lib
+    from maskbit_amd import _lib
     from maskbit_amd.parallel import gather_images
     from maskbit_amd.sampling import build_plan, draw_noise, run_loop
 
     B = args.batch
-    gen = LFQBert(**GEN)
-    tok = ConvVQModel(tok_config())
-    seeded_fill(gen, 100)
-    seeded_fill(tok, 200)
-    gen = gen.eval().requires_grad_(False).to(dev)
-    tok = tok.eval().requires_grad_(False).to(dev)
+    gen, tok = build_models(dev)
+    MODES = {"strict": -1, "fp16": 0}                   # LFQBert.act_split (-1: hi + lo activation pairs, the product default)
+    gen.weight_split, gen.act_split = 0, MODES[args.mode]
     torch.manual_seed(1234 + rank)
     plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
                       SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])
@@ -197,16 +214,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
-    # Outside the timed region, N = 1 only: the same workload in the strict-parity engine mode (act_split = 3: every GEMM activation as
-    # an fp16 hi + e4m3 lo pair, the mode that meets the north star's <= 1e-3 token mismatch; profiles/r01_parity_modes.md), one batch.
-    strict = None
+    # Outside the timed region, N = 1 only: (1) the MEASURED token mismatch of the timed mode against the reference's own full-size run,
+    # (2) the same workload and the same parity measurement in the other precision mode, one batch.
+    modes = None
     if world == 1 and not args.no_modes:
-        gen.act_split = 3
+        other = "fp16" if args.mode == "strict" else "strict"
+        modes = {args.mode: {"images_per_s": B * world * args.steps / elapsed, "timed": True, "parity": measured_parity(gen)}}
+        gen.act_split = MODES[other]
         one_batch(10_000); torch.cuda.synchronize()
         ts = time.perf_counter()
         one_batch(10_001); torch.cuda.synchronize()
-        strict = B / (time.perf_counter() - ts)
-        gen.act_split = 0
+        modes[other] = {"images_per_s": B / (time.perf_counter() - ts), "timed": False, "parity": measured_parity(gen)}
+        gen.act_split = MODES[args.mode]
 
     if rank == 0:
         total_images = B * world * args.steps
@@ -223,20 +242,22 @@ def main():
             fam_flops = sum(gemm_flops[k] * prof[k][0] for k in gemm_flops if k in prof)
             fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
             traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.*), if present
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if B == B_PER_GPU:
-                    traffic = pmc[dom.replace("gemm_", "")]["hbm_bytes_corrected"]
-            except Exception:
-                pass
+            traffic_src = None
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    if B == B_PER_GPU and args.mode in pmc.get("_mode", "fp16"):
+                        traffic = pmc[dom.replace("gemm_", "")]["hbm_bytes_corrected"]
+                        traffic_src = name
+                        break
+                except Exception:
+                    pass
             roofline = {"bound": "mfma", "kernel": f"gemm_ht_kernel ({dom}: M={M}, N={4096 if dom == 'gemm_ffn_up' else (3072 if dom == 'gemm_qkv' else 1024)}, "
                                                    f"K={4096 if dom == 'gemm_ffn_down' else 1024})",
                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                        "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_traffic.md)",
+                        "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src})",
                         "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
                         "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
-                        "peak_sustained_measured": {"mfma_tflops": 2090.0, "hbm_read_gbs": 6100.0, "hbm_copy_gbs": 5000.0,
-                                                    "source": "profiles/r01_peaks.md (tools/micro/peaks.hip; shader clock 2.0 GHz under MFMA load)"},
                         "end_to_end_frac": value / world * (2 * NUM_STEPS * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
             # the two other rooflines the north star names: attention core on MFMA, decoder on HBM
             if "attention" in prof:
@@ -262,9 +283,10 @@ def main():
                                    f"batch {B}/GPU, conv_vqgan decode to 256x256 uint8" + (", RCCL all-gather of images" if world > 1 else ""),
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, one process per GPU)"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
-            "precision_modes": {"source": "profiles/r01_parity_modes.md (teacher-forced against the fp32 oracle, 64 CFG steps, 84 284 sampled tokens)",
-                                "default_fp16": {"images_per_s": value, "token_mismatch": 1.57e-3},
-                                "act_split_3": {"images_per_s": strict, "token_mismatch": 5.93e-4}},
+            "precision": {"timed_mode": args.mode,
+                          "strict": "fp16 MFMA over hi + lo activation pairs (lo pass in 8 / 4 bits), fp32 accumulate: the product default",
+                          "fp16": "single fp16 operands, fp32 accumulate (LFQBert.act_split = 0)"},
+            "precision_modes": modes,
             "kernels_note": f"HIP events on the launch stream inside the timed region; generator kernels sampled on every {PROF_EVERY}th forward",
         }
         print(json.dumps(line), flush=True)

@@ -90,7 +90,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out);
 void mb_gen_destroy(mb_gen* g);
 /* One call per checkpoint entry (key names of SURVEY.md 8b / BaseModel.load_pretrained,
  * modeling/modules/base_model.py:87-141).  `data` is a device fp32 tensor in the checkpoint's
- * own layout; GEMM weights are repacked to bf16 here.  Unknown names return -2. */
+ * own layout; GEMM weights are repacked to fp16 here (plus the 8- / 4-bit lo-pass copies of the strict mode).  Unknown names return -2. */
 int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream);
 /* tokens int64 [nb,seq,m] (value C = masked), labels int64 [nb], drop uint8 [nb] (1 => label
  * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */

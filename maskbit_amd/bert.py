@@ -3,7 +3,7 @@
 Call surface of the reference's ``modeling.bert.LFQBert`` (bert.py:344-508): same constructor
 keywords, same checkpoint keys, ``model(img_tokens, class_labels, drop_label_mask)
 -> logits [b, seq, m, C]`` float32.  The forward itself is ``mb_gen_forward`` in
-libmaskbit_hip.so: fused bit-token embed + LayerNorm, 24 x (bf16 MFMA QKV GEMM, LDS-resident
+libmaskbit_hip.so: fused bit-token embed + LayerNorm, 24 x (fp16 MFMA QKV GEMM, LDS-resident
 attention, out-proj GEMM + residual, LayerNorm, FFN GEMMs with fused erf-GELU / residual), head.
 Both the post-norm (every shipped config) and the pre-norm variant run on the engine; ``Bert`` is the
 embedding-table sibling of ``LFQBert``.
@@ -21,7 +21,15 @@ from . import _lib
 from .base_model import BaseModel, ParamSpec
 
 DEFAULT_WEIGHT_SPLIT = 0
-DEFAULT_ACT_SPLIT = 0
+# -1 = "strict": the cheapest activation precision that meets the <= 1e-3 token mismatch against the fp32 reference
+# (act_split 3 where the lo-pass kernels take the shape, i.e. hidden and mlp multiples of 256; act_split 2 otherwise).
+DEFAULT_ACT_SPLIT = -1
+
+
+def resolve_act_split(act_split: int, hidden: int, mlp: int) -> int:
+    if act_split >= 0:
+        return act_split
+    return 3 if hidden % 256 == 0 and mlp % 256 == 0 else 2
 
 
 def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int, prenorm: bool = False,
@@ -77,11 +85,11 @@ class LFQBert(BaseModel):
         # GEMM weight precision of the device engine (not a reference argument): 0 = fp16, 1 = fp16 hi+lo pairs ("fp16x2",
         # twice the GEMM work, weight rounding 2^-22).  Default from MASKBIT_AMD_WEIGHT_SPLIT; may be changed before a call.
         self.weight_split = int(os.environ.get("MASKBIT_AMD_WEIGHT_SPLIT", str(DEFAULT_WEIGHT_SPLIT)))
-        # Activation precision of the trunk GEMMs: 0 = fp16; 1 = fp16 hi+lo pairs for the LayerNorm outputs (QKV and FFN-up GEMMs do twice the
-        # work); 2 = also for the attention output and the FFN hidden (all four trunk GEMMs do twice the work); 3 = as 2 with the lo halves
-        # and a weight copy in e4m3 (the correction pass costs half a sweep).  2 and 3 meet the <= 1e-3 token mismatch against the fp32
-        # reference (DESIGN.md "Precision").  Default from MASKBIT_AMD_ACT_SPLIT; may be changed
-        # before a call (the engine is rebuilt).
+        # Activation precision of the trunk GEMMs: 0 = single fp16 (fastest; 1.4-1.6e-3 token mismatch, the operating point of the reference's
+        # own TF32 GPU runs); 1 = fp16 hi+lo pairs for the LayerNorm outputs; 2 = also for the attention output and the FFN hidden (all four
+        # trunk GEMMs do twice the work); 3 = as 2 with the lo halves and a weight copy in 8 / 4 bits (the correction pass costs a fraction
+        # of a sweep).  2 and 3 meet the <= 1e-3 token mismatch against the fp32 reference (DESIGN.md "Precision").  -1 (DEFAULT) = 3 where
+        # the shape allows, else 2.  Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
         self.act_split = int(os.environ.get("MASKBIT_AMD_ACT_SPLIT", str(DEFAULT_ACT_SPLIT)))
         self._engine_split = None
         if not self.embed_tables:
@@ -95,8 +103,11 @@ class LFQBert(BaseModel):
 
     # ---- engine hooks ---------------------------------------------------------------------
     def _engine_create(self, capacity: int):
+        act = resolve_act_split(int(self.act_split), self.hidden_dim, self.mlp_dim)
+        if self.weight_split and int(self.act_split) < 0:
+            act = 0                                                # fp16x2 weights (opt-in experiment) are not combined with act_split
         cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass,
-                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables), int(self.act_split))
+                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables), act)
         self._engine_split = (int(self.weight_split), int(self.act_split))
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")

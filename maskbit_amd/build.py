@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmaskbit_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "gemm_ht.hip", "gemm_w4.hip", "norm_embed.hip", "attention.hip", "sampling.hip", "decoder.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "gemm_ht.hip", "norm_embed.hip", "attention.hip", "sampling.hip", "decoder.hip"]
 
 
 def hipcc() -> str:

@@ -2,6 +2,7 @@
 // repack, the generator forward schedule, the fused sampling step and the whole sampling loop.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -91,7 +92,7 @@ int dev_alloc(T** p, size_t n) {
 // ================================================================================================
 struct mb_gen {
   mb_gen_cfg c{};
-  int max_seqs = 0, N = 0, C = 0, gbits = 0, device = 0;
+  int max_seqs = 0, chunk_seqs = 0, N = 0, C = 0, gbits = 0, device = 0;   // chunk_seqs: sequences per forward pass (workspace size)
   struct Layer {
     h16 *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
@@ -142,7 +143,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   auto attn_maps = [&](int l) {
     return attn ? attention_probs(s, g->qkv, attn + (size_t)l * nb * N * N, nb, N, d, c.heads) : 0;
   };
-  int attn_rc = 0;
+  int attn_rc = 0, gemm_rc = 0;
   h16* const xlo_trunk = (c.act_split == 1 || c.act_split == 2) ? g->x_lo : nullptr;   // LayerNorms that feed trunk GEMMs write lo halves only when those GEMMs use them
   const bool f8 = c.act_split == 3;                       // e4m3 lo halves + e4m3 weight copies: the lo pass costs half a sweep
   g_prof.next_forward();
@@ -155,7 +156,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
     else if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
     ga.out_lo = out_lo;
-    gemm_tn(s, epi, ga);
+    gemm_rc |= gemm_tn(s, epi, ga);
   };
   // act_split == 2: the attention output and the FFN hidden also exist as hi + lo pairs, so the two residual GEMMs sweep their weight twice as well
   auto split2 = [&](GemmArgs& ga, const h16* lo, int kw) { if (lo) { ga.K = 2 * kw; ga.ka = 0; ga.A2 = lo; ga.kw = kw; } };
@@ -183,14 +184,14 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       { ProfScope p("gemm_attn_out", s, true);
         GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
         split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
-        gemm_tn(s, EPI_RES_F32, ga); }
+        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
       { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, g->x8); }
       { ProfScope p("gemm_ffn_up", s, true);
         xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8); }
       { ProfScope p("gemm_ffn_down", s, true);
         GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
         split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
-        gemm_tn(s, EPI_RES_F32, ga); }
+        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
     }
     { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }   // norm_after_transformer
   } else {
@@ -207,7 +208,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
-      gemm_tn(s, EPI_RES_F32, ga); }
+      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
     { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, g->x8); }
     { ProfScope p("gemm_ffn_up", s, true);
       xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8); }
@@ -215,7 +216,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
-      gemm_tn(s, EPI_RES_F32, ga); }
+      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
     { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, g->x8); }   // the last one feeds the head
   }
   }
@@ -223,17 +224,35 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)};
     split2(ga, g->x_lo, d);   // the two head GEMMs always take their LayerNorm inputs as hi + lo pairs: their rounding lands on the logits
                               // un-averaged and is amplified by the guidance scale, and the two GEMMs are 0.4 % of a forward (DESIGN.md "Precision")
-    gemm_tn(s, EPI_GELU_F32, ga); }
+    gemm_rc |= gemm_tn(s, EPI_GELU_F32, ga); }
   { ProfScope p("layernorm", s, true);
     layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
   { ProfScope p("gemm_head", s, true);
     GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)};
     split2(ga, g->x_lo, d);
     ga.bias_per_pos = c.embed_tables;
-    gemm_tn(s, EPI_LOGITS_F32, ga); }
+    gemm_rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   if (attn_rc) return fail(-3, "attention maps: head dim %d / %d tokens not supported", d / c.heads, N);
+  if (gemm_rc) return fail(-3, "act_split = %d: a trunk GEMM of this forward (%d sequences x %d tokens, hidden %d, mlp %d) is outside the "
+                               "half-tile kernel's shapes", c.act_split, nb, N, d, f);
+  return 0;
+}
+
+// The kernels index with 32-bit element / byte offsets (rows * mlp * 4 < 2^32): forwards over more sequences than that allows run as
+// independent chunks (sequences never interact), which also bounds the workspace of very large batches.
+int gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, int nb, hipStream_t s,
+                float* attn = nullptr) {
+  const int chunk = g->chunk_seqs;
+  if (nb <= chunk) return gen_forward_impl(g, tokens, labels, drop, logits, nb, s, attn);
+  if (attn) return fail(-3, "attention maps are limited to %d sequences per call", chunk);
+  const size_t P = (size_t)g->c.seq * g->c.splits;
+  for (int b0 = 0; b0 < nb; b0 += chunk) {
+    const int nc = nb - b0 < chunk ? nb - b0 : chunk;
+    int rc = gen_forward_impl(g, tokens + (size_t)b0 * P, labels + b0, drop ? drop + b0 : nullptr, logits + (size_t)b0 * P * g->C, nc, s);
+    if (rc) return rc;
+  }
   return 0;
 }
 
@@ -278,7 +297,7 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
   if (ln_stats && (!ln_g || !ln_b || epi != mb::EPI_RES_F32)) return fail(-1, "mb_gemm_ex: LayerNorm residual needs gamma, beta and the fp32+residual epilogue");
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period, ka, scale, ln_stats, ln_g, ln_b};
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -289,7 +308,7 @@ int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W
   mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, 2 * kw, 0, 0, nullptr};
   a.A2 = (const h16*)A_lo; a.kw = kw;
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -301,7 +320,7 @@ int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const
   a.kw = kw; a.A8 = (const uint8_t*)A8; a.W8 = (const uint8_t*)W8; a.w8_exp = w8_exp;
   if (!mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_f8lo: shape not supported by the half-tile kernel");
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -322,7 +341,7 @@ int mb_gemm(int epi, const void* A, const void* W, const float* bias, const floa
   if (K % 64) return fail(-1, "mb_gemm: K must be a multiple of 64");
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period};
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -351,7 +370,11 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
-  const size_t d = c.hidden, f = c.mlp, M = (size_t)max_seqs * g->N;
+  // rows per forward pass: 32-bit byte offsets inside the kernels need rows * max(mlp, 3 * hidden) * 4 < 2^32 (gemm_ht_supported)
+  const size_t widest = (size_t)(c.mlp > 3 * c.hidden ? c.mlp : 3 * c.hidden);
+  const size_t max_rows = ((1ull << 32) - 1) / (4 * widest);
+  g->chunk_seqs = (int)std::min<size_t>((size_t)max_seqs, std::max<size_t>(1, max_rows / g->N));
+  const size_t d = c.hidden, f = c.mlp, M = (size_t)g->chunk_seqs * g->N;
   int rc = 0;
   g->layers.resize(c.depth);
   const size_t ws = g->split ? 2 : 1;                  // fp16 values per weight
@@ -482,14 +505,14 @@ int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, cons
                    int nb, mb_stream stream) {
   if (!g || !tokens || !labels || !logits) return fail(-1, "mb_gen_forward: null argument");
   if (nb <= 0 || nb > g->max_seqs) return fail(-1, "mb_gen_forward: nb=%d outside [1, %d]", nb, g->max_seqs);
-  return gen_forward_impl(g, tokens, labels, drop, logits, nb, (hipStream_t)stream);
+  return gen_forward(g, tokens, labels, drop, logits, nb, (hipStream_t)stream);
 }
 
 int mb_gen_forward_attn(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, float* attn,
                         int nb, mb_stream stream) {
   if (!g || !tokens || !labels || !logits || !attn) return fail(-1, "mb_gen_forward_attn: null argument");
   if (nb <= 0 || nb > g->max_seqs) return fail(-1, "mb_gen_forward_attn: nb=%d outside [1, %d]", nb, g->max_seqs);
-  return gen_forward_impl(g, tokens, labels, drop, logits, nb, (hipStream_t)stream, attn);
+  return gen_forward(g, tokens, labels, drop, logits, nb, (hipStream_t)stream, attn);
 }
 
 int mb_sample_step(const float* logits_c, const float* logits_u, float scale, float temperature,
@@ -584,10 +607,10 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
     if (plan->use_guidance) {
       HIP_TRY(hipMemcpyAsync(g->tok_cfg, cur, B * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
       HIP_TRY(hipMemcpyAsync(g->tok_cfg + B * P, cur, B * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-      rc = gen_forward_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, g->logits, 2 * B, s);
+      rc = gen_forward(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, g->logits, 2 * B, s);
       lu = g->logits + (size_t)B * P * C;
     } else {
-      rc = gen_forward_impl(g, cur, labels, nullptr, g->logits, B, s);
+      rc = gen_forward(g, cur, labels, nullptr, g->logits, B, s);
     }
     if (rc) return rc;
     int64_t* pred = step_tokens ? step_tokens + (size_t)i * B * P : g->pred;

@@ -137,17 +137,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   }
 }
 
-void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
-  // variant: 0 auto; -1 this 128x128 kernel; 6 / 8 the half-tile kernel with that MT; 257 its sequence-aligned tiles;
-  // 16/26 (MT 6) and 18/28 (MT 8): DMA-only / compute-only ablations of the half-tile kernel (timing experiments)
-  if (variant == 4 && !a.A8 && gemm_ht_supported(epi, a)) { gemm_w4(s, epi, a); return; }
-  if (a.A8 && variant < 0) variant = 0;               // the e4m3 lo pass exists in the half-tile kernel only
+int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
+  // variant: 0 auto; -1 this 128x128 kernel; 6 / 8 the half-tile kernel with that MT; 257 its sequence-aligned tiles.
+  // Returns 0, or -1 when the request needs the half-tile kernel (8-bit / 4-bit lo pass) and the shape is outside it
+  // (the caller reports it; nothing is launched).
+  if (a.A8 && variant < 0) variant = 0;               // the lo pass exists in the half-tile kernel only
   if (variant >= 0 && gemm_ht_supported(epi, a)) {
     if (variant % 1000 == 257 && a.M % 257) variant = variant - variant % 1000;
     gemm_ht(s, epi, a, variant);
-    return;
+    return 0;
   }
-  if (a.A8) { fprintf(stderr, "maskbit_hip: e4m3 lo pass requested for a GEMM shape the half-tile kernel does not take (M=%d N=%d K=%d)\n", a.M, a.N, a.K); abort(); }
+  if (a.A8) return -1;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles), block(256);
   switch (epi) {
@@ -157,6 +157,7 @@ void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
     case EPI_GELU_F32: hipLaunchKernelGGL(gemm_tn_kernel<EPI_GELU_F32>, grid, block, 0, s, a); break;
     case EPI_LOGITS_F32: hipLaunchKernelGGL(gemm_tn_kernel<EPI_LOGITS_F32>, grid, block, 0, s, a); break;
   }
+  return 0;
 }
 
 __global__ void cast_kernel(const float* __restrict__ src, h16* __restrict__ dst, size_t n) {

@@ -42,7 +42,7 @@ namespace mb {
 // 4 n-tiles are split between the two wave rows (wm = 0 takes the B0 half in phase 0, wm = 1 the B1 half in phase 1:
 // +4 MFMAs per wave per K-tile).  The extra row lives in a 1 KiB "X" buffer per parity, re-filled by one extra DMA
 // instruction of wave 7 in phase 3.  tiles = nb * N/256: whole CU rounds for nb = 128.
-template <int MT, int EPI, int XP = 0, bool SEQ = false>   // XP (experiments): 1 = DMA only, 2 = no DMA in the main loop
+template <int MT, int EPI, int XP = 0, bool SEQ = false>   // XP: 0 = fp16 K-tiles only, 4 = fp16 K-tiles followed by an e4m3 lo pass
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
 
 #define MB_LOAD_A(H)                                                                            \
-  if (XP != 1) _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+  _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
       xa[i] = frag_set(xa[i], *(const h16x8*)(par + (H) * AH_BYTES + xbase + i * 16 * 128 + fo[ks]), ks);
 #define MB_LOAD_B(H)                                                                            \
-  if (XP != 1) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
       wb[H][i] = frag_set(wb[H][i], *(const h16x8*)(par + wbase + (H) * BH_BYTES + i * 16 * 128 + fo[ks]), ks);
 #define MB_SYNC_L()                                     \
   __builtin_amdgcn_s_barrier();                         \
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     return MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 8, 9, 10, 11, 12, 13, 14, 15), __builtin_shufflevector(x, x, 8, 9, 10, 11, 12, 13, 14, 15), c);
   };
 #define MB_MMA(AH, BH)                                                                              \
-  if (XP != 1) {                                                                                    \
+  {                                                                                                 \
     if (F8 && f8t) {                                                                                \
       _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
         acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], true);  \
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* DMA issue is placed where the read phase is short (a global_load_lds blocks the issuing wave until the address unit takes */ \
       /* it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3 */ \
       /* (no reads).  Every half-tile is re-filled >= 2 phases after its last reader; K-tile 1 came with the prologue. */ \
-      const bool n1 = XP != 2 && t >= 1 && t + 1 < nk, n2 = XP != 2 && t + 2 < nk; \
+      const bool n1 = t >= 1 && t + 1 < nk, n2 = t + 2 < nk; \
       /* ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0] */ \
       MB_LOAD_B(0) MB_LOAD_A(0)                          /* B first: the first MFMAs need both B fragments and only xa[0] */ \
       h16x16 xe; \
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output */ \
       /* stores stay in flight until the wait of K-tile 1. */ \
       if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); dma_b(cur, t + 2, 0); } \
-      if (t >= 1 || XP == 2) { \
+      if (t >= 1) { \
         if (n2) {                                        /* A0, B1, (X,) B0 of K-tile t+2 may stay in flight */ \
           if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
@@ -518,10 +518,6 @@ bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
   bool persistent = true;
   if (mt >= 1000) { persistent = false; mt -= 1000; }   // A/B: one tile per workgroup
-  if (mt == 16) { launch_ht<6, EPI_RES_F32, 1>(s, a); return; }   // ablations (see tools/xp_gemm.py)
-  if (mt == 26) { launch_ht<6, EPI_RES_F32, 2>(s, a); return; }
-  if (mt == 18) { launch_ht<8, EPI_RES_F32, 1>(s, a); return; }
-  if (mt == 28) { launch_ht<8, EPI_RES_F32, 2>(s, a); return; }
   if (mt != 6 && mt != 8 && mt != 257) {
     // pick the tile height that wastes fewer CU-rounds (one workgroup per CU)
     const int num_cu = num_cu_cached();

@@ -54,12 +54,11 @@ struct GemmArgs {
   const int* w8_exp = nullptr;
   uint8_t* out_lo8 = nullptr;
 };
-void gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);
+int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   // 0, or -1: lo-pass request outside the half-tile kernel's shapes
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
 // e4m3 copy of a weight (row stride 2K bytes, first K used) for the fp8 correction pass; *exp_out = the power of two it was scaled by
 void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp);
-void gemm_w4(hipStream_t s, GemmEpi epi, const GemmArgs& a);   // 4-wave 128x128-per-wave variant (gemm_w4.hip)
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,

@@ -60,6 +60,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
         if (xo) xo[c] = o;
         if (xb) xb[c] = to_h(o);
         if (xl) xl[c] = to_h(o - (float)to_h(o));
+        if (x8) x8[c] = (uint8_t)(lo8_pack4(o, 0.f, 0.f, 0.f) & 0xffu);
       }
     }
   }

@@ -37,10 +37,11 @@ def generate_uint8(model: LFQBert, vqgan_model: ConvVQModel, labels: torch.Tenso
                    softmax_temperature: float = 1.0, randomize_temperature: float = 4.5, mask_schedule_strategy: Text = "linear",
                    num_steps: int = 12, guidance_scale: float = 3.0, guidance_annealing: Text = "none",
                    use_sampling_annealing: bool = False, scale_pow: float = 4.0,
-                   total_samples: Optional[int] = None) -> Iterator[np.ndarray]:
+                   total_samples: Optional[int] = None, return_codes: bool = False) -> Iterator[np.ndarray]:
     """Yield ``total_samples // batchsize`` arrays ``uint8 [batchsize, H, W, 3]`` (host memory), batch *i* generated for
     ``labels[batchsize * i : batchsize * (i + 1)]`` exactly as eval_maskbit.py:111-135 does.  Each yielded array is a fresh copy
-    (the reference appends them to a list)."""
+    (the reference appends them to a list).  ``return_codes=True`` yields ``(images, codes int64 [batchsize, n])`` -- the combined
+    tokens each image was decoded from (what the reference's evaluator takes as ``codebook_indices``, evaluator.py:536)."""
     if not isinstance(model, LFQBert) or not isinstance(vqgan_model, ConvVQModel):
         raise TypeError("generate_uint8() needs a maskbit_amd generator and tokenizer")
     dev = model._require_cuda("generate_uint8")
@@ -62,14 +63,15 @@ def generate_uint8(model: LFQBert, vqgan_model: ConvVQModel, labels: torch.Tenso
     pending = None                                      # (slot, copy-done event) of the batch whose copy is in flight
 
     def collect(p):
-        slot, done = p
+        slot, done, codes = p
         done.synchronize()
-        return pinned[slot].numpy().copy()
+        out = pinned[slot].numpy().copy()
+        return (out, codes.cpu().numpy()) if return_codes else out
 
     for i in range(nbatch):
         y = labels[batchsize * i: batchsize * (i + 1)].long()
         exp_noise, conf_noise = draw_noise(batchsize, n, m, model.effective_codebook_size, num_steps, randomize_temperature, dev)
-        _, u8, _, _ = run_loop(model, vqgan_model, y, plan, exp_noise, conf_noise, want_steps=False, want_image=False, want_u8=True)
+        _, u8, _, codes = run_loop(model, vqgan_model, y, plan, exp_noise, conf_noise, want_steps=False, want_image=False, want_u8=True)
         slot = i & 1
         if pinned[slot] is None or pinned[slot].shape != u8.shape:
             pinned[slot] = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
@@ -83,6 +85,13 @@ def generate_uint8(model: LFQBert, vqgan_model: ConvVQModel, labels: torch.Tenso
         u8.record_stream(side)                           # the allocator must not hand the block out before the copy has read it
         if pending is not None:
             yield collect(pending)                       # batch i-1: its copy overlapped the sampling just enqueued
-        pending = (slot, done)
+        pending = (slot, done, codes)
     if pending is not None:
         yield collect(pending)
+
+
+def to_evaluator_uint8(u8_nhwc: torch.Tensor) -> torch.Tensor:
+    """NHWC uint8 (the decoder epilogue's output) -> the NCHW uint8 tensor ``GeneratorEvaluator.update`` builds for its Inception
+    network, ``(generated_images * 255).to(torch.uint8)`` on the clamped float image (evaluator/evaluator.py:549-551): the same
+    bytes without materialising the float image.  A view, no copy."""
+    return u8_nhwc.permute(0, 3, 1, 2)

@@ -1,7 +1,7 @@
 """Multi-GPU sampling: batch shards across ranks, one image gather at the end.
 
 The sampling path is embarrassingly parallel over samples: every rank owns a
-contiguous block of the batch and a full replica of the weights (0.61 GB bf16 + 59 MB), runs the whole
+contiguous block of the batch and a full replica of the weights (0.61 GB fp16 + 59 MB), runs the whole
 loop + decode on its block, and the only exchange is ONE ``all_gather`` of uint8 NHWC images
 (196 608 B per image) over RCCL/xGMI.  There is no counterpart in the reference (its inference is
 single-device, eval_maskbit.py:65).
@@ -66,7 +66,7 @@ def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: st
     """Sample ``len(global_labels)`` images across the process group; every rank returns all images,
     uint8 NHWC, identical on every rank (and, with ``noise="batch"``, identical to a 1-GPU run)."""
     import torch.distributed as dist
-    from .sampling import build_plan, draw_noise, run_loop
+    from .sampling import _ForcedPlan, build_plan, draw_noise, run_loop
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     B = int(global_labels.numel())
@@ -74,7 +74,14 @@ def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: st
     n, m, C_ = model.seq_len, model.splits, model.effective_codebook_size
     plan = build_plan(num_steps, n * m, guidance_scale, guidance_annealing, scale_pow, softmax_temperature,
                       use_sampling_annealing, mask_schedule_strategy)
+    if guidance_scale != 0.0 and not any(a != 0.0 for a in plan[0]):
+        plan = _ForcedPlan(plan)                      # as sample(): the CFG forward runs even when every annealed scale is 0
     dev = model.device
+    if hi == lo:                                      # more ranks than samples: this rank contributes an empty block to the gather
+        if noise == "batch":
+            draw_noise(B, n, m, C_, num_steps, randomize_temperature, dev)      # keep the generators in step with the other ranks
+        side = int(round(n ** 0.5)) << (vqgan_model.num_resolutions - 1)
+        return gather_images(torch.empty((0, side, side, vqgan_model.num_channels), dtype=torch.uint8, device=dev), group)
     if noise == "batch":
         e, c = draw_noise(B, n, m, C_, num_steps, randomize_temperature, dev)
         e, c = slice_noise(e, c, lo, hi, n * m)

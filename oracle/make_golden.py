@@ -7,7 +7,8 @@ weights into them with strict key checking (which also pins the checkpoint key n
 shapes of SURVEY.md 8b), runs them on CPU in fp32 and stores inputs + outputs as .npz.
 Nothing of the reference's source travels: fixtures hold tensors only.
 
-    python oracle/make_golden.py            # writes tests/golden/*.npz
+    python oracle/make_golden.py            # writes tests/golden/*.npz (all but the one below)
+    python oracle/make_golden.py full64     # tests/golden/sample_full12_64.npz: the reference's full-size 64-step CFG run
 
 Weights for the tiny cases are stored inside the fixtures; the full-size cases regenerate
 weights from a seed with oracle.make_*_weights and guard them with a sha256 sentinel.
@@ -99,10 +100,58 @@ def masked_test_tokens(cfg: O.GenCfg, b: int, seed: int) -> torch.Tensor:
     return torch.where(r < frac, torch.full_like(t, cfg.group_codes), t)
 
 
+FULL64 = dict(num_steps=64, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2,
+              mask_schedule_strategy="arccos")      # configs/generator/maskbit_generator_12bit.yaml (BASELINE configs[2])
+
+
+def full64(LFQBert, ConvVQModel, ref_sample, B: int = 4, seed: int = 1234):
+    """Full-size, free-running golden: the REAL reference's sample() (sampling.py:55-136) on the 12-bit generator,
+    64 steps, CFG 7.1 cosine, arccos schedule, seed fixed, on CPU fp32.  Stored per step: the predicted tokens
+    (l_full_tokens, int16) and the masked-token state the model saw (bit-packed mask: what a teacher-forced replay
+    needs), plus the final codes, pixel crops, a 4x-subsampled uint8 image and hashes.  Weights are regenerated from
+    seeds (sha-guarded), noise from the seed (torch CPU generator, draw order of the reference on a CPU model)."""
+    gsd = O.make_generator_weights(FULL_GEN12, seed=100, head_gain=12.0)
+    tsd = O.make_tokenizer_weights(FULL_TOK12, seed=200)
+    gen = build_ref_gen(LFQBert, FULL_GEN12, gsd)
+    tok = build_ref_tok(ConvVQModel, FULL_TOK12, O.make_tokenizer_weights(FULL_TOK12, seed=200, with_encoder=True))
+    labels = torch.tensor([7, 282, 604, 980, 1, 404, 850, 33][:B])
+    seen = []
+    inner = gen.forward
+
+    def spy(tokens, y, drop, *a, **k):                 # the model's input at every step = the masked-token state
+        seen.append(tokens[: tokens.shape[0] // 2].clone())
+        return inner(tokens, y, drop, *a, **k)
+
+    gen.forward = spy
+    torch.manual_seed(seed)
+    image, steps = ref_sample(gen, tok, num_samples=B, labels=labels.clone(), softmax_temperature=1.0, mask_token=64,
+                              patch_size=16, codebook_size=4096, codebook_splits=2, **FULL64)
+    gen.forward = inner
+    steps = torch.stack(steps)                          # [64, B, 256, 2]
+    masks = torch.stack(seen) == 64                     # [64, B, 256, 2] positions masked when step i ran
+    assert masks[0].all() and steps.max() < 64 + 1
+    assert torch.equal(torch.where(masks[1:], torch.full_like(steps[:-1], 64), steps[:-1]), torch.stack(seen)[1:])
+    codes = O.combine_groups(steps[-1], 12, 2)
+    u8 = (torch.clamp(image, 0.0, 1.0) * 255.0).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8)
+    crops = {f"crop_{y}_{x}": image[:, :, y:y + 16, x:x + 16].numpy() for (y, x) in ((0, 0), (120, 120), (240, 240), (37, 201))}
+    np.savez_compressed(os.path.join(OUT, "sample_full12_64.npz"), seed=seed, gen_seed=100, head_gain=12.0, tok_seed=200,
+                        labels=labels.numpy(), steps=steps.numpy().astype(np.int16),
+                        masks=np.packbits(masks.numpy().reshape(64, -1), axis=1), codes=codes.numpy().astype(np.int16),
+                        image_u8_q=u8[:, ::4, ::4].numpy(), image_u8_sha=sha(u8), image_mean=image.mean((0, 2, 3)).numpy(),
+                        image_std=image.std((0, 2, 3)).numpy(),
+                        w_sha_in_proj0=sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]),
+                        w_sha_conv_in=sha(tsd["decoder.conv_in.weight"]),
+                        kw_keys=np.array(list(FULL64.keys())), kw_vals=np.array([str(v) for v in FULL64.values()]), **crops)
+    print("sample_full12_64: sampled positions", int(masks.sum()), "final mask tokens left:", int((steps[-1] == 64).sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     LFQBert, ConvVQModel, ref_sample, ref_ratio, ref_combine, ref_split = _import_reference()
+    if "full64" in sys.argv[1:]:                        # only the (2-minute) full-size free-running run
+        full64(LFQBert, ConvVQModel, ref_sample)
+        return
 
     # ---- 1. tiny generator forward --------------------------------------------------------
     gsd = O.make_generator_weights(TINY_GEN, seed=11, head_gain=40.0)
