@@ -141,13 +141,13 @@ int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
   // variant: 0 auto; -1 this 128x128 kernel; 6 / 8 the half-tile kernel with that MT; 257 its sequence-aligned tiles.
   // Returns 0, or -1 when the request needs the half-tile kernel (8-bit / 4-bit lo pass) and the shape is outside it
   // (the caller reports it; nothing is launched).
-  if (a.A8 && variant < 0) variant = 0;               // the lo pass exists in the half-tile kernel only
+  if ((a.A8 || a.A4) && variant < 0) variant = 0;     // the lo pass exists in the half-tile kernel only
   if (variant >= 0 && gemm_ht_supported(epi, a)) {
     if (variant % 1000 == 257 && a.M % 257) variant = variant - variant % 1000;
     gemm_ht(s, epi, a, variant);
     return 0;
   }
-  if (a.A8) return -1;
+  if (a.A8 || a.A4) return -1;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles), block(256);
   switch (epi) {
@@ -194,6 +194,50 @@ __global__ void w8_kernel(const float* __restrict__ W, uint8_t* __restrict__ out
   }
 }
 
+// ---- e2m1 copy of a weight for the fp4 correction pass: one workgroup per weight row.  The row's power-of-two scale 2^r is the best of three
+// candidates around 2.2 / rms (measured optimum for Gaussian rows: quantisation error ~1.5 % of the row's energy) by summed squared error.
+__global__ __launch_bounds__(256) void w4_kernel(const float* __restrict__ W, uint8_t* __restrict__ out, int N, int K, uint8_t* __restrict__ scale_out) {
+  __shared__ float red[4][4];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* w = W + (size_t)n * K;
+  auto block_sum = [&](float v, int slot) {
+    v = wave_sum(v);
+    if (lane == 0) red[slot][wv] = v;
+    __syncthreads();
+    const float t = (red[slot][0] + red[slot][1]) + (red[slot][2] + red[slot][3]);
+    __syncthreads();
+    return t;
+  };
+  float ss = 0.f;
+  for (int k = tid; k < K; k += 256) { const float v = (float)(h16)w[k]; ss += v * v; }
+  const float rms = sqrtf(block_sum(ss, 0) / (float)K);
+  int r0 = 0;
+  if (rms > 0.f && rms < 3.0e38f) r0 = (int)rintf(log2f(2.2f / rms));
+  r0 = max(-100, min(100, r0));
+  float err[3] = {0.f, 0.f, 0.f};
+  const float F4V[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+  for (int k = tid; k < K; k += 256) {
+    const float v = (float)(h16)w[k];                                   // the fp16 engine multiplies by fp16(W): quantise THAT value
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float m = ldexpf(1.0f, r0 - 1 + c);
+      const float q = F4V[fp4_code(v * m) & 7];
+      const float d = fabsf(v) * m - q;
+      err[c] += d * d / (m * m);
+    }
+  }
+  float e0 = block_sum(err[0], 1), e1 = block_sum(err[1], 2), e2 = block_sum(err[2], 3);
+  const int best = (e1 <= e0 && e1 <= e2) ? 1 : (e0 <= e2 ? 0 : 2);
+  const int r = r0 - 1 + best;
+  const float m = ldexpf(1.0f, r);
+  if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)max(0, min(254, 127 - r));
+  uint8_t* o = out + (size_t)n * 2 * K;
+  for (int k = tid * 4; k < K; k += 1024) {
+    const float4 v = *(const float4*)(w + k);
+    *(uint16_t*)(o + k / 2) = (uint16_t)fp4_pack4((float)(h16)v.x, (float)(h16)v.y, (float)(h16)v.z, (float)(h16)v.w, m);
+  }
+}
+
 // ---- split-weight repack ----------------------------------------------------------------------
 __global__ void absmax_kernel(const float* __restrict__ src, size_t n, unsigned* __restrict__ out) {
   float m = 0.f;
@@ -223,6 +267,10 @@ void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K,
   (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
   hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K, tmp, scale_out);
+}
+void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out) {
+  (void)hipMemsetAsync(dst4, 0, 2 * (size_t)N * K, s);
+  hipLaunchKernelGGL(w4_kernel, dim3(N), dim3(256), 0, s, src, dst4, N, K, scale_out);
 }
 void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp) {
   const size_t n = (size_t)N * K;

@@ -36,18 +36,34 @@
 
 namespace mb {
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// A fragment pair (two 16-byte LDS reads of one lane) lives in ONE 8-VGPR tuple: the e4m3 MFMA takes it whole, the f16 / fp4 MFMAs its halves
+typedef h16 h16x16 __attribute__((ext_vector_type(16)));
+
+// One 16x16 output tile x one MX-fp4 K-tile of 256: two scaled MFMAs of K = 128, each over 16 bytes per lane and operand (the compiler narrows
+// the 8-VGPR operand to the 4 it reads).  SW / SX: which byte of the lane's scale VGPRs holds the E8M0 scale of this weight / token row.
+template <int SW, int SX>
+__device__ __forceinline__ f32x4 mma_f4(f32x4 c, const h16x16& w, const h16x16& x, int wsc, int xsc) {
+  const i32x8 wv = __builtin_bit_cast(i32x8, w), xv = __builtin_bit_cast(i32x8, x);
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 0, 1, 2, 3, -1, -1, -1, -1),
+                                                        __builtin_shufflevector(xv, xv, 0, 1, 2, 3, -1, -1, -1, -1), c, 4, 4, SW, wsc, SX, xsc);
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 4, 5, 6, 7, -1, -1, -1, -1),
+                                                          __builtin_shufflevector(xv, xv, 4, 5, 6, 7, -1, -1, -1, -1), c, 4, 4, SW, wsc, SX, xsc);
+}
+
 // SEQ = true: "sequence-aligned" tiles.  The trunk's M is nb*257 (256 image tokens + the class token per
 // sequence) and 257 is prime, so every ordinary tiling leaves a nearly empty CU round.  With SEQ a tile covers exactly
 // one sequence: 256 rows through the regular MT = 8 machinery plus the class-token row as a 17th, one-row m-tile whose
 // 4 n-tiles are split between the two wave rows (wm = 0 takes the B0 half in phase 0, wm = 1 the B1 half in phase 1:
 // +4 MFMAs per wave per K-tile).  The extra row lives in a 1 KiB "X" buffer per parity, re-filled by one extra DMA
 // instruction of wave 7 in phase 3.  tiles = nb * N/256: whole CU rounds for nb = 128.
-template <int MT, int EPI, int XP = 0, bool SEQ = false>   // XP: 0 = fp16 K-tiles only, 4 = fp16 K-tiles followed by an e4m3 lo pass
+template <int MT, int EPI, int XP = 0, bool SEQ = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
   // inside the K loop): those GEMMs run one tile per workgroup, everything else walks the tile list persistently.
-  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
+  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4 && XP != 5;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
   constexpr int AUX = 0;   // DMA cache policy: default beats nt (-14 %) and sc1 (-6 %) here, sc0 is equal (measured)
   constexpr int BM = 32 * MT, MH = MT / 2;
   constexpr int AH_ROWS = BM / 2;
@@ -67,12 +83,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int KA = a.ka ? a.ka : (a.kw ? a.kw : K), nka = KA / 64;   // split weights: A has KA = K/2 columns and is swept twice
   const int KW = a.kw ? a.kw : K, nkw = KW / 64;       // split activations: W has K/2 columns and is swept twice, A2 (lo halves) takes over from A
   constexpr bool F8 = XP == 4;                         // e4m3 lo pass: K-tiles >= nka come from (A8, W8), 128 K-elements per tile
+  constexpr bool F4 = XP == 5;                         // MX-fp4 lo pass: K-tiles >= nka come from (A4, W4), 256 K-elements per tile, fp16 fragment reads
+  constexpr bool LO = F8 || F4;
+  static_assert(!F4 || MT == 8, "the fp4 lo pass is written for the 256-row machinery");
   // Sequence-aligned e4m3 kernels: the DMA of an e4m3 K-tile permutes the 16-byte chunks of a row on the way into LDS (position ks*4+g
   // receives chunk 2g+ks, the 32 bytes lane group g feeds to the K = 128 MFMA), so the fragment reads are the fp16 ones -- reading
   // chunks 2g+ks in place was a 2-way LDS bank conflict on every read (PMC: 10.2 M conflict cycles of 40.9 M active, fp16 tiles: 0)
   constexpr bool PERM = F8 && SEQ;
-  const h16* const Alo = F8 ? (const h16*)a.A8 : (a.A2 ? a.A2 : a.A);
-  const h16* const Wlo = F8 ? (const h16*)a.W8 : a.W;
+  const h16* const Alo = F8 ? (const h16*)a.A8 : (F4 ? (const h16*)a.A4 : (a.A2 ? a.A2 : a.A));
+  const h16* const Wlo = F8 ? (const h16*)a.W8 : (F4 ? (const h16*)a.W4 : a.W);
   const int ntiles = tiles_m * tiles_n;
 
   // ---- per-tile DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
@@ -129,9 +148,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     for (int j = 0; j < 2; ++j) {
       // sequence-aligned tiles never clamp a row, so the four half-tile instructions of a wave differ by whole rows only:
       // one per-lane offset + a uniform (h * 64 + j * 128) * KA (6 VGPRs less than a table; used where VGPRs are the limit: the e4m3 kernels)
-      uint32_t o = (SEQ && F8) ? p.offA[0][0] + (t < nka ? 0 : p.d8) : p.offA[h][j];
-      if (F8) asm volatile("" : "+v"(o));               // keeps the 64-bit address arithmetic at the use (it was hoisted out of the two K loops and spilled)
-      const uint32_t u = (SEQ && F8) ? (uint32_t)(h * 64 + j * 128) * (uint32_t)KA : 0u;
+      uint32_t o = (SEQ && LO) ? p.offA[0][0] + ((PERM && t >= nka) ? p.d8 : 0) : p.offA[h][j];
+      if (LO) asm volatile("" : "+v"(o));               // keeps the 64-bit address arithmetic at the use (it was hoisted out of the two K loops and spilled)
+      const uint32_t u = (SEQ && LO) ? (uint32_t)(h * 64 + j * 128) * (uint32_t)KA : 0u;
       MB_GLDS16_AUX((t < nka ? a.A : Alo) + u + o + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
     }
   };
@@ -139,9 +158,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      uint32_t o = (SEQ && F8) ? p.offB[0][0] + (t < nkw ? 0 : p.d8) : p.offB[h][j];
-      if (F8) asm volatile("" : "+v"(o));
-      const uint32_t u = (SEQ && F8) ? (uint32_t)(h * 32 + j * 128) * (uint32_t)KW : 0u;
+      uint32_t o = (SEQ && LO) ? p.offB[0][0] + ((PERM && t >= nkw) ? p.d8 : 0) : p.offB[h][j];
+      if (LO) asm volatile("" : "+v"(o));
+      const uint32_t u = (SEQ && LO) ? (uint32_t)(h * 32 + j * 128) * (uint32_t)KW : 0u;
       MB_GLDS16_AUX((t < nkw ? a.W : Wlo) + u + o + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
     }
   };
@@ -172,6 +191,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // Both scales live in VGPRs of their own for the whole kernel (opaque here, used again after every K-tile): a rematerialised copy
   // was allocated INSIDE the destination registers of the class-row v_mfma_scale (dst v[78:81], scales v79 / v78) and produced garbage.
   if (F8) asm volatile("" : "+v"(sc_ab));
+  // MX-fp4 pass: per-lane E8M0 scale bytes of this tile's rows -- wsc: the 4 weight rows (n-tiles) of this lane, xsc0 / xsc1: the 4 + 4 token rows
+  // (m-tiles of the two A halves), xscc: the class-token row.  Loaded once per tile by plain loads that complete under the prologue's wait.
+  int wsc = 0, xsc0 = 0, xsc1 = 0, xscc = 0;
   const int xbase = wm * (8 * MT) * 128;              // this wave's rows inside an A half-tile
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
 
@@ -186,11 +208,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   __builtin_amdgcn_sched_barrier(0);                    \
   __builtin_amdgcn_s_setprio(1);
   // one 16x16 output tile x one K-tile: two f16 MFMAs of K = 32, or (e4m3 K-tile) one scaled MFMA of K = 128 over the same 2 x 16 bytes per lane
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  typedef int i32x8 __attribute__((ext_vector_type(8)));
-  typedef int i32x8 __attribute__((ext_vector_type(8)));
-  // A fragment pair (two 16-byte LDS reads of one lane) lives in ONE 8-VGPR tuple: the e4m3 MFMA takes it whole, the f16 MFMAs its halves
-  typedef h16 h16x16 __attribute__((ext_vector_type(16)));
   auto frag_set = [](h16x16 f, h16x8 v, int ks) -> h16x16 {
     return ks == 0 ? __builtin_shufflevector(__builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7), f, 0, 1, 2, 3, 4, 5, 6, 7, 24, 25, 26, 27, 28, 29, 30, 31)
                    : __builtin_shufflevector(f, __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23);
@@ -200,9 +217,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     c = MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(x, x, 0, 1, 2, 3, 4, 5, 6, 7), c);
     return MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 8, 9, 10, 11, 12, 13, 14, 15), __builtin_shufflevector(x, x, 8, 9, 10, 11, 12, 13, 14, 15), c);
   };
+#define MB_F4_ONE(AH, BH, I, N)                                                                     \
+  if constexpr (F4) acc[(BH) * 2 + (N)][(AH) * MH + (I)] =                                          \
+      mma_f4<(BH) * 2 + (N), (I)>(acc[(BH) * 2 + (N)][(AH) * MH + (I)], wb[BH][N], xa[I], wsc, (AH) ? xsc1 : xsc0);
 #define MB_MMA(AH, BH)                                                                              \
   {                                                                                                 \
-    if (F8 && f8t) {                                                                                \
+    if (F4 && f8t) {                                                                                \
+      MB_F4_ONE(AH, BH, 0, 0) MB_F4_ONE(AH, BH, 0, 1) MB_F4_ONE(AH, BH, 1, 0) MB_F4_ONE(AH, BH, 1, 1)  \
+      MB_F4_ONE(AH, BH, 2, 0) MB_F4_ONE(AH, BH, 2, 1) MB_F4_ONE(AH, BH, 3, 0) MB_F4_ONE(AH, BH, 3, 1)  \
+      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
+        asm volatile("" : "+v"(acc[(BH) * 2 + n][(AH) * MH + i]));                                  \
+    } else if (F8 && f8t) {                                                                         \
       _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
         acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], true);  \
       /* pin: left alone, the compiler sank all 32 scaled MFMAs of a K-tile below the phase barriers into one burst at the loop end */ \
@@ -220,8 +245,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   Plan cur;
   int vb = blockIdx.x;
   make_plan(vb, cur);
+  uint32_t sb[8] = {};                                 // F4: raw scale bytes of this lane's 8 token rows
+  if constexpr (F4) {
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
+    const int r15 = lo_ & 15;
+    wsc = ((const int*)a.w_scale)[((cur.n0 >> 6) + wn) * 16 + r15];
+    const uint8_t* sp = a.a_scale + cur.m0 + wm * (16 * MT) + r15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sb[i] = sp[min((i >> 2) * (8 * MT) + (i & 3) * 16, a.M - 1 - (cur.m0 + wm * (16 * MT) + r15))];   // rows past M (ragged last tile) re-read row M-1
+    if (SEQ) xscc = a.a_scale[cur.m0 + 256];
+  }
   prologue(cur);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (F4) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc), "+v"(xscc), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]) :: "memory");
+    xsc0 = sb[0] | (sb[1] << 8) | (sb[2] << 16) | (sb[3] << 24);
+    xsc1 = sb[4] | (sb[5] << 8) | (sb[6] << 16) | (sb[7] << 24);
+    asm volatile("" : "+v"(wsc), "+v"(xsc0), "+v"(xsc1), "+v"(xscc));   // held in VGPRs of their own through the K loops (cf. sc_ab)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();                        // K-tiles 0 and 1 of the first tile are in LDS for everyone
 
   while (true) {
@@ -237,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #define MB_KTILE(F8T)                                                                                  \
     {                                                                                                    \
       const char* par = smem + (t & 1) * PAR_BYTES; \
-      constexpr bool f8t = F8 && (F8T);                 /* this K-tile holds e4m3 operands */ \
+      constexpr bool f8t = LO && (F8T);                 /* this K-tile holds e4m3 / fp4 operands */ \
       int fo[2], xo[2]; \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
         if (F8 && !PERM) { \
@@ -246,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           const int r15 = lo_ & 15, gg = lo_ >> 4, sl = f8t ? 2 * gg + ks : ks * 4 + gg; \
           fo[ks] = r15 * 128 + ((sl ^ (r15 >> 1)) * 16); \
           xo[ks] = r15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + sl * 16 : fo[ks]; \
-        } else { fo[ks] = foff[ks]; xo[ks] = F8 ? foff[ks] + xadd : xoffe[ks]; } \
+        } else { fo[ks] = foff[ks]; xo[ks] = LO ? foff[ks] + xadd : xoffe[ks]; } \
       } \
       /* DMA issue is placed where the read phase is short (a global_load_lds blocks the issuing wave until the address unit takes */ \
       /* it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3 */ \
@@ -258,7 +300,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       if (SEQ && wm == 0) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       MB_SYNC_L() \
       if (SEQ && wm == 0) { \
-        if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, true); } \
+        if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<0, 0>(acce[0], wb[0][0], xe, wsc, xscc); acce[1] = mma_f4<1, 0>(acce[1], wb[0][1], xe, wsc, xscc); } } \
+        else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, true); } \
         else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, false); } \
         /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
         /* cover this pair here): pad before the register moves that end this block */ \
@@ -271,7 +314,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       if (n1) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
       if (SEQ && wm == 1) { \
-        if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, true); } \
+        if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<2, 0>(acce[0], wb[1][0], xe, wsc, xscc); acce[1] = mma_f4<3, 0>(acce[1], wb[1][1], xe, wsc, xscc); } } \
+        else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, true); } \
         else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, false); } \
         /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
         /* cover this pair here): pad before the register moves that end this block */ \
@@ -294,11 +338,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       } \
       MB_SYNC_L() MB_MMA(1, 0) \
       if (F8) asm volatile("" :: "v"(sc_ab)); \
+      if (F4) asm volatile("" :: "v"(wsc), "v"(xsc0), "v"(xsc1), "v"(xscc)); \
     }
     {
       int t = 0;
-      for (; t < (F8 ? nka : nk); ++t) MB_KTILE(false)
-      if (F8) for (; t < nk; ++t) MB_KTILE(true)
+      for (; t < (LO ? nka : nk); ++t) MB_KTILE(false)
+      if (LO) for (; t < nk; ++t) MB_KTILE(true)
     }
 #undef MB_KTILE
     if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the two groups
@@ -309,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int m0 = cur.m0, n0 = cur.n0;
     constexpr int NROWS = SEQ ? MT + 1 : MT;
     int l15e = l15, ge = g;                              // opaque copies (see make_plan): no per-row address tables
-    if (F8) { int lo_ = lane; asm volatile("" : "+v"(lo_)); l15e = lo_ & 15; ge = lo_ >> 4; }   // (recomputed: l15 / g need not live through the K loops)
+    if (LO) { int lo_ = lane; asm volatile("" : "+v"(lo_)); l15e = lo_ & 15; ge = lo_ >> 4; }   // (recomputed: l15 / g need not live through the K loops)
     asm volatile("" : "+v"(l15e), "+v"(ge));             // carried in VGPRs through the main loop
     auto row_of = [&](int r) { return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256; };
     auto col_of = [&](int r, int nt) {
@@ -325,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     Plan nxt;
     if (has_next) { make_plan(nvb, nxt); dma_x(nxt, 0); dma_x(nxt, 1); }
     f32x4 bias4[4], bcls[2];           // bcls: class-token row (indexing bias4 by wave id would put the array in scratch)
-    if constexpr (F8) {
+    if constexpr (LO) {
       // The e4m3 kernels run at the 256-VGPR limit, where the allocator may move registers around: an asm load whose result it does
       // not track could be copied while still in flight.  Plain loads here (the compiler waits for them; the overlap with the next
       // tile's prologue DMA is given up in this mode).
@@ -481,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #undef MB_LOAD_B
 #undef MB_SYNC_L
 #undef MB_MMA
+#undef MB_F4_ONE
 }
 
 static int num_cu_cached() {
@@ -504,13 +550,14 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
     configured = true;
   }
   const int tiles_m = SEQ ? a.M / 257 : (a.M + BM - 1) / BM, tiles_n = a.N / 256;
-  const int grid = (EPI != EPI_RES_F32 && XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
+  const int grid = (EPI != EPI_RES_F32 && XP != 4 && XP != 5 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
   hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
-  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8) &&
+  if (a.A4 && (a.A8 || !a.W4 || !a.a_scale || !a.w_scale || a.kw % 256 || a.K != a.kw + a.kw / 4 || epi == EPI_GELU_F32)) return false;
+  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8 || a.A4) &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
          (uint64_t)a.M * a.N * 4 < (1ull << 32);      // 32-bit element / byte offsets inside the kernel
 }
@@ -530,6 +577,16 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
       const long tiles = (long)(a.M / 257) * (a.N / 256);
       if ((double)((tiles + num_cu - 1) / num_cu) * 272 < cost(mt)) mt = 257;
     }
+  }
+  if (a.A4) {                                                              // MX-fp4 lo pass (XP = 5 instantiations)
+    const bool seq = a.M % 257 == 0 && mt != 8;
+    switch (epi) {
+      case EPI_H16: if (seq) launch_ht<8, EPI_H16, 5, true>(s, a, persistent); else launch_ht<8, EPI_H16, 5>(s, a, persistent); break;
+      case EPI_GELU_H16: if (seq) launch_ht<8, EPI_GELU_H16, 5, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 5>(s, a, persistent); break;
+      case EPI_RES_F32: if (seq) launch_ht<8, EPI_RES_F32, 5, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 5>(s, a, persistent); break;
+      default: break;
+    }
+    return;
   }
   if (a.A8) {                                                              // e4m3 lo pass (XP = 4 instantiations)
     const bool seq = a.M % 257 == 0 && mt != 8;

@@ -82,6 +82,30 @@ __device__ __forceinline__ uint32_t lo8_pack4(float v0, float v1, float v2, floa
   return lo8_pack4h(v0, v1, v2, v3, h16x4{to_h(v0), to_h(v1), to_h(v2), to_h(v3)});
 }
 
+// MX-fp4 (e2m1) "lo halves" for the strict mode's 4-bit correction pass.  A block of lo values (one LayerNorm row, or 64 columns of an
+// attention / GELU output row) shares one power-of-two scale chosen from the block's largest |lo|: v = lo * 2^s with 4 <= max|v| < 8,
+// i.e. s = 129 - biased_exponent(max|lo|); values in [5, 8) saturate to 6 (measured residual 1.7-2.5 % of the lo variance on Gaussian,
+// GELU and heavy-tailed rows, DESIGN.md "Precision").  The MFMA's E8M0 scale byte that undoes 2^s is 127 - s = biased_exponent - 2.
+// e2m1 codes 0..7 = {0, .5, 1, 1.5, 2, 3, 4, 6}, bit 3 = sign; element 2j is the low nibble of byte j.
+__device__ __forceinline__ uint32_t fp4_scale_byte(float maxlo) {            // 0 for an all-zero block (every product is then 0 anyway)
+  const int e = (__float_as_int(maxlo) >> 23) & 0xff;
+  return (uint32_t)(e >= 2 ? e - 2 : 0);
+}
+__device__ __forceinline__ float fp4_scale_mul(float maxlo) {                // 2^s as a float (0 for an all-zero / denormal block: codes become 0)
+  const int e = (__float_as_int(maxlo) >> 23) & 0xff;
+  return e >= 2 ? __int_as_float((256 - e) << 23) : 0.0f;                    // 2^(129 - e): biased exponent 256 - e in [2, 254]
+}
+__device__ __forceinline__ uint32_t fp4_code(float v) {                      // v already scaled; round to nearest e2m1, saturating at 6
+  const float a = fminf(fabsf(v), 6.0f);
+  int k = ((__float_as_int(a) >> 23) & 0xff) - 127;                          // floor(log2 a) for a >= 1
+  k = max(0, min(k, 2));
+  const float r = rintf(a * __int_as_float((128 - k) << 23));                // a / 2^(k-1): grid step 0.5 below 2, 1 below 4, 2 above
+  return (uint32_t)((int)r + 2 * k) | (v < 0.0f ? 8u : 0u);
+}
+__device__ __forceinline__ uint32_t fp4_pack4(float v0, float v1, float v2, float v3, float mul) {   // 4 consecutive columns -> 16 bits
+  return fp4_code(v0 * mul) | (fp4_code(v1 * mul) << 4) | (fp4_code(v2 * mul) << 8) | (fp4_code(v3 * mul) << 12);
+}
+
 // LayerNorm affine of one element, written with explicit roundings: the LayerNorm kernel and the GEMM epilogue that
 // re-derives the normalised residual from (y, mean, rstd) must produce the same bits.
 __device__ __forceinline__ float ln_affine(float v, float mean, float rstd, float g, float b) {

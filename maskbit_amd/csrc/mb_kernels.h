@@ -53,6 +53,15 @@ struct GemmArgs {
   const uint8_t* W8 = nullptr;
   const int* w8_exp = nullptr;
   uint8_t* out_lo8 = nullptr;
+  // MX-fp4 "lo pass" (half-tile kernel only), the cheaper sibling of the e4m3 one: A4 = e2m1(lo * 2^s) two per byte, W4 = e2m1(W * 2^r), both
+  // with the row stride in bytes of their fp16 siblings (2*kw, first kw/2 used).  K-tiles below kw/64 are fp16 (A, W), the following kw/256
+  // K-tiles hold 256 K-elements per 128-byte row and run on v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = blgp = 4 (two MFMAs of K = 128
+  // per 16x16 tile, the fp16 tiles' fragment reads); K = kw + kw/4.  a_scale[m] = the E8M0 byte undoing row m's 2^s (mb_common.h
+  // fp4_scale_byte), w_scale = the weights' bytes in the lane order of the kernel: entry ((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3).
+  const uint8_t* A4 = nullptr;
+  const uint8_t* W4 = nullptr;
+  const uint8_t* a_scale = nullptr;
+  const uint8_t* w_scale = nullptr;
 };
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   // 0, or -1: lo-pass request outside the half-tile kernel's shapes
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -60,9 +69,14 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
 // e4m3 copy of a weight (row stride 2K bytes, first K used) for the fp8 correction pass; *exp_out = the power of two it was scaled by
 void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp);
 
+// e2m1 copy of a weight for the fp4 correction pass: dst4[n][2K bytes] (first K/2 used) = e2m1(fp16(W[n]) * 2^r_n), r_n per row chosen to
+// minimise the row's quantisation error; scale_out in the kernel's lane order (GemmArgs.w_scale)
+void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);
+
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr, uint8_t* x8 = nullptr);   // x8: e4m3(lo * 2^15), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr, uint8_t* x8 = nullptr,
+                    uint8_t* x4 = nullptr, uint8_t* x4_scale = nullptr);   // x4: e2m1 lo halves (row stride 2d bytes) + one E8M0 byte per row   // x8: e4m3(lo * 2^15), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
 
 // ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------
 struct EmbedArgs {
@@ -80,6 +94,8 @@ struct EmbedArgs {
   const float* tables = nullptr;
   h16* x_lo = nullptr;     // optional: lo halves of x_h16 (split-activation GEMMs)
   uint8_t* x8 = nullptr;   // optional: e4m3 lo halves, row stride 2d bytes
+  uint8_t* x4 = nullptr;   // optional: e2m1 lo halves (row stride 2d bytes) with one E8M0 scale byte per row in x4_scale
+  uint8_t* x4_scale = nullptr;
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);

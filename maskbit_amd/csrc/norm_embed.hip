@@ -15,7 +15,8 @@ constexpr int MAXS = 32;  // scalar fallback path: d <= 64 * MAXS = 2048
 template <int NV>
 __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr, uint8_t* x8 = nullptr) {
+                                          float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr, uint8_t* x8 = nullptr,
+                                          uint8_t* x4 = nullptr, uint8_t* x4s = nullptr) {
   // xl (optional): the fp16 lo halves o - fp16(o) of the same row, for the split-activation GEMMs
   constexpr bool VEC = NV > 0;
   constexpr int nv = NV;
@@ -38,6 +39,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
   if (st && lane == 0) *(float2*)st = make_float2(mean, rstd);       // for the GEMM epilogue that re-derives these rows
+  float maxlo = 0.f;                                                  // x4: largest |lo| of the row -> its shared power-of-two scale
   if (VEC) {
 #pragma unroll
     for (int q = 0; q < nv; ++q) {
@@ -51,6 +53,17 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
       if (xb) *(h16x4*)(xb + c) = hi;
       if (xl) *(h16x4*)(xl + c) = h16x4{to_h(o.x - (float)hi[0]), to_h(o.y - (float)hi[1]), to_h(o.z - (float)hi[2]), to_h(o.w - (float)hi[3])};
       if (x8) *(uint32_t*)(x8 + c) = lo8_pack4h(o.x, o.y, o.z, o.w, hi);
+      if (x4) {                                                       // keep the lo halves in the row's registers for the second sweep
+        v[q] = make_float4(o.x - (float)hi[0], o.y - (float)hi[1], o.z - (float)hi[2], o.w - (float)hi[3]);
+        maxlo = fmaxf(maxlo, fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w))));
+      }
+    }
+    if (x4) {
+      maxlo = wave_max(maxlo);
+      const float mul = fp4_scale_mul(maxlo);
+      if (lane == 0) *x4s = (uint8_t)fp4_scale_byte(maxlo);
+#pragma unroll
+      for (int q = 0; q < nv; ++q) *(uint16_t*)(x4 + q * 128 + lane * 2) = (uint16_t)fp4_pack4(v[q].x, v[q].y, v[q].z, v[q].w, mul);
     }
   } else {
     for (int q = 0; q < ns; ++q) {
@@ -69,7 +82,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* x_f32,
-                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8) {
+                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -84,15 +97,16 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   else     { for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; sc[q] = c < d ? yr[c] : 0.f; } }
   ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
                  x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr,
-                 x_lo ? x_lo + (size_t)row * d : nullptr, x8 ? x8 + (size_t)row * 2 * d : nullptr);
+                 x_lo ? x_lo + (size_t)row * d : nullptr, x8 ? x8 + (size_t)row * 2 * d : nullptr,
+                 x4 ? x4 + (size_t)row * 2 * d : nullptr, x4s ? x4s + row : nullptr);
 }
 
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8) {
-  dim3 grid((M + 3) / 4), block(256);
-  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8);
-  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8);
-  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8);
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s) {
+  dim3 grid((M + 3) / 4), block(256);      // x4 (e2m1 lo halves): vector path only (d = 768 / 1024; mb_gen_create restricts the mode to those)
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, nullptr, nullptr);
 }
 
 // One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,
@@ -177,7 +191,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
     }
   }
   ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d, nullptr,
-                 a.x_lo ? a.x_lo + (size_t)row * d : nullptr, a.x8 ? a.x8 + (size_t)row * 2 * d : nullptr);
+                 a.x_lo ? a.x_lo + (size_t)row * d : nullptr, a.x8 ? a.x8 + (size_t)row * 2 * d : nullptr,
+                 a.x4 ? a.x4 + (size_t)row * 2 * d : nullptr, a.x4_scale ? a.x4_scale + row : nullptr);
 }
 
 void embed_ln(hipStream_t s, const EmbedArgs& a) {
