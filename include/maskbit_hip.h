@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MB_ABI_VERSION 3
+#define MB_ABI_VERSION 4
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
 typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
@@ -54,7 +54,9 @@ typedef struct {
    * attention output and the FFN hidden are hi + lo pairs (written by the attention kernel and the FFN-up epilogue), so all four
    * trunk GEMMs of a layer do twice their work.  3 = as 2, but the lo halves are stored as e4m3(lo * 2^12) and multiplied with an e4m3
    * copy of the weights on v_mfma_scale_f32_16x16x128_f8f6f4 (whose E8M0 scales undo the powers of two): the correction pass costs half
-   * a sweep; needs hidden and mlp to be multiples of 256.  Not combined with weight_split. */
+   * a sweep; needs hidden and mlp to be multiples of 256.  4 = as 3, but the lo halves of the LayerNorm outputs are MX-fp4 (e2m1, one
+   * power-of-two scale per row) against an e2m1 copy of the QKV / FFN-up weights (per-row scales): that correction pass costs a quarter
+   * sweep (hidden 768 / 1024).  2, 3 and 4 meet the <= 1e-3 token mismatch against the fp32 reference.  Not combined with weight_split. */
   int act_split;
 } mb_gen_cfg;
 
@@ -158,6 +160,14 @@ int mb_layernorm(const float* y, const float* gamma, const float* beta, float ep
  * (2*kw bytes, first kw used); kw % 128 == 0.  Diagnostic / test entry for mb_gen_cfg.act_split == 3. */
 int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const void* W8, const int* w8_exp, const float* bias,
                  const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
+/* The same with an MX-fp4 lo pass (mb_gen_cfg.act_split == 4): A4 = e2m1(lo * 2^s_m) two values per byte with one E8M0 scale byte per row
+ * (a_scale[m], as mb_layernorm_f4 writes them), W4 / w_scale from mb_w4_from_f32 (per-row scales in the kernel's lane order); both 4-bit
+ * operands with the row stride of their fp16 siblings (2*kw bytes, first kw/2 used); kw % 256 == 0, N % 64 == 0. */
+int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
+int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x4, void* x4_scale,
+                    int M, int d, mb_stream stream);
+int mb_gemm_f4lo(int epi, const void* A_hi, const void* A4, const void* a_scale, const void* W, const void* W4, const void* w_scale,
+                 const float* bias, const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
 int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual,
                       float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,

@@ -24,12 +24,15 @@ DEFAULT_WEIGHT_SPLIT = 0
 # -1 = "strict": the cheapest activation precision that meets the <= 1e-3 token mismatch against the fp32 reference
 # (act_split 3 where the lo-pass kernels take the shape, i.e. hidden and mlp multiples of 256; act_split 2 otherwise).
 DEFAULT_ACT_SPLIT = -1
+STRICT_LEVEL = int(os.environ.get("MASKBIT_AMD_STRICT_LEVEL", "3"))   # lo-pass format behind "strict": 3 = e4m3, 4 = MX-fp4 for the LayerNorm outputs
 
 
 def resolve_act_split(act_split: int, hidden: int, mlp: int) -> int:
     if act_split >= 0:
         return act_split
-    return 3 if hidden % 256 == 0 and mlp % 256 == 0 else 2
+    if hidden % 256 == 0 and mlp % 256 == 0:
+        return STRICT_LEVEL if (STRICT_LEVEL < 4 or hidden in (768, 1024)) else 3
+    return 2
 
 
 def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int, prenorm: bool = False,

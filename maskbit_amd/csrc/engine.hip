@@ -115,6 +115,10 @@ struct mb_gen {
   h16 *att_lo = nullptr, *h_lo = nullptr;                                                // cfg.act_split == 2: lo halves of att and h
   // cfg.act_split == 3: the lo halves as e4m3 (row stride 2 * width bytes) + e4m3 copies of the four trunk weights per layer
   uint8_t *x8 = nullptr, *att8 = nullptr, *h8 = nullptr;
+  // cfg.act_split == 4: the LayerNorm outputs' lo halves as MX-fp4 (x4, one E8M0 scale byte per row in x4s) + e2m1 copies of the two
+  // weights that read them (qkv, net.0) with per-row scales; attention output / FFN hidden keep the e4m3 lo halves of act_split 3
+  uint8_t *x4 = nullptr, *x4s = nullptr;
+  std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {qkv, -, 1, -}]
   std::vector<uint8_t*> w8;                                                              // [4 * layer + {qkv, o, 1, 2}]
   int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
   // loop state for mb_sample
@@ -145,15 +149,18 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   };
   int attn_rc = 0, gemm_rc = 0;
   h16* const xlo_trunk = (c.act_split == 1 || c.act_split == 2) ? g->x_lo : nullptr;   // LayerNorms that feed trunk GEMMs write lo halves only when those GEMMs use them
-  const bool f8 = c.act_split == 3;                       // e4m3 lo halves + e4m3 weight copies: the lo pass costs half a sweep
+  const bool f8 = c.act_split >= 3;                       // e4m3 lo halves + e4m3 weight copies: the lo pass costs half a sweep
+  const bool x4m = c.act_split == 4;                      // ... and the LayerNorm outputs' lo halves as MX-fp4: their lo pass costs a quarter sweep
+  uint8_t* const x8p = x4m ? nullptr : g->x8;
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
   // K = 2d K-tiles, the first d columns pairing x_h16 with W, the second d columns x_lo with the same W
   auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc, h16* out_lo = nullptr,
-                   const uint8_t* w8 = nullptr, const int* w8e = nullptr, uint8_t* out_lo8 = nullptr) {
+                   const uint8_t* w8 = nullptr, const int* w8e = nullptr, uint8_t* out_lo8 = nullptr, int widx = -1) {
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
-    if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
+    if (x4m) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4s[widx]; ga.out_lo8 = out_lo8; }
+    else if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
     else if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
     ga.out_lo = out_lo;
     gemm_rc |= gemm_tn(s, epi, ga);
@@ -168,7 +175,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
     e.x_lo = c.depth ? xlo_trunk : g->x_lo;
-    e.x8 = g->x8;
+    e.x8 = x8p; e.x4 = g->x4; e.x4_scale = g->x4s;
     embed_ln(s, e);
   }
   if (c.prenorm) {
@@ -176,18 +183,18 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
     for (int l = 0; l < c.depth; ++l) {
       const mb_gen::Layer& L = g->layers[l];
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, g->x8); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s); }
       { ProfScope p("gemm_qkv", s, true);
-        xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr); }
+        xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
       { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
       attn_rc |= attn_maps(l);
       { ProfScope p("gemm_attn_out", s, true);
         GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
         split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
         gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, g->x8); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s); }
       { ProfScope p("gemm_ffn_up", s, true);
-        xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8); }
+        xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
       { ProfScope p("gemm_ffn_down", s, true);
         GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
         split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
@@ -198,7 +205,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     { ProfScope p("gemm_qkv", s, true);
-      xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr); }
+      xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
     { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
     attn_rc |= attn_maps(l);
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
@@ -209,15 +216,15 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
       gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, g->x8); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, g->x4, g->x4s); }
     { ProfScope p("gemm_ffn_up", s, true);
-      xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8); }
+      xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
     { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
       gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, g->x8); }   // the last one feeds the head
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p, g->x4, g->x4s); }   // the last one feeds the head
   }
   }
   { ProfScope p("gemm_head", s, true);
@@ -325,6 +332,33 @@ int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
+int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream) {
+  if (!W || !dst4 || !scale_out || N <= 0 || K <= 0 || N % 64 || K % 4) return fail(-1, "mb_w4_from_f32: bad arguments");
+  mb::w4_from_f32((hipStream_t)stream, W, (uint8_t*)dst4, N, K, (uint8_t*)scale_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+int mb_gemm_f4lo(int epi, const void* A_hi, const void* A4, const void* a_scale, const void* W, const void* W4, const void* w_scale, const float* bias,
+                 const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
+  if (!A_hi || !A4 || !a_scale || !W || !W4 || !w_scale || !bias || epi < 0 || epi > 2 || kw <= 0 || kw % 256) return fail(-1, "mb_gemm_f4lo: bad arguments");
+  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, kw + kw / 4, 0, 0, nullptr};
+  a.kw = kw; a.A4 = (const uint8_t*)A4; a.W4 = (const uint8_t*)W4; a.a_scale = (const uint8_t*)a_scale; a.w_scale = (const uint8_t*)w_scale;
+  if (!mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_f4lo: shape not supported by the half-tile kernel");
+  ProfScope p("gemm_diag", (hipStream_t)stream);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x4, void* x4_scale, int M, int d,
+                    mb_stream stream) {
+  if (!y || !gamma || !beta || !x4 || !x4_scale || M <= 0 || (d != 768 && d != 1024)) return fail(-1, "mb_layernorm_f4: bad arguments (d must be 768 or 1024)");
+  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, nullptr, M, d, nullptr, nullptr, (uint8_t*)x4, (uint8_t*)x4_scale);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
 int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x_lo, float* stats, int M,
                  int d, mb_stream stream) {
   if (!y || !gamma || !beta || M <= 0 || d <= 0 || d > 2048) return fail(-1, "mb_layernorm: bad arguments");
@@ -364,8 +398,9 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if ((c.prenorm != 0 && c.prenorm != 1) || (c.embed_tables != 0 && c.embed_tables != 1)) return fail(-1, "prenorm / embed_tables must be 0 or 1");
   if (c.embed_tables && c.weight_split) return fail(-1, "weight_split is not supported with embed_tables (the tied head spans one table per group)");
   if (c.embed_tables && c.splits > 8) return fail(-1, "embed_tables supports up to 8 token groups");
-  if (c.act_split < 0 || c.act_split > 3) return fail(-1, "act_split must be 0, 1, 2 or 3");
-  if (c.act_split == 3 && (c.hidden % 256 || c.mlp % 256)) return fail(-1, "act_split = 3 (e4m3 lo pass) needs hidden and mlp to be multiples of 256");
+  if (c.act_split < 0 || c.act_split > 4) return fail(-1, "act_split must be 0 .. 4");
+  if (c.act_split >= 3 && (c.hidden % 256 || c.mlp % 256)) return fail(-1, "act_split = 3 / 4 (8- / 4-bit lo pass) needs hidden and mlp to be multiples of 256");
+  if (c.act_split == 4 && c.hidden != 768 && c.hidden != 1024) return fail(-1, "act_split = 4 (MX-fp4 lo pass) is built for hidden = 768 or 1024");
   if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
@@ -396,15 +431,23 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->ln_stats, M * 2); rc |= galloc(g, &g->x_h16, M * d);
   if (!c.weight_split) rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, act_split >= 1 for the trunk
   if (c.act_split == 2) { rc |= galloc(g, &g->att_lo, M * d); rc |= galloc(g, &g->h_lo, M * f); }
-  if (c.act_split == 3) {
-    rc |= galloc(g, &g->x8, M * 2 * d); rc |= galloc(g, &g->att8, M * 2 * d); rc |= galloc(g, &g->h8, M * 2 * f);
+  if (c.act_split >= 3) {
+    const bool x4m = c.act_split == 4;
+    if (x4m) { rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, M + 256); } else rc |= galloc(g, &g->x8, M * 2 * d);
+    rc |= galloc(g, &g->att8, M * 2 * d); rc |= galloc(g, &g->h8, M * 2 * f);
     rc |= galloc(g, &g->w8_exp, (size_t)4 * c.depth);
-    g->w8.assign((size_t)4 * c.depth, nullptr);
+    g->w8.assign((size_t)4 * c.depth, nullptr); g->w4.assign((size_t)4 * c.depth, nullptr); g->w4s.assign((size_t)4 * c.depth, nullptr);
     for (int l = 0; l < c.depth; ++l) {
-      rc |= galloc(g, &g->w8[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w8[4 * l + 1], 2 * d * d);
-      rc |= galloc(g, &g->w8[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w8[4 * l + 3], 2 * d * f);
+      if (x4m) {
+        rc |= galloc(g, &g->w4[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4s[4 * l], 3 * d);
+        rc |= galloc(g, &g->w4[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4s[4 * l + 2], f);
+      } else { rc |= galloc(g, &g->w8[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w8[4 * l + 2], 2 * f * d); }
+      rc |= galloc(g, &g->w8[4 * l + 1], 2 * d * d); rc |= galloc(g, &g->w8[4 * l + 3], 2 * d * f);
     }
-    if (!rc) { (void)hipMemset(g->x8, 0, M * 2 * d); (void)hipMemset(g->att8, 0, M * 2 * d); (void)hipMemset(g->h8, 0, M * 2 * f); }
+    if (!rc) {
+      if (x4m) { (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, M + 256); } else (void)hipMemset(g->x8, 0, M * 2 * d);
+      (void)hipMemset(g->att8, 0, M * 2 * d); (void)hipMemset(g->h8, 0, M * 2 * f);
+    }
   }
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
@@ -494,7 +537,10 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   else if (dst_h && g->split) mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
   else if (dst_h) {
     mb::cast_f32_to_h16(s, data, dst_h, numel);
-    if (c.act_split == 3 && sidx >= 0 && sidx < 4 * c.depth) mb::w8_from_f32(s, data, g->w8[sidx], wrows, wcols, g->w8_exp + sidx, g->split_tmp);
+    if (c.act_split >= 3 && sidx >= 0 && sidx < 4 * c.depth) {
+      if (g->w4[sidx]) mb::w4_from_f32(s, data, g->w4[sidx], wrows, wcols, g->w4s[sidx]);
+      else mb::w8_from_f32(s, data, g->w8[sidx], wrows, wcols, g->w8_exp + sidx, g->split_tmp);
+    }
   }
   else HIP_TRY(hipMemcpyAsync(dst_f, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   g->loaded++;

@@ -44,6 +44,19 @@ def test_teacher_forced_mismatch_vs_reference_run(setup):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("level", [2, 3, 4])
+def test_every_strict_level_meets_the_bound(setup, level):
+    """act_split 2 (fp16 lo halves), 3 (e4m3 lo halves) and 4 (MX-fp4 lo halves for the LayerNorm outputs) against the reference's run."""
+    g, gen, tok, noise = setup
+    gen.weight_split, gen.act_split = 0, level
+    bad, tot, per_step, _ = R.teacher_forced(gen, g, noise)
+    gen.act_split = -1
+    print(f"act_split = {level}: teacher-forced mismatch vs the reference's run {bad}/{tot} = {bad / tot:.2e}; "
+          f"per 8 steps {[sum(per_step[i:i + 8]) for i in range(0, 64, 8)]}")
+    assert bad / tot <= 1e-3
+
+
+@pytest.mark.timeout(900)
 def test_free_running_64_steps_vs_reference_run(setup):
     """One mb_sample call over all 64 steps + decode with the reference's noise.  A single flipped token changes every later step of
     that image, so the trajectories are compared statistically: the first step (same input for both) must agree to <= 2e-3, images
