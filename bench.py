@@ -177,8 +177,9 @@ def main():
 
     B = args.batch
     gen, tok = build_models(dev)
-    MODES = {"strict": -1, "fp16": 0}                   # LFQBert.act_split (-1: hi + lo activation pairs, the product default)
-    gen.weight_split, gen.act_split = 0, MODES[args.mode]
+    MODES = {"strict": (-1, -1), "fp16": (0, 0)}        # LFQBert (act_split, cfg_pair): (-1, -1) = the product default
+    gen.weight_split = 0
+    gen.act_split, gen.cfg_pair = MODES[args.mode]
     torch.manual_seed(1234 + rank)
     plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
                       SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])
@@ -220,12 +221,12 @@ def main():
     if world == 1 and not args.no_modes:
         other = "fp16" if args.mode == "strict" else "strict"
         modes = {args.mode: {"images_per_s": B * world * args.steps / elapsed, "timed": True, "parity": measured_parity(gen)}}
-        gen.act_split = MODES[other]
+        gen.act_split, gen.cfg_pair = MODES[other]
         one_batch(10_000); torch.cuda.synchronize()
         ts = time.perf_counter()
         one_batch(10_001); torch.cuda.synchronize()
         modes[other] = {"images_per_s": B / (time.perf_counter() - ts), "timed": False, "parity": measured_parity(gen)}
-        gen.act_split = MODES[args.mode]
+        gen.act_split, gen.cfg_pair = MODES[args.mode]
 
     if rank == 0:
         total_images = B * world * args.steps
@@ -284,8 +285,10 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, one process per GPU)"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "precision": {"timed_mode": args.mode,
-                          "strict": "fp16 MFMA over hi + lo activation pairs (lo pass in 8 / 4 bits), fp32 accumulate: the product default",
-                          "fp16": "single fp16 operands, fp32 accumulate (LFQBert.act_split = 0)"},
+                          "strict": "the product default: fp16 MFMA, fp32 accumulate, classifier-free guidance in differential form (the unconditional "
+                                    "stream's operands carried as fp16(x_u - x_c)) + an MX-fp4 correction pass for the QKV / FFN-up weight rounding "
+                                    "in the steps with guidance scale < 1",
+                          "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
             "precision_modes": modes,
             "kernels_note": f"HIP events on the launch stream inside the timed region; generator kernels sampled on every {PROF_EVERY}th forward",
         }

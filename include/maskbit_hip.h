@@ -58,6 +58,14 @@ typedef struct {
    * power-of-two scale per row) against an e2m1 copy of the QKV / FFN-up weights (per-row scales): that correction pass costs a quarter
    * sweep (hidden 768 / 1024).  2, 3 and 4 meet the <= 1e-3 token mismatch against the fp32 reference.  Not combined with weight_split. */
   int act_split;
+  /* Classifier-free guidance in differential form (mb_gen_forward_cfg / mb_sample; DESIGN.md "Precision"): 0 = off (the guided forward is
+   * the plain forward over [cond | uncond]); 1 = the unconditional stream's GEMM operands are carried as fp16(x_u - x_c) next to fp16(x_c),
+   * so the operand rounding of x_c is common to both streams and cancels in (c - u), the term the guidance scale multiplies -- at no
+   * extra GEMM work; 2 = additionally an MX-fp4 correction pass for the fp16 rounding of the QKV / FFN-up WEIGHTS (e2m1(x_c) against
+   * e2m1(W - fp16(W)), a quarter sweep) in the steps whose guidance scale is below 1, where weight rounding is the dominant error.
+   * Needs seq = 256, hidden 768 / 1024, mlp % 256 == 0, post-norm, act_split = weight_split = 0; otherwise the engine falls back to the
+   * plain forward. */
+  int cfg_pair;
 } mb_gen_cfg;
 
 /* ConvDecoder configuration (modeling/modules/autoencoder.py:358-397, configs/tokenizer yaml files). */
@@ -98,6 +106,11 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
  * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */
 int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop,
                    float* logits, int nb, mb_stream stream);
+/* The guided forward of sample() (sampling.py:83-88): tokens int64 [B,seq,m], labels int64 [B] -> logits fp32 [2B,seq,m,C], rows [0,B) the
+ * conditional and [B,2B) the label-dropped forward of the same tokens.  With cfg.cfg_pair the two streams run in differential form
+ * (see mb_gen_cfg.cfg_pair); `scale` is the step's guidance scale (a hint for the precision plan: pass the value the logits will be
+ * combined with, or a negative number when unknown). */
+int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, mb_stream stream);
 /* The same forward with `return_attn=True` (bert.py:461, 505-508; nn.MultiheadAttention need_weights with head averaging,
  * bert.py:119,137): additionally attn fp32 [depth, nb, seq+1, seq+1], layer l's softmax weights averaged over the heads
  * (class token = last row / column).  Visualisation path, not used by sample(). */
@@ -168,6 +181,11 @@ int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float
                     int M, int d, mb_stream stream);
 int mb_gemm_f4lo(int epi, const void* A_hi, const void* A4, const void* a_scale, const void* W, const void* W4, const void* w_scale,
                  const float* bias, const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
+/* A "CFG pair" GEMM (mb_gen_cfg.cfg_pair): rows [0, pair_rows) of A / out are conditional, [pair_rows, 2 pair_rows) their unconditional twins whose
+ * A rows hold the difference operand; out_c = f(A_c.W), out_u = f(A_c.W + A_delta.W) (GELU epilogue: the u rows receive gelu(u) - gelu(c)).
+ * pair_rows % 257 == 0.  A4 / a_scale / W4 / w_scale (all four or none): an MX-fp4 correction pass over kw/256 extra K-tiles. */
+int mb_gemm_pair(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
+                 int pair_rows, int N, int kw, const void* A4, const void* a_scale, const void* W4, const void* w_scale, mb_stream stream);
 int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual,
                       float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,

@@ -15,7 +15,7 @@ ABI_VERSION = 4
 
 
 class GenCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass", "weight_split", "prenorm", "embed_tables", "act_split")]
+    _fields_ = [(n, C.c_int) for n in ("bits", "splits", "hidden", "heads", "depth", "mlp", "seq", "nclass", "weight_split", "prenorm", "embed_tables", "act_split", "cfg_pair")]
 
 
 class DecCfg(C.Structure):
@@ -38,6 +38,7 @@ SIGNATURES = {
     "mb_gen_destroy": (None, [C.c_void_p]),
     "mb_gen_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     "mb_gen_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_gen_forward_cfg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mb_gen_forward_attn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_sample_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -58,6 +59,8 @@ SIGNATURES = {
     "mb_layernorm_f4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mb_gemm_f4lo": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mb_gemm_pair": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mb_gemm_act_split": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),
     "mb_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

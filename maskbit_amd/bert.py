@@ -25,6 +25,14 @@ DEFAULT_WEIGHT_SPLIT = 0
 # (act_split 3 where the lo-pass kernels take the shape, i.e. hidden and mlp multiples of 256; act_split 2 otherwise).
 DEFAULT_ACT_SPLIT = -1
 STRICT_LEVEL = int(os.environ.get("MASKBIT_AMD_STRICT_LEVEL", "3"))   # lo-pass format behind "strict": 3 = e4m3, 4 = MX-fp4 for the LayerNorm outputs
+# Differential classifier-free guidance (mb_gen_cfg.cfg_pair): -1 = auto (2 where the shape allows it), 0 = off, 1 = differential operands,
+# 2 = + MX-fp4 correction of the QKV / FFN-up weight rounding where it dominates.  Where it applies it REPLACES the hi + lo activation pairs
+# (act_split resolves to 0): same parity class at the cost of the plain fp16 forward.
+DEFAULT_CFG_PAIR = -1
+
+
+def pair_capable(seq_len: int, hidden: int, mlp: int, prenorm: bool) -> bool:
+    return seq_len == 256 and hidden in (768, 1024) and mlp % 256 == 0 and not prenorm
 
 
 def resolve_act_split(act_split: int, hidden: int, mlp: int) -> int:
@@ -94,6 +102,7 @@ class LFQBert(BaseModel):
         # of a sweep).  2 and 3 meet the <= 1e-3 token mismatch against the fp32 reference (DESIGN.md "Precision").  -1 (DEFAULT) = 3 where
         # the shape allows, else 2.  Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
         self.act_split = int(os.environ.get("MASKBIT_AMD_ACT_SPLIT", str(DEFAULT_ACT_SPLIT)))
+        self.cfg_pair = int(os.environ.get("MASKBIT_AMD_CFG_PAIR", str(DEFAULT_CFG_PAIR)))
         self._engine_split = None
         if not self.embed_tables:
             self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
@@ -106,15 +115,28 @@ class LFQBert(BaseModel):
 
     # ---- engine hooks ---------------------------------------------------------------------
     def _engine_create(self, capacity: int):
-        act = resolve_act_split(int(self.act_split), self.hidden_dim, self.mlp_dim)
-        if self.weight_split and int(self.act_split) < 0:
-            act = 0                                                # fp16x2 weights (opt-in experiment) are not combined with act_split
+        act, pair = self.resolved_precision()
         cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass,
-                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables), act)
-        self._engine_split = (int(self.weight_split), int(self.act_split))
+                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables), act, pair)
+        self._engine_split = (int(self.weight_split), int(self.act_split), int(self.cfg_pair))
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
         return h
+
+    def resolved_precision(self):
+        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch the cheapest way":
+        differential CFG + weight-rounding correction where the shape allows it, hi + lo activation pairs otherwise."""
+        capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm) and not self.weight_split
+        pair, act = int(self.cfg_pair), int(self.act_split)
+        if pair < 0:
+            pair = 2 if (capable and act <= 0) else 0
+        if pair and not (capable and act <= 0):
+            pair = 0
+        if pair:
+            return 0, pair
+        if self.weight_split and act < 0:
+            return 0, 0                                            # fp16x2 weights (opt-in experiment) are not combined with act_split
+        return resolve_act_split(act, self.hidden_dim, self.mlp_dim), 0
 
     def _engine_destroy(self, h) -> None:
         _lib.load().mb_gen_destroy(h)
@@ -125,7 +147,7 @@ class LFQBert(BaseModel):
 
     def engine(self, min_seqs: int):
         """Device engine able to hold ``min_seqs`` sequences (CFG needs 2 x batch)."""
-        if self._engine is not None and self._engine_split != (int(self.weight_split), int(self.act_split)):
+        if self._engine is not None and self._engine_split != (int(self.weight_split), int(self.act_split), int(self.cfg_pair)):
             self._drop_engine()                                    # precision mode changed: rebuild and repack
         have = self._engine_key[1] if self._engine_key else 0
         return self._ensure_engine(max(min_seqs, have, 16))
@@ -169,6 +191,28 @@ class LFQBert(BaseModel):
                 return logits, list(attn.unbind(0))
             _lib.check(_lib.load().mb_gen_forward(h, toks.data_ptr(), labs.data_ptr(), drop.data_ptr() if drop is not None else None,
                                                   logits.data_ptr(), b, torch.cuda.current_stream().cuda_stream), "mb_gen_forward")
+        return logits
+
+
+    @torch.no_grad()
+    def forward_cfg(self, img_tokens: torch.Tensor, class_labels: torch.Tensor, scale: float = -1.0) -> torch.Tensor:
+        """The guided forward of sample() (sampling.py:83-88) in one call: logits [2b, seq, m, C], rows [0, b) = model(tokens, labels, ~drop),
+        rows [b, 2b) = the label-dropped forward of the same tokens.  On the engine the two streams run in differential form (cfg_pair);
+        ``scale`` is the guidance scale the caller will combine them with (precision plan hint; negative = unknown)."""
+        dev = self._require_cuda("forward_cfg")
+        if img_tokens.dim() != 3 or img_tokens.shape[1] != self.seq_len or img_tokens.shape[2] != self.splits:
+            raise ValueError(f"img_tokens must be [b, {self.seq_len}, {self.splits}], got {tuple(img_tokens.shape)}")
+        b = img_tokens.shape[0]
+        if class_labels.numel() != b:
+            raise ValueError(f"class_labels must hold {b} labels, got {tuple(class_labels.shape)}")
+        self._check_labels(class_labels)
+        toks = img_tokens.to(device=dev, dtype=torch.int64).contiguous()
+        labs = class_labels.to(device=dev, dtype=torch.int64).reshape(b).contiguous()
+        logits = torch.empty((2 * b, self.seq_len, self.splits, self.effective_codebook_size), dtype=torch.float32, device=dev)
+        h = self.engine(2 * b)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mb_gen_forward_cfg(h, toks.data_ptr(), labs.data_ptr(), logits.data_ptr(), b, float(scale),
+                                                      torch.cuda.current_stream().cuda_stream), "mb_gen_forward_cfg")
         return logits
 
 

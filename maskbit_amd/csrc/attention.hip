@@ -33,9 +33,11 @@ constexpr int ATT_MAXQT = (ATT_NKT + ATT_NW - 1) / ATT_NW;   // q-tiles per wave
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <int DH>
+// AUX (CFG pair attention, mb_kernels.h attention_pair): 1 = also store the fp32 output rows to aux (conditional sequences), 2 = subtract the
+// conditional twin's fp32 rows (aux) and store the DIFFERENCE as the fp16 output (unconditional sequences, sq_off = P)
+template <int DH, int AUX = 0>
 __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
-                                                          int N, int d, int heads, float scale_log2e) {
+                                                          int N, int d, int heads, float scale_log2e, float* __restrict__ aux = nullptr, int sq_off = 0) {
   constexpr int ROW = DH * 2;            // bytes per K / V row
   constexpr int SL = DH / 8;             // 16-byte slots per row (8 or 4)
   constexpr int KS = DH / 32;            // k-steps of the QK^T MFMA
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int sq = blockIdx.x / heads, h = blockIdx.x - sq * heads;
+  const int sq0 = blockIdx.x / heads, h = blockIdx.x - sq0 * heads;
+  const int sq = sq0 + sq_off;
   const size_t rs = (size_t)3 * d;                                   // qkv row stride (elements)
   const h16* base = qkv + (size_t)sq * N * rs + h * DH;
 
@@ -131,6 +134,12 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
     sum += __shfl_xor(sum, 32);
     float inv = 1.0f / sum;
     asm volatile("" : "+v"(inv));          // every cross-lane op of the softmax has retired before the asm LDS reads start
+    f32x4 twin[DH / 16];                   // AUX 2: the conditional twin's output rows, requested now, used after the PV loop
+    if constexpr (AUX == 2) {
+      const int qq = min(qt * 16 + l15, N - 1);
+#pragma unroll
+      for (int nt = 0; nt < DH / 16; ++nt) twin[nt] = *(const f32x4*)(aux + ((size_t)sq0 * N + qq) * d + h * DH + nt * 16 + g * 4);
+    }
 
     // ---- O^T = V^T P^T ; V^T fragments by transpose reads, one k-block ahead
     f32x4 o[NT];
@@ -196,7 +205,9 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
       const size_t ooff = ((size_t)sq * N + q) * d + h * DH;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 v = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+        f32x4 v = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+        if constexpr (AUX == 1) *(f32x4*)(aux + ((size_t)sq0 * N + q) * d + h * DH + nt * 16 + g * 4) = v;
+        if constexpr (AUX == 2) v = v - twin[nt];
         const h16x4 hi = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
         *(h16x4*)(out + ooff + nt * 16 + g * 4) = hi;
         if (out_lo)                                             // split activations: the fp16 lo halves v - fp16(v)
@@ -432,6 +443,21 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
   dim3 grid(nb * heads), block(64 * ATT_NW);
   if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
   else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
+}
+
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads) {
+  const int dh = d / heads;
+  if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  dim3 grid(P * heads), block(64 * ATT_NW);
+  if (dh == 64) {
+    hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);
+    hipLaunchKernelGGL((attention_kernel<64, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
+  } else {
+    hipLaunchKernelGGL((attention_kernel<32, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);
+    hipLaunchKernelGGL((attention_kernel<32, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
+  }
+  return 0;
 }
 
 }  // namespace mb

@@ -120,6 +120,12 @@ struct mb_gen {
   uint8_t *x4 = nullptr, *x4s = nullptr;
   std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {qkv, -, 1, -}]
   std::vector<uint8_t*> w8;                                                              // [4 * layer + {qkv, o, 1, 2}]
+  // cfg.cfg_pair: differential CFG forward.  pair_ok = the shape allows it; aux = the conditional attention output in fp32 (attention_pair);
+  // cfg_pair == 2 ("W mode"): x4 / x4s hold e2m1(x_c) of the LayerNorm outputs, w4lo / w4los the e2m1 rounding errors of qkv / net.0
+  bool pair_ok = false;
+  float* att_aux = nullptr;
+  float* logits_tmp = nullptr;                          // guided forwards over more pairs than one pass holds
+  std::vector<uint8_t*> w4lo, w4los;                                                     // [4 * layer + {qkv, -, 1, -}]
   int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
   // loop state for mb_sample
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
@@ -152,6 +158,9 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   const bool f8 = c.act_split >= 3;                       // e4m3 lo halves + e4m3 weight copies: the lo pass costs half a sweep
   const bool x4m = c.act_split == 4;                      // ... and the LayerNorm outputs' lo halves as MX-fp4: their lo pass costs a quarter sweep
   uint8_t* const x8p = x4m ? nullptr : g->x8;
+  // cfg_pair == 2 outside a guided forward (plain forward(), sampling without guidance): weight rounding is the dominant logit error there, so the
+  // QKV / FFN-up GEMMs always carry the MX-fp4 weight-correction pass (x4 = e2m1 of the LayerNorm VALUES against e2m1(W - fp16(W)))
+  const bool wm = g->pair_ok && c.cfg_pair == 2;
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
@@ -159,7 +168,8 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc, h16* out_lo = nullptr,
                    const uint8_t* w8 = nullptr, const int* w8e = nullptr, uint8_t* out_lo8 = nullptr, int widx = -1) {
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
-    if (x4m) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4s[widx]; ga.out_lo8 = out_lo8; }
+    if (wm) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4los[widx]; }
+    else if (x4m) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4s[widx]; ga.out_lo8 = out_lo8; }
     else if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
     else if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
     ga.out_lo = out_lo;
@@ -175,7 +185,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
     e.x_lo = c.depth ? xlo_trunk : g->x_lo;
-    e.x8 = x8p; e.x4 = g->x4; e.x4_scale = g->x4s;
+    e.x8 = x8p; e.x4 = g->x4; e.x4_scale = g->x4s; e.x4_values = wm;
     embed_ln(s, e);
   }
   if (c.prenorm) {
@@ -183,7 +193,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
     for (int l = 0; l < c.depth; ++l) {
       const mb_gen::Layer& L = g->layers[l];
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s, wm); }
       { ProfScope p("gemm_qkv", s, true);
         xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
       { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
@@ -192,7 +202,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
         GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
         split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
         gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s, wm); }
       { ProfScope p("gemm_ffn_up", s, true);
         xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
       { ProfScope p("gemm_ffn_down", s, true);
@@ -216,7 +226,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
       gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, g->x4, g->x4s); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, g->x4, g->x4s, wm); }
     { ProfScope p("gemm_ffn_up", s, true);
       xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
     { ProfScope p("gemm_ffn_down", s, true);
@@ -224,7 +234,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
       gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p, g->x4, g->x4s); }   // the last one feeds the head
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p, g->x4, g->x4s, wm); }   // the last one feeds the head
   }
   }
   { ProfScope p("gemm_head", s, true);
@@ -247,6 +257,71 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   return 0;
 }
 
+// Differential CFG forward (mb_gen_cfg.cfg_pair): nb = 2 * B sequences laid out [B conditional | B label-dropped twins] in every buffer.
+// Wherever a fp16 GEMM operand is produced (embedding LayerNorm, the LayerNorms, attention output, GELU output), the conditional rows hold
+// fp16(x_c) and the unconditional rows the DIFFERENCE fp16(x_u - x_c); the pair GEMM (gemm_ht.hip, PAIR) adds the two products for the
+// unconditional outputs.  The fp32 residual stream, qkv and the logits hold ordinary values for both streams.  wmode: MX-fp4 correction
+// pass for the fp16 rounding of the QKV / FFN-up weights (conditional rows; the unconditional outputs inherit it through acc_c).
+int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, int B, bool wmode, hipStream_t s) {
+  using namespace mb;
+  const mb_gen_cfg& c = g->c;
+  const int d = c.hidden, f = c.mlp, N = g->N, nb = 2 * B, M = nb * N, P = B * N;
+  g_prof.next_forward();
+  int rc = 0;
+  uint8_t* const x4 = wmode ? g->x4 : nullptr;
+  uint8_t* const x4s = wmode ? g->x4s : nullptr;
+  auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo) {
+    GemmArgs ga{A, W, bias, res, res, out16, M, Nout, K, 0, 0, nullptr};
+    ga.pair_rows = P;
+    if (lo) { ga.K = K + K / 4; ga.kw = K; ga.A4 = g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4los[widx]; }
+    return ga;
+  };
+  {
+    ProfScope p("embed_ln", s, true);
+    EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
+                g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
+    embed_ln(s, e);
+    rc |= pairify_rows(s, g->y_f32, g->x_h16, P, d, x4, x4s);          // y_f32 holds the embedding LayerNorm's fp32 rows here
+  }
+  for (int l = 0; l < c.depth; ++l) {
+    const mb_gen::Layer& L = g->layers[l];
+    { ProfScope p("gemm_qkv", s, true);
+      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wmode);
+      rc |= gemm_tn(s, EPI_H16, ga, 257); }
+    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads); }
+    { ProfScope p("gemm_attn_out", s, true);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, false);
+      if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
+      rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
+    { ProfScope p("layernorm", s, true); rc |= layernorm_pair(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_h16, g->ln_stats, P, d, x4, x4s); }
+    { ProfScope p("gemm_ffn_up", s, true);
+      GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, wmode);
+      rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
+    { ProfScope p("gemm_ffn_down", s, true);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, false);
+      ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
+      rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
+    { ProfScope p("layernorm", s, true);
+      if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi + lo rows
+      else rc |= layernorm_pair(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_h16, g->ln_stats, P, d, x4, x4s); }
+  }
+  { ProfScope p("gemm_head", s, true);
+    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 2 * d, 0, 0, nullptr};
+    ga.A2 = g->x_lo; ga.kw = d;
+    rc |= gemm_tn(s, EPI_GELU_F32, ga); }
+  { ProfScope p("layernorm", s, true);
+    layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
+  { ProfScope p("gemm_head", s, true);
+    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, 2 * d, N, 0, nullptr};
+    ga.A2 = g->x_lo; ga.kw = d;
+    ga.bias_per_pos = c.embed_tables;
+    rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  if (rc) return fail(-3, "differential CFG forward: a kernel refused the shape (%d pairs x %d tokens, hidden %d, mlp %d)", B, N, d, f);
+  return 0;
+}
+
 // The kernels index with 32-bit element / byte offsets (rows * mlp * 4 < 2^32): forwards over more sequences than that allows run as
 // independent chunks (sequences never interact), which also bounds the workspace of very large batches.
 int gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, int nb, hipStream_t s,
@@ -259,6 +334,33 @@ int gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const u
     const int nc = nb - b0 < chunk ? nb - b0 : chunk;
     int rc = gen_forward_impl(g, tokens + (size_t)b0 * P, labels + b0, drop ? drop + b0 : nullptr, logits + (size_t)b0 * P * g->C, nc, s);
     if (rc) return rc;
+  }
+  return 0;
+}
+
+// Guided forward (sampling.py:83-88) over B samples: logits rows [0, B) conditional, [B, 2B) label-dropped.
+int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, hipStream_t s) {
+  const size_t P = (size_t)g->c.seq * g->c.splits;
+  const bool pair = g->pair_ok && g->c.cfg_pair > 0;
+  const bool wmode = pair && g->c.cfg_pair == 2 && scale >= 0.f && scale < 1.0f;      // weight rounding dominates while (1+s)^2 + s^2 is small
+  const int chunk = g->chunk_seqs / 2;                  // pairs per pass
+  if (chunk < 1) return fail(-1, "engine holds %d sequences: too few for a guided forward", g->chunk_seqs);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nc = B - b0 < chunk ? B - b0 : chunk;
+    HIP_TRY(hipMemcpyAsync(g->tok_cfg, tokens + (size_t)b0 * P, nc * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->tok_cfg + nc * P, tokens + (size_t)b0 * P, nc * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->lab_cfg, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->lab_cfg + nc, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(g->drop_cfg, 0, nc, s));
+    HIP_TRY(hipMemsetAsync(g->drop_cfg + nc, 1, nc, s));
+    float* out = (nc == B) ? logits : g->logits_tmp;    // chunked: through a buffer of the engine's own, then to the two halves of the caller's
+    int rc = pair ? gen_forward_pair_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, out, nc, wmode, s)
+                  : gen_forward_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, out, 2 * nc, s);
+    if (rc) return rc;
+    if (nc != B) {
+      HIP_TRY(hipMemcpyAsync(logits + (size_t)b0 * P * g->C, out, nc * P * g->C * sizeof(float), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(logits + (size_t)(B + b0) * P * g->C, out + (size_t)nc * P * g->C, nc * P * g->C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
   }
   return 0;
 }
@@ -305,6 +407,19 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period, ka, scale, ln_stats, ln_g, ln_b};
   ProfScope p("gemm_diag", (hipStream_t)stream);
   if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+int mb_gemm_pair(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
+                 int pair_rows, int N, int kw, const void* A4, const void* a_scale, const void* W4, const void* w_scale, mb_stream stream) {
+  if (!A || !W || !bias || epi < 0 || epi > 2 || pair_rows <= 0 || kw <= 0 || kw % 64) return fail(-1, "mb_gemm_pair: bad arguments");
+  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, 2 * pair_rows, N, kw, 0, 0, nullptr};
+  a.pair_rows = pair_rows;
+  if (A4) { a.K = kw + kw / 4; a.kw = kw; a.A4 = (const uint8_t*)A4; a.a_scale = (const uint8_t*)a_scale; a.W4 = (const uint8_t*)W4; a.w_scale = (const uint8_t*)w_scale; }
+  if (!mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_pair: shape not supported by the pair tiles");
+  ProfScope p("gemm_diag", (hipStream_t)stream);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, 257)) return fail(-3, "mb_gemm_pair: shape refused");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -402,6 +517,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (c.act_split >= 3 && (c.hidden % 256 || c.mlp % 256)) return fail(-1, "act_split = 3 / 4 (8- / 4-bit lo pass) needs hidden and mlp to be multiples of 256");
   if (c.act_split == 4 && c.hidden != 768 && c.hidden != 1024) return fail(-1, "act_split = 4 (MX-fp4 lo pass) is built for hidden = 768 or 1024");
   if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
+  if (c.cfg_pair < 0 || c.cfg_pair > 2) return fail(-1, "cfg_pair must be 0, 1 or 2");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
@@ -450,10 +566,26 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
     }
   }
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
+  // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
+  g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && !c.prenorm && !c.act_split && !c.weight_split &&
+               g->chunk_seqs >= 2;
+  if (g->pair_ok) {
+    rc |= galloc(g, &g->att_aux, (M / 2) * d);
+    if (c.cfg_pair == 2) {
+      rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, M + 256);
+      if (!rc) { (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, M + 256); }
+      g->w4lo.assign((size_t)4 * c.depth, nullptr); g->w4los.assign((size_t)4 * c.depth, nullptr);
+      for (int l = 0; l < c.depth; ++l) {
+        rc |= galloc(g, &g->w4lo[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4los[4 * l], 3 * d);
+        rc |= galloc(g, &g->w4lo[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4los[4 * l + 2], f);
+      }
+    }
+  }
   const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
   rc |= galloc(g, &g->tok_a, B * P); rc |= galloc(g, &g->tok_b, B * P); rc |= galloc(g, &g->tok_cfg, B * P);
   rc |= galloc(g, &g->pred, B * P); rc |= galloc(g, &g->codes, B * c.seq);
   rc |= galloc(g, &g->lab_cfg, B); rc |= galloc(g, &g->drop_cfg, B); rc |= galloc(g, &g->logits, B * P * C);
+  if (g->chunk_seqs < max_seqs) rc |= galloc(g, &g->logits_tmp, (size_t)g->chunk_seqs * P * C);
   if (rc) { mb_gen_destroy(g); return rc; }
   *out = g;
   return 0;
@@ -537,6 +669,7 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   else if (dst_h && g->split) mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
   else if (dst_h) {
     mb::cast_f32_to_h16(s, data, dst_h, numel);
+    if (g->pair_ok && c.cfg_pair == 2 && sidx >= 0 && sidx < 4 * c.depth && g->w4lo[sidx]) mb::w4lo_from_f32(s, data, g->w4lo[sidx], wrows, wcols, g->w4los[sidx]);
     if (c.act_split >= 3 && sidx >= 0 && sidx < 4 * c.depth) {
       if (g->w4[sidx]) mb::w4_from_f32(s, data, g->w4[sidx], wrows, wcols, g->w4s[sidx]);
       else mb::w8_from_f32(s, data, g->w8[sidx], wrows, wcols, g->w8_exp + sidx, g->split_tmp);
@@ -552,6 +685,12 @@ int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, cons
   if (!g || !tokens || !labels || !logits) return fail(-1, "mb_gen_forward: null argument");
   if (nb <= 0 || nb > g->max_seqs) return fail(-1, "mb_gen_forward: nb=%d outside [1, %d]", nb, g->max_seqs);
   return gen_forward(g, tokens, labels, drop, logits, nb, (hipStream_t)stream);
+}
+
+int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, mb_stream stream) {
+  if (!g || !tokens || !labels || !logits) return fail(-1, "mb_gen_forward_cfg: null argument");
+  if (B <= 0 || 2 * B > g->max_seqs) return fail(-1, "mb_gen_forward_cfg: B=%d needs %d sequences, engine holds %d", B, 2 * B, g->max_seqs);
+  return gen_forward_cfg(g, tokens, labels, logits, B, scale, (hipStream_t)stream);
 }
 
 int mb_gen_forward_attn(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, float* attn,
@@ -637,12 +776,6 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
   const size_t P = (size_t)n * m;
   // state init (sampling.py:65-71): every position masked; CFG batch = [cond | label-dropped]
   mb::fill_i64(s, g->tok_a, (int64_t)C, (size_t)B * P);
-  if (plan->use_guidance) {
-    HIP_TRY(hipMemcpyAsync(g->lab_cfg, labels, B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(g->lab_cfg + B, labels, B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(g->drop_cfg, 0, B, s));
-    HIP_TRY(hipMemsetAsync(g->drop_cfg + B, 1, B, s));
-  }
   int64_t* cur = g->tok_a;
   int64_t* nxt = g->tok_b;
   int64_t* last_pred = g->pred;
@@ -651,9 +784,7 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
     const float* lu = nullptr;
     int rc;
     if (plan->use_guidance) {
-      HIP_TRY(hipMemcpyAsync(g->tok_cfg, cur, B * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-      HIP_TRY(hipMemcpyAsync(g->tok_cfg + B * P, cur, B * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-      rc = gen_forward(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, g->logits, 2 * B, s);
+      rc = gen_forward_cfg(g, cur, labels, g->logits, B, plan->scale[i], s);
       lu = g->logits + (size_t)B * P * C;
     } else {
       rc = gen_forward(g, cur, labels, nullptr, g->logits, B, s);

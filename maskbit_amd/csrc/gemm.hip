@@ -147,7 +147,7 @@ int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
     gemm_ht(s, epi, a, variant);
     return 0;
   }
-  if (a.A8 || a.A4) return -1;
+  if (a.A8 || a.A4 || a.pair_rows) return -1;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles), block(256);
   switch (epi) {
@@ -238,6 +238,26 @@ __global__ __launch_bounds__(256) void w4_kernel(const float* __restrict__ W, ui
   }
 }
 
+// e2m1 copy of a weight's fp16 rounding error (one workgroup per row), for the weight-correction pass of the differential CFG forward
+__global__ __launch_bounds__(256) void w4lo_kernel(const float* __restrict__ W, uint8_t* __restrict__ out, int N, int K, uint8_t* __restrict__ scale_out) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* w = W + (size_t)n * K;
+  float mx = 0.f;
+  for (int k = tid; k < K; k += 256) mx = fmaxf(mx, fabsf(w[k] - (float)(h16)w[k]));
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float mul = fp4_scale_mul(mx);
+  if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)fp4_scale_byte(mx);
+  uint8_t* o = out + (size_t)n * 2 * K;
+  for (int k = tid * 4; k < K; k += 1024) {
+    const float4 v = *(const float4*)(w + k);
+    *(uint16_t*)(o + k / 2) = (uint16_t)fp4_pack4(v.x - (float)(h16)v.x, v.y - (float)(h16)v.y, v.z - (float)(h16)v.z, v.w - (float)(h16)v.w, mul);
+  }
+}
+
 // ---- split-weight repack ----------------------------------------------------------------------
 __global__ void absmax_kernel(const float* __restrict__ src, size_t n, unsigned* __restrict__ out) {
   float m = 0.f;
@@ -271,6 +291,10 @@ void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K,
 void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out) {
   (void)hipMemsetAsync(dst4, 0, 2 * (size_t)N * K, s);
   hipLaunchKernelGGL(w4_kernel, dim3(N), dim3(256), 0, s, src, dst4, N, K, scale_out);
+}
+void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out) {
+  (void)hipMemsetAsync(dst4, 0, 2 * (size_t)N * K, s);
+  hipLaunchKernelGGL(w4lo_kernel, dim3(N), dim3(256), 0, s, src, dst4, N, K, scale_out);
 }
 void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp) {
   const size_t n = (size_t)N * K;

@@ -58,9 +58,17 @@ __device__ __forceinline__ f32x4 mma_f4(f32x4 c, const h16x16& w, const h16x16& 
 // 4 n-tiles are split between the two wave rows (wm = 0 takes the B0 half in phase 0, wm = 1 the B1 half in phase 1:
 // +4 MFMAs per wave per K-tile).  The extra row lives in a 1 KiB "X" buffer per parity, re-filled by one extra DMA
 // instruction of wave 7 in phase 3.  tiles = nb * N/256: whole CU rounds for nb = 128.
-template <int MT, int EPI, int XP = 0, bool SEQ = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass
+// PAIR = true (with SEQ): "CFG pair" tiles for the differential form of classifier-free guidance (DESIGN.md "Precision").  The M rows are
+// a.pair_rows conditional rows followed by a.pair_rows unconditional rows (whole 257-token sequences); in A the unconditional rows hold
+// the DIFFERENCE operand fp16(x_u - x_c).  A tile covers 128 tokens of one sequence pair: the A0 half-tile = their conditional rows, the A1
+// half-tile = their difference rows, so one lane ends up with acc_c (m-tiles 0..3) and acc_delta (m-tiles 4..7) of the SAME tokens and the
+// epilogue emits out_c = f(acc_c), out_u = f(acc_c + acc_delta): the rounding error of the conditional operand is common to both
+// streams and cancels in (c - u), which is what the guidance scale multiplies.  The class-token m-tile carries two rows (lane rows 0 / 1 =
+// class row of c / its difference row); both tiles of a sequence pair compute it, the second one stores it.
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
+  static_assert(!PAIR || (SEQ && XP != 4), "pair tiles are sequence-aligned (fp16 or fp4 lo pass)");
   // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
   // inside the K loop): those GEMMs run one tile per workgroup, everything else walks the tile list persistently.
   constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4 && XP != 5;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
@@ -99,6 +107,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     uint32_t offA[2][2], offB[2][2], offX;   // element offsets into A / W
     int d8;                                  // PERM: added to offA / offB for e4m3 K-tiles (permuted source chunk)
     int m0, n0;
+    int cls;                                 // PAIR: the conditional class-token row of this tile's sequence pair; odd tiles store it
+    int q;                                   // PAIR: which 128-token half of the sequence this tile covers
   };
   int dstA[2], dstB[2];                       // byte offset of the instruction inside its half-tile buffer
 #pragma unroll
@@ -111,7 +121,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int rows_sr = min(8, tiles_m - sr * 8);
     const int rem = L - sr * 8 * tiles_n;
     const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
-    p.m0 = tm * TILE_ROWS; p.n0 = tn * 256;
+    p.m0 = PAIR ? (tm >> 1) * 257 + (tm & 1) * 128 : tm * TILE_ROWS; p.n0 = tn * 256;
+    p.cls = PAIR ? (tm >> 1) * 257 + 256 : 0; p.q = tm & 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ja = min(wave + 8 * j, A_INSTR - 1);   // surplus slot re-loads the last chunk (uniform vmcnt)
@@ -123,14 +134,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       const int slot_b = (lane_o & 7) ^ ((hrb >> 1) & 7);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int gm = min(p.m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
+        const int gm = PAIR ? p.m0 + h * a.pair_rows + hra : min(p.m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
         p.offA[h][j] = (uint32_t)gm * (uint32_t)KA + slot_a * 8;
         const int gn = min(p.n0 + wns * 64 + h * 32 + c, a.N - 1);
         p.offB[h][j] = (uint32_t)gn * (uint32_t)KW + slot_b * 8;
       }
     }
     // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
-    p.offX = (uint32_t)min(p.m0 + 256, a.M - 1) * (uint32_t)KA + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
+    p.offX = (uint32_t)(PAIR ? p.cls + ((lane_o >> 3) == 1 ? a.pair_rows : 0) : min(p.m0 + 256, a.M - 1)) * (uint32_t)KA + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
     if (PERM) {
       const int ra = wave * 8 + (lane_o >> 3);                           // row of instruction j = 0 inside its half-tile (A and B alike)
       const int qa = (lane_o & 7) ^ ((ra >> 1) & 7);
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       // one per-lane offset + a uniform (h * 64 + j * 128) * KA (6 VGPRs less than a table; used where VGPRs are the limit: the e4m3 kernels)
       uint32_t o = (SEQ && LO) ? p.offA[0][0] + ((PERM && t >= nka) ? p.d8 : 0) : p.offA[h][j];
       if (LO) asm volatile("" : "+v"(o));               // keeps the 64-bit address arithmetic at the use (it was hoisted out of the two K loops and spilled)
-      const uint32_t u = (SEQ && LO) ? (uint32_t)(h * 64 + j * 128) * (uint32_t)KA : 0u;
+      const uint32_t u = (SEQ && LO) ? (uint32_t)(PAIR ? h * a.pair_rows + j * 64 : h * 64 + j * 128) * (uint32_t)KA : 0u;
       MB_GLDS16_AUX((t < nka ? a.A : Alo) + u + o + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
     }
   };
@@ -174,13 +185,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 
   // ---- fragment read offsets inside a half-tile (rows 128 B, slot swizzled with (row>>1)&7)
   int foff[2], xoffe[2];
-  const int xadd = l15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES : 0;   // F8 kernels: xoffe[ks] == foff[ks] + xadd (lane row 0's foff is its slot offset), one VGPR less
+  // F8 kernels: xoffe[ks] == foff[ks] + xadd (lane row 0's foff is its slot offset), one VGPR less.  PAIR: lane row 1 reads X row 1 (the
+  // class row's difference operand): foff of lane row 1 = 128 + slot offset = its X-row offset as well
+  const int xadd = (l15 == 0 || (PAIR && l15 == 1)) ? 2 * AH_BYTES + 2 * BH_BYTES : 0;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     foff[ks] = l15 * 128 + (((ks * 4 + g) ^ (l15 >> 1)) * 16);
     // class row: only lane row 0 feeds a result that is kept, so the other 15 lane rows read their usual (conflict-free)
     // A-fragment addresses instead of the X buffer -- 16 lanes on the 8 X rows was a 2-way bank conflict on every read
-    xoffe[ks] = l15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + (ks * 4 + g) * 16 : foff[ks];
+    xoffe[ks] = (l15 == 0 || (PAIR && l15 == 1)) ? 2 * AH_BYTES + 2 * BH_BYTES + foff[ks] : foff[ks];
   }
   // e4m3 K-tile of 128: lane group g owns K bytes 32g .. 32g+31 of its row = slots 2g and 2g+1 (tools/micro/mfma_f8_probe.hip); the F8
   // kernels recompute their fragment offsets per K-tile instead of holding a second set in registers
@@ -250,10 +263,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     int lo_ = lane; asm volatile("" : "+v"(lo_));
     const int r15 = lo_ & 15;
     wsc = ((const int*)a.w_scale)[((cur.n0 >> 6) + wn) * 16 + r15];
-    const uint8_t* sp = a.a_scale + cur.m0 + wm * (16 * MT) + r15;
+    if (PAIR) {
+      const uint8_t* sp = a.a_scale + cur.m0 + wm * 64 + r15;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sb[i] = sp[min((i >> 2) * (8 * MT) + (i & 3) * 16, a.M - 1 - (cur.m0 + wm * (16 * MT) + r15))];   // rows past M (ragged last tile) re-read row M-1
-    if (SEQ) xscc = a.a_scale[cur.m0 + 256];
+      for (int i = 0; i < 8; ++i) sb[i] = sp[(i >> 2) * a.pair_rows + (i & 3) * 16];
+      xscc = a.a_scale[cur.cls + (r15 == 1 ? a.pair_rows : 0)];
+    } else {
+      const uint8_t* sp = a.a_scale + cur.m0 + wm * (16 * MT) + r15;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sb[i] = sp[min((i >> 2) * (8 * MT) + (i & 3) * 16, a.M - 1 - (cur.m0 + wm * (16 * MT) + r15))];   // rows past M (ragged last tile) re-read row M-1
+      if (SEQ) xscc = a.a_scale[cur.m0 + 256];
+    }
   }
   prologue(cur);
   if constexpr (F4) {
@@ -351,16 +371,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const float* __restrict__ resp = a.residual;
     float* __restrict__ out32 = a.out_f32;
     h16* __restrict__ out16 = a.out_h16;
-    const int m0 = cur.m0, n0 = cur.n0;
+    const int m0 = cur.m0, n0 = cur.n0, clsrow = cur.cls, tq = cur.q;
     constexpr int NROWS = SEQ ? MT + 1 : MT;
     int l15e = l15, ge = g;                              // opaque copies (see make_plan): no per-row address tables
     if (LO) { int lo_ = lane; asm volatile("" : "+v"(lo_)); l15e = lo_ & 15; ge = lo_ >> 4; }   // (recomputed: l15 / g need not live through the K loops)
     asm volatile("" : "+v"(l15e), "+v"(ge));             // carried in VGPRs through the main loop
-    auto row_of = [&](int r) { return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256; };
+    auto row_of = [&](int r) {
+      if (PAIR) return r < MT ? m0 + (r / MH) * a.pair_rows + wm * 64 + (r % MH) * 16 + l15e : clsrow + (l15e == 1 ? a.pair_rows : 0);
+      return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256;
+    };
     auto col_of = [&](int r, int nt) {
       return r < MT ? n0 + wn * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + ge * 4 : n0 + wn * 64 + wm * 32 + nt * 16 + ge * 4;
     };
-    auto row_ok = [&](int r) { return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : l15e == 0; };
+    auto row_ok = [&](int r) {
+      if (PAIR) return r < MT ? true : (l15e < 2 && tq == 1);
+      return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : l15e == 0;
+    };
     // ---- next tile: start its first two K-tiles NOW (all LDS is free), so they fly during the epilogue math.
     // The bias of THIS tile is fetched in between by inline-asm loads the compiler does not track: vmcnt retires in
     // order, so one counted wait for "everything but the 16 DMA instructions issued after them" releases the bias
@@ -403,7 +429,36 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     // Pass 1 (arithmetic, in place): + bias (+ residual, fetched one m-tile ahead of its use) (+ GELU).
     // Pass 2 (after the DMA wait): stores; fp16 results of two neighbouring n-tiles are exchanged between lane
     // rows g and g^1 with v_permlane16_swap so that a lane stores 8 consecutive columns (16 B; the tail is issue-bound).
-    {
+    if constexpr (PAIR) {
+      // pair tiles: m-tiles 0..MH-1 hold acc_c, MH..MT-1 acc_delta of the same tokens -> (v_c, v_u = v_c + delta) or, with GELU, (h_c, h_u - h_c)
+      const float osc = a.scale ? *a.scale : 1.0f;
+      auto pair2 = [&](f32x4& c, f32x4& dl, const f32x4& b) {
+        f32x4 vc = __builtin_elementwise_fma(c, (f32x4)(osc), b);
+        f32x4 vu = __builtin_elementwise_fma(dl, (f32x4)(osc), vc);
+        if (EPI == EPI_GELU_H16 || EPI == EPI_GELU_F32) {
+          const f32x2 c0 = gelu_erf2((f32x2){vc[0], vc[1]}), c1 = gelu_erf2((f32x2){vc[2], vc[3]});
+          const f32x2 u0 = gelu_erf2((f32x2){vu[0], vu[1]}), u1 = gelu_erf2((f32x2){vu[2], vu[3]});
+          vc = f32x4{c0.x, c0.y, c1.x, c1.y};
+          vu = f32x4{u0.x - c0.x, u0.y - c0.y, u1.x - c1.x, u1.y - c1.y};
+        }
+        c = vc; dl = vu;
+        asm volatile("" : "+v"(c), "+v"(dl));
+      };
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) pair2(acc[nt][i], acc[nt][i + MH], bias4[nt]);
+      // class rows: lane row 0 = acc_c, lane row 1 = acc_delta of the same 4 features (the lane above in the same lane group)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        f32x4 cup;                                             // the conditional accumulator, as seen by lane row 1
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cup[e] = __shfl_up(acce[n][e], 1);
+        f32x4 c = l15e == 1 ? cup : acce[n], dl = l15e == 1 ? acce[n] : f32x4{0.f, 0.f, 0.f, 0.f};
+        pair2(c, dl, bcls[n]);
+        acce[n] = l15e == 1 ? dl : c;
+      }
+    } else {
       const float osc = a.scale ? *a.scale : 1.0f;          // split weights: undo their power-of-two pre-scale
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
@@ -540,22 +595,23 @@ static int num_cu_cached() {
   return num_cu;
 }
 
-template <int MT, int EPI, int XP = 0, bool SEQ = false>
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>
 static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) {
   constexpr int BM = 32 * MT;
   constexpr int LDS = 2 * (BM * 128 + 2 * 128 * 128 + (SEQ ? 1024 : 0));
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     configured = true;
   }
-  const int tiles_m = SEQ ? a.M / 257 : (a.M + BM - 1) / BM, tiles_n = a.N / 256;
+  const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = a.N / 256;
   const int grid = (EPI != EPI_RES_F32 && XP != 4 && XP != 5 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
-  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
+  if (a.pair_rows && (a.pair_rows % 257 || a.M != 2 * a.pair_rows || a.A8 || a.A2 || a.ka || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
   if (a.A4 && (a.A8 || !a.W4 || !a.a_scale || !a.w_scale || a.kw % 256 || a.K != a.kw + a.kw / 4 || epi == EPI_GELU_F32)) return false;
   return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8 || a.A4) &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
@@ -577,6 +633,15 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
       const long tiles = (long)(a.M / 257) * (a.N / 256);
       if ((double)((tiles + num_cu - 1) / num_cu) * 272 < cost(mt)) mt = 257;
     }
+  }
+  if (a.pair_rows) {                                                       // CFG pair tiles (sequence-aligned; fp16, or fp16 + MX-fp4 lo pass)
+    switch (epi) {
+      case EPI_H16: if (a.A4) launch_ht<8, EPI_H16, 5, true, true>(s, a, persistent); else launch_ht<8, EPI_H16, 0, true, true>(s, a, persistent); break;
+      case EPI_GELU_H16: if (a.A4) launch_ht<8, EPI_GELU_H16, 5, true, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 0, true, true>(s, a, persistent); break;
+      case EPI_RES_F32: if (a.A4) launch_ht<8, EPI_RES_F32, 5, true, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 0, true, true>(s, a, persistent); break;
+      default: break;
+    }
+    return;
   }
   if (a.A4) {                                                              // MX-fp4 lo pass (XP = 5 instantiations)
     const bool seq = a.M % 257 == 0 && mt != 8;

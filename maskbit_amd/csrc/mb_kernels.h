@@ -62,6 +62,11 @@ struct GemmArgs {
   const uint8_t* W4 = nullptr;
   const uint8_t* a_scale = nullptr;
   const uint8_t* w_scale = nullptr;
+  // "CFG pair" GEMM (sequence-aligned half-tile kernel only): the M = 2 * pair_rows rows are pair_rows conditional rows followed by their
+  // unconditional twins (whole 257-token sequences); in A the unconditional rows hold the difference operand fp16(x_u - x_c).  Output
+  // rows: out_c = f(A_c . W), out_u = f(A_c . W + A_delta . W) -- with the GELU epilogue the unconditional rows receive gelu(u) - gelu(c),
+  // i.e. the next GEMM's difference operand.  See gemm_ht.hip and DESIGN.md "Precision".
+  int pair_rows = 0;
 };
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   // 0, or -1: lo-pass request outside the half-tile kernel's shapes
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -72,11 +77,19 @@ void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, i
 // e2m1 copy of a weight for the fp4 correction pass: dst4[n][2K bytes] (first K/2 used) = e2m1(fp16(W[n]) * 2^r_n), r_n per row chosen to
 // minimise the row's quantisation error; scale_out in the kernel's lane order (GemmArgs.w_scale)
 void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);
+// the same layout for the weight's fp16 ROUNDING ERROR: e2m1((W[n] - fp16(W[n])) * 2^r_n), r_n from the row's largest |error| (fp4_scale_mul)
+void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
                     float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr, uint8_t* x8 = nullptr,
-                    uint8_t* x4 = nullptr, uint8_t* x4_scale = nullptr);   // x4: e2m1 lo halves (row stride 2d bytes) + one E8M0 byte per row   // x8: e4m3(lo * 2^15), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
+                    uint8_t* x4 = nullptr, uint8_t* x4_scale = nullptr, bool x4_values = false);   // x4: e2m1 lo halves -- or, x4_values, the values -- (row stride 2d bytes) + one E8M0 byte per row   // x8: e4m3(lo * 2^15), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
+
+// "CFG pair" forms (hidden = 768 / 1024 only; -1 otherwise): rows r < P are conditional, r + P their unconditional twins.  Writes
+// x_h16[r] = fp16(x_c), x_h16[r + P] = fp16(x_u - x_c), both rows' {mean, rstd}; optional x4 / x4s: e2m1 of the conditional VALUES + scale bytes.
+int layernorm_pair(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps, h16* x_h16, float* stats, int P, int d,
+                   uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
+int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
 
 // ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------
 struct EmbedArgs {
@@ -96,12 +109,17 @@ struct EmbedArgs {
   uint8_t* x8 = nullptr;   // optional: e4m3 lo halves, row stride 2d bytes
   uint8_t* x4 = nullptr;   // optional: e2m1 lo halves (row stride 2d bytes) with one E8M0 scale byte per row in x4_scale
   uint8_t* x4_scale = nullptr;
+  bool x4_values = false;  // x4 = e2m1 of the values instead of the lo halves
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
 void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo = nullptr, uint8_t* out_lo8 = nullptr);   // out_lo: optional lo halves (split activations)
+// "CFG pair" attention: sequences [0, P) are conditional, [P, 2P) their unconditional twins.  Two launches: the conditional sequences also
+// store their fp32 output rows to `aux` [P*N, d]; the unconditional ones then write out[r + P*N] = fp16(att_u - att_c) (difference operand of
+// the out-proj pair GEMM).  Short-sequence kernel only (N <= 288): returns -1 otherwise.
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads);
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 

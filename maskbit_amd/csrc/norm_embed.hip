@@ -16,7 +16,8 @@ template <int NV>
 __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                           float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr, uint8_t* x8 = nullptr,
-                                          uint8_t* x4 = nullptr, uint8_t* x4s = nullptr) {
+                                          uint8_t* x4 = nullptr, uint8_t* x4s = nullptr, bool x4_values = false) {
+  // x4: e2m1 of the row's lo halves (act_split 4), or with x4_values of the VALUES themselves (operand of the weight-rounding correction pass)
   // xl (optional): the fp16 lo halves o - fp16(o) of the same row, for the split-activation GEMMs
   constexpr bool VEC = NV > 0;
   constexpr int nv = NV;
@@ -54,7 +55,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
       if (xl) *(h16x4*)(xl + c) = h16x4{to_h(o.x - (float)hi[0]), to_h(o.y - (float)hi[1]), to_h(o.z - (float)hi[2]), to_h(o.w - (float)hi[3])};
       if (x8) *(uint32_t*)(x8 + c) = lo8_pack4h(o.x, o.y, o.z, o.w, hi);
       if (x4) {                                                       // keep the lo halves in the row's registers for the second sweep
-        v[q] = make_float4(o.x - (float)hi[0], o.y - (float)hi[1], o.z - (float)hi[2], o.w - (float)hi[3]);
+        v[q] = x4_values ? o : make_float4(o.x - (float)hi[0], o.y - (float)hi[1], o.z - (float)hi[2], o.w - (float)hi[3]);
         maxlo = fmaxf(maxlo, fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w))));
       }
     }
@@ -82,7 +83,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* x_f32,
-                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s) {
+                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s, bool x4v) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -98,15 +99,107 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
                  x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr,
                  x_lo ? x_lo + (size_t)row * d : nullptr, x8 ? x8 + (size_t)row * 2 * d : nullptr,
-                 x4 ? x4 + (size_t)row * 2 * d : nullptr, x4s ? x4s + row : nullptr);
+                 x4 ? x4 + (size_t)row * 2 * d : nullptr, x4s ? x4s + row : nullptr, x4v);
+}
+
+// ---- "CFG pair" LayerNorm (differential classifier-free guidance, DESIGN.md "Precision"): one wave normalises row r of the conditional
+// stream and its unconditional twin r + P together and writes  x_h16[r] = fp16(x_c),  x_h16[r + P] = fp16(x_u - x_c)  -- the operands of
+// the pair GEMM (gemm_ht.hip): the rounding error of x_c is then common to both streams and cancels in (c - u).  Row statistics of both rows
+// go to `stats` (the residual GEMMs re-derive LayerNorm(y) from them).  x4 / x4s (optional, "W mode"): e2m1(x_c * 2^s) of the conditional row
+// with its E8M0 scale byte (the unconditional row's byte is 0: its products vanish) for the weight-rounding correction pass.
+template <int NV>
+__device__ __forceinline__ float2 ln_normalize(float4* v, int d, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const float a = v[q].x - mean, b = v[q].y - mean, c = v[q].z - mean, e = v[q].w - mean;
+    ss += (a * a + b * b) + (c * c + e * e);
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = q * 256 + lane * 4;
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    v[q] = make_float4(ln_affine(v[q].x, mean, rstd, g.x, b.x), ln_affine(v[q].y, mean, rstd, g.y, b.y),
+                       ln_affine(v[q].z, mean, rstd, g.z, b.z), ln_affine(v[q].w, mean, rstd, g.w, b.w));
+  }
+  return make_float2(mean, rstd);
+}
+
+// store the pair operands of one row pair held in registers (xc, xu = the two fp32 rows)
+template <int NV>
+__device__ __forceinline__ void pair_store(const float4* xc, const float4* xu, int lane, h16* oc, h16* ou, uint8_t* x4, uint8_t* x4s_c, uint8_t* x4s_u) {
+  float amax = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = q * 256 + lane * 4;
+    *(h16x4*)(oc + c) = h16x4{to_h(xc[q].x), to_h(xc[q].y), to_h(xc[q].z), to_h(xc[q].w)};
+    *(h16x4*)(ou + c) = h16x4{to_h(xu[q].x - xc[q].x), to_h(xu[q].y - xc[q].y), to_h(xu[q].z - xc[q].z), to_h(xu[q].w - xc[q].w)};
+    if (x4) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(xc[q].x), fabsf(xc[q].y)), fmaxf(fabsf(xc[q].z), fabsf(xc[q].w))));
+  }
+  if (x4) {
+    amax = wave_max(amax);
+    const float mul = fp4_scale_mul(amax);
+    if (lane == 0) { *x4s_c = (uint8_t)fp4_scale_byte(amax); *x4s_u = 0; }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) *(uint16_t*)(x4 + q * 128 + lane * 2) = (uint16_t)fp4_pack4(xc[q].x, xc[q].y, xc[q].z, xc[q].w, mul);
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_pair_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                      h16* __restrict__ x_h16, float* __restrict__ stats, int P, int d, uint8_t* x4, uint8_t* x4s) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= P) return;
+  float4 vc[NV], vu[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) { vc[q] = *(const float4*)(y + (size_t)row * d + q * 256 + lane * 4); vu[q] = *(const float4*)(y + (size_t)(row + P) * d + q * 256 + lane * 4); }
+  const float2 sc = ln_normalize<NV>(vc, d, gamma, beta, eps, lane), su = ln_normalize<NV>(vu, d, gamma, beta, eps, lane);
+  if (stats && lane == 0) { *(float2*)(stats + 2 * (size_t)row) = sc; *(float2*)(stats + 2 * (size_t)(row + P)) = su; }
+  pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
+                 x4s ? x4s + row : nullptr, x4s ? x4s + row + P : nullptr);
+}
+
+// pair operands from fp32 rows that already exist (the embedding LayerNorm's output, the first residual): x32 [2P, d] -> x_h16 as above
+template <int NV>
+__global__ __launch_bounds__(256) void pairify_kernel(const float* __restrict__ x32, h16* __restrict__ x_h16, int P, int d, uint8_t* x4, uint8_t* x4s) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= P) return;
+  float4 vc[NV], vu[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) { vc[q] = *(const float4*)(x32 + (size_t)row * d + q * 256 + lane * 4); vu[q] = *(const float4*)(x32 + (size_t)(row + P) * d + q * 256 + lane * 4); }
+  pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
+                 x4s ? x4s + row : nullptr, x4s ? x4s + row + P : nullptr);
+}
+
+int layernorm_pair(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps, h16* x_h16, float* stats, int P, int d,
+                   uint8_t* x4, uint8_t* x4s) {
+  dim3 grid((P + 3) / 4), block(256);
+  if (d == 1024) hipLaunchKernelGGL(ln_pair_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_h16, stats, P, d, x4, x4s);
+  else if (d == 768) hipLaunchKernelGGL(ln_pair_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_h16, stats, P, d, x4, x4s);
+  else return -1;
+  return 0;
+}
+int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, uint8_t* x4, uint8_t* x4s) {
+  dim3 grid((P + 3) / 4), block(256);
+  if (d == 1024) hipLaunchKernelGGL(pairify_kernel<4>, grid, block, 0, s, x32, x_h16, P, d, x4, x4s);
+  else if (d == 768) hipLaunchKernelGGL(pairify_kernel<3>, grid, block, 0, s, x32, x_h16, P, d, x4, x4s);
+  else return -1;
+  return 0;
 }
 
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s) {
-  dim3 grid((M + 3) / 4), block(256);      // x4 (e2m1 lo halves): vector path only (d = 768 / 1024; mb_gen_create restricts the mode to those)
-  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s);
-  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s);
-  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, nullptr, nullptr);
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s, bool x4v) {
+  dim3 grid((M + 3) / 4), block(256);      // x4 (e2m1 lo halves / values): vector path only (d = 768 / 1024; mb_gen_create restricts the modes to those)
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s, x4v);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s, x4v);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, nullptr, nullptr, false);
 }
 
 // One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,
@@ -192,7 +285,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
   }
   ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d, nullptr,
                  a.x_lo ? a.x_lo + (size_t)row * d : nullptr, a.x8 ? a.x8 + (size_t)row * 2 * d : nullptr,
-                 a.x4 ? a.x4 + (size_t)row * 2 * d : nullptr, a.x4_scale ? a.x4_scale + row : nullptr);
+                 a.x4 ? a.x4 + (size_t)row * 2 * d : nullptr, a.x4_scale ? a.x4_scale + row : nullptr, a.x4_values);
 }
 
 void embed_ln(hipStream_t s, const EmbedArgs& a) {

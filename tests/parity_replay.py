@@ -97,14 +97,12 @@ def teacher_forced(gen, g=None, noise=None):
     scale, temp, mask_len = plan_of(g)
     S, B = g["steps"].shape[0], g["steps"].shape[1]
     y = g["labels"].to(dev)
-    yy = torch.cat([y, y])
-    dd = torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(dev)
     per_step, remask = [], 0
     total = 0
     for i in range(S):
         tin_cpu = tokens_in(g, i)
         tin = tin_cpu.to(dev).contiguous()
-        lg = gen(torch.cat([tin, tin]), yy, dd)
+        lg = gen.forward_cfg(tin, y, scale[i])                       # the guided forward of the loop (cond | label-dropped)
         lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
         tout, pred = torch.empty_like(tin), torch.empty_like(tin)
         _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr(), scale[i], temp[i], q[i].data_ptr(), c[i].data_ptr(), mask_len[i],

@@ -21,9 +21,9 @@ def _teacher_forced(cfg, sd, model, B, N, labels, seed, **kw):
     O.sample_loop(lambda t, yy, dd: O.lfq_bert_forward(sd, cfg, t, yy, dd), B, labels, num_steps=N, mask_token=C_,
                   codebook_splits=m, record=rec, **kw)
     if os.environ.get("MB_TEST_ALSO_FP16"):              # context: the single-fp16 mode on the same oracle run
-        model.act_split = 0
+        model.act_split, model.cfg_pair = 0, 0
         r0 = _replay(lib, _lib, cfg, model, rec, B, labels, kw)
-        model.act_split = -1
+        model.act_split, model.cfg_pair = -1, -1
         print(f"  [single fp16: mismatch {r0[0]:.2e} ({r0[2]}/{r0[3]}), mean |logit err| {r0[1]:.4f}]")
     r = _replay(lib, _lib, cfg, model, rec, B, labels, kw)
     print(f"  [default precision: {r[2]}/{r[3]} mismatches]")
@@ -39,7 +39,7 @@ def _replay(lib, _lib, cfg, model, rec, B, labels, kw):
     for i, r in enumerate(rec):
         tin = r.tokens_in.to(DEV).contiguous()
         if cfgd:
-            lg = model(torch.cat([tin, tin]), torch.cat([labels, labels]).to(DEV), drop)
+            lg = model.forward_cfg(tin, labels.to(DEV), r.scale)          # the guided forward of the loop
             lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
         else:
             lc, lu = model(tin, labels.to(DEV), torch.zeros(B, dtype=torch.bool, device=DEV)), None
@@ -144,7 +144,7 @@ def _full_length_run(bits, num_steps, B, kw, seed):
     stream = torch.cuda.current_stream().cuda_stream
     for i in range(num_steps):
         if gs != 0.0:
-            lg = model(torch.cat([tok, tok]), torch.cat([labels, labels]), drop)
+            lg = model.forward_cfg(tok, labels, plan[0][i])
             lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
         else:
             lc, lu = model(tok, labels, torch.zeros(B, dtype=torch.bool, device=DEV)), None

@@ -29,29 +29,30 @@ def test_fixture_is_the_documented_run(setup):
 def test_teacher_forced_mismatch_vs_reference_run(setup):
     """<= 1e-3 in the product default precision (the mode bench.py times); the single-fp16 mode is measured beside it for context."""
     g, gen, tok, noise = setup
-    gen.weight_split, gen.act_split = 0, -1
+    gen.weight_split, gen.act_split, gen.cfg_pair = 0, -1, -1
     bad, tot, per_step, remask = R.teacher_forced(gen, g, noise)
     print(f"product default: teacher-forced mismatch vs the reference's run {bad}/{tot} = {bad / tot:.2e}; re-mask differences {remask}; "
           f"per 8 steps {[sum(per_step[i:i + 8]) for i in range(0, 64, 8)]}")
     assert tot == 84284
     assert bad / tot <= 1e-3
-    gen.act_split = 0
+    gen.act_split, gen.cfg_pair = 0, 0
     bad0, _, per0, _ = R.teacher_forced(gen, g, noise)
     print(f"single fp16:     teacher-forced mismatch vs the reference's run {bad0}/{tot} = {bad0 / tot:.2e}; "
           f"per 8 steps {[sum(per0[i:i + 8]) for i in range(0, 64, 8)]}")
-    gen.act_split = -1
+    gen.act_split, gen.cfg_pair = -1, -1
     assert bad0 / tot < 3e-3 and bad <= bad0
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("level", [2, 3, 4])
-def test_every_strict_level_meets_the_bound(setup, level):
-    """act_split 2 (fp16 lo halves), 3 (e4m3 lo halves) and 4 (MX-fp4 lo halves for the LayerNorm outputs) against the reference's run."""
+@pytest.mark.parametrize("act,pair", [(2, 0), (3, 0), (4, 0), (0, 1), (0, 2)])
+def test_every_strict_mode_meets_the_bound(setup, act, pair):
+    """act_split 2 (fp16 lo halves), 3 (e4m3 lo halves), 4 (MX-fp4 lo halves for the LayerNorm outputs); cfg_pair 1 (differential CFG operands)
+    and 2 (+ MX-fp4 weight-rounding correction, the product default at this shape) against the reference's run."""
     g, gen, tok, noise = setup
-    gen.weight_split, gen.act_split = 0, level
+    gen.weight_split, gen.act_split, gen.cfg_pair = 0, act, pair
     bad, tot, per_step, _ = R.teacher_forced(gen, g, noise)
-    gen.act_split = -1
-    print(f"act_split = {level}: teacher-forced mismatch vs the reference's run {bad}/{tot} = {bad / tot:.2e}; "
+    gen.act_split, gen.cfg_pair = -1, -1
+    print(f"act_split = {act}, cfg_pair = {pair}: teacher-forced mismatch vs the reference's run {bad}/{tot} = {bad / tot:.2e}; "
           f"per 8 steps {[sum(per_step[i:i + 8]) for i in range(0, 64, 8)]}")
     assert bad / tot <= 1e-3
 
@@ -62,7 +63,7 @@ def test_free_running_64_steps_vs_reference_run(setup):
     that image, so the trajectories are compared statistically: the first step (same input for both) must agree to <= 2e-3, images
     whose final codes equal the reference's must decode to the reference's pixels, and the drift is reported."""
     g, gen, tok, noise = setup
-    gen.weight_split, gen.act_split = 0, -1
+    gen.weight_split, gen.act_split, gen.cfg_pair = 0, -1, -1
     r = R.free_running(gen, tok, g, noise)
     sm = r["step_mismatch"]
     print(f"free-running token mismatch vs the reference's run: step 0 {sm[0]:.2e}, step 15 {sm[15]:.2e}, step 31 {sm[31]:.2e}, "

@@ -1,0 +1,90 @@
+"""Differential classifier-free guidance (mb_gen_cfg.cfg_pair, DESIGN.md "Precision"): the pair GEMM, the pair LayerNorm / attention
+operands, and the guided forward against the CPU oracle.  The reference computes the guided logits as
+c + s (c - u) from one forward over [cond | uncond] (sampling.py:83-99); the engine carries the unconditional stream's fp16 GEMM operands
+as differences from the conditional stream's, so that operand rounding cancels in (c - u)."""
+import pytest
+import torch
+
+from hip_helpers import hip_generator
+from oracle import maskbit_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("epi,pairs,N,K", [(0, 2, 768, 256), (1, 3, 512, 1024), (2, 2, 256, 512), (2, 5, 1024, 1024)])
+def test_pair_gemm(epi, pairs, N, K):
+    """out_c = f(A_c.W^T + b), out_u = f((A_c + A_delta).W^T + b) with f = identity->fp16 / GELU (u rows: gelu(u) - gelu(c)) / + residual -> fp32,
+    against fp64 on the same fp16 operands: rows of whole 257-token sequences, class-token rows included."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(epi * 7 + pairs)
+    P = pairs * 257
+    xc = torch.randn(P, K, device=DEV) * 1.5
+    xu = xc + torch.randn(P, K, device=DEV) * 0.05
+    A = torch.cat([xc.half(), (xu - xc).half()])
+    W = (torch.randn(N, K, device=DEV) * 0.05).half()
+    bias = torch.randn(N, device=DEV) * 0.1
+    res = torch.randn(2 * P, N, device=DEV) if epi == 2 else None
+    out32 = res.clone() if epi == 2 else None                     # in place, as the engine's residual stream
+    out16 = torch.full((2 * P, N), float("nan"), device=DEV, dtype=torch.float16) if epi != 2 else None
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out32.data_ptr() if out32 is not None else None,
+                                out32.data_ptr() if out32 is not None else None, out16.data_ptr() if out16 is not None else None,
+                                P, N, K, None, None, None, None, st), "mb_gemm_pair")
+    torch.cuda.synchronize()
+    pc = A[:P].double() @ W.double().t() + bias.double()
+    pu = (A[:P].double() + A[P:].double()) @ W.double().t() + bias.double()
+    if epi == 1:
+        gc, gu = torch.nn.functional.gelu(pc), torch.nn.functional.gelu(pu)
+        want = torch.cat([gc, gu - gc])
+    elif epi == 2:
+        want = torch.cat([pc, pu]) + res.double()
+    else:
+        want = torch.cat([pc, pu])
+    got = (out32 if out32 is not None else out16).double()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    tol = 3e-5 if epi == 2 else 2e-3 * max(1.0, float(want.abs().max()))
+    assert float(err.max()) < tol, (float(err.max()), int(err.argmax()) // N, int(err.argmax()) % N)
+
+
+def _full12():
+    cfg = O.GenCfg(bits=12, splits=2)
+    sd = O.make_generator_weights(cfg, seed=100, head_gain=12.0)
+    return cfg, sd, hip_generator(cfg, sd)
+
+
+@pytest.mark.timeout(900)
+def test_guided_forward_full_size_vs_oracle():
+    """forward_cfg at full size (B = 3 pairs, masked / unmasked tokens): (a) with cfg_pair = 0 it IS the plain forward over [cond | uncond], bit for
+    bit; (b) in differential form (cfg_pair = 1, 2) both streams stay as close to the fp32 oracle as the plain fp16 forward does, and the
+    guided combination c + s (c - u) at s = 6 is several times closer -- the operand rounding no longer reaches (c - u)."""
+    cfg, sd, m = _full12()
+    g = torch.Generator().manual_seed(3)
+    t = torch.randint(0, 65, (3, 256, 2), generator=g)
+    y = torch.tensor([5, 321, 999])
+    drop = torch.cat([torch.zeros(3, dtype=torch.bool), torch.ones(3, dtype=torch.bool)])
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = O.lfq_bert_forward(sd, cfg, torch.cat([t, t]), torch.cat([y, y]), drop)
+    s = 6.0
+    guided = lambda lg: lg[:3] + s * (lg[:3] - lg[3:])
+    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0
+    plain = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV))
+    assert torch.equal(m.forward_cfg(t.to(DEV), y.to(DEV)), plain)
+    e_plain = float((guided(plain.cpu()) - guided(ref)).abs().mean())
+    for pair in (1, 2):
+        m.cfg_pair = pair
+        for scale in ((-1.0, 0.5) if pair == 2 else (-1.0,)):                       # cfg_pair 2: with and without the weight-correction pass
+            lg = m.forward_cfg(t.to(DEV), y.to(DEV), scale).cpu()
+            rel = float((lg - ref).norm() / ref.norm())
+            e_pair = float((guided(lg) - guided(ref)).abs().mean())
+            print(f"cfg_pair = {pair}, scale hint {scale}: rel-Frobenius logit error {rel:.2e}; mean |guided logit error| {e_pair:.4f} (plain fp16 forward: {e_plain:.4f})")
+            assert rel < 2e-3 and e_pair < 0.6 * e_plain
+    # the plain forward() of a cfg_pair = 2 engine carries the weight-correction pass: closer to the oracle than single fp16
+    m.cfg_pair = 2
+    w = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV)).cpu()
+    e_w, e_0 = float((w - ref).abs().mean()), float((plain.cpu() - ref).abs().mean())
+    print(f"plain forward: mean |logit error| single fp16 {e_0:.4f}, with the MX-fp4 weight-rounding correction of QKV / FFN-up {e_w:.4f}")
+    assert e_w < e_0
+    m.cfg_pair = -1

@@ -59,7 +59,7 @@ def test_generator_fp16x2_weights_full12():
     m = hip_generator(cfg, sd)
     args = (torch.from_numpy(z["tokens"]).to(DEV), torch.from_numpy(z["labels"]).to(DEV), torch.from_numpy(z["drop"]).to(DEV))
     ref = torch.from_numpy(z["logits"])
-    m.weight_split, m.act_split = 0, 0                              # independent of MASKBIT_AMD_* in the environment
+    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0                              # independent of MASKBIT_AMD_* in the environment
     e0 = rel_fro(m(*args), ref)
     m.weight_split = 1
     e1 = rel_fro(m(*args), ref)
@@ -79,7 +79,7 @@ def test_generator_split_activations_full12_and_tiny():
     m = hip_generator(cfg, sd)
     args = (torch.from_numpy(z["tokens"]).to(DEV), torch.from_numpy(z["labels"]).to(DEV), torch.from_numpy(z["drop"]).to(DEV))
     ref = torch.from_numpy(z["logits"])
-    m.weight_split, m.act_split = 0, 0                              # independent of MASKBIT_AMD_* in the environment
+    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0                              # independent of MASKBIT_AMD_* in the environment
     e0 = rel_fro(m(*args), ref)
     m.act_split = 1
     out1 = m(*args)
@@ -99,13 +99,13 @@ def test_generator_split_activations_full12_and_tiny():
     m.weight_split = 1
     with pytest.raises(RuntimeError):
         m(*args)                                                                                # the two modes are not combined
-    m.weight_split, m.act_split = 0, 0
+    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0
     assert abs(rel_fro(m(*args), ref) - e0) < 1e-9
     zt = load_golden("gen_tiny.npz")
     mt = hip_generator(TINY_GEN, golden_weights(zt))
     t, y, d = torch.from_numpy(zt["tokens"]).to(DEV), torch.from_numpy(zt["labels"]).to(DEV), torch.from_numpy(zt["drop"]).to(DEV)
     rt = torch.from_numpy(zt["logits"])
-    mt.weight_split, mt.act_split = 0, 0
+    mt.weight_split, mt.act_split, mt.cfg_pair = 0, 0, 0
     a0 = rel_fro(mt(t, y, d), rt)
     mt.act_split = 3
     with pytest.raises(RuntimeError):

@@ -59,7 +59,7 @@ def test_teacher_forced_token_parity_full_size():
     The CPU oracle drives an 8-step CFG run of the full 12-bit model; the HIP path redoes every step
     from the oracle's inputs and noise.  Mismatch is counted over the positions that are sampled
     (masked) at that step.  Engine modes against the same oracle run:
-      * the product default (act_split = -1 -> 3 at this width): must meet the north star's 1e-3;
+      * the product default (differential CFG operands + MX-fp4 weight-rounding correction at this width): must meet the north star's 1e-3;
       * act_split = 0 (single fp16 operands -- the 10-bit mantissa of the TF32 matmuls the reference's configs enable): ~1.2e-3 on this
         8-step stress schedule (CFG scale up to 5.4 while 30% of the tokens are still masked); context only, bound 3e-3;
       * act_split = 2 (every GEMM activation as an fp16 hi+lo pair) and act_split = 3 (the lo halves and a copy of the weights as e4m3, a
@@ -79,13 +79,14 @@ def test_teacher_forced_token_parity_full_size():
                   guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2, mask_schedule_strategy="arccos",
                   mask_token=64, codebook_splits=2, record=rec)
     drop = torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(DEV)
-    # -1 = the product default (strict: hi + lo activation pairs); 0 = single fp16, reported with a loose bound as context
-    for act_split, bound in ((-1, 1e-3), (0, 3e-3), (2, 1e-3), (3, 1e-3)):
-        m.act_split = act_split
+    # (act_split, cfg_pair): (-1, -1) = the product default (differential CFG + weight-rounding correction at this shape); (0, 0) = single
+    # fp16, reported with a loose bound as context; (2, 0) / (3, 0) = hi + lo activation pairs (fp16 / e4m3 lo halves)
+    for act_split, cfg_pair, bound in ((-1, -1, 1e-3), (0, 0, 3e-3), (2, 0, 1e-3), (3, 0, 1e-3)):
+        m.act_split, m.cfg_pair = act_split, cfg_pair
         bad = tot = 0
         for r in rec:
             tin = r.tokens_in.to(DEV).contiguous()
-            lg = m(torch.cat([tin, tin]), torch.cat([y, y]).to(DEV), drop)
+            lg = m.forward_cfg(tin, y.to(DEV), r.scale)                  # the guided forward of the loop
             lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
             assert float((lc.cpu() - r.logits_c).abs().mean()) < 0.03
             tout, pred = torch.empty_like(tin), torch.empty_like(tin)
@@ -97,7 +98,7 @@ def test_teacher_forced_token_parity_full_size():
             msk = r.tokens_in == 64
             bad += int((pred.cpu() != r.pred)[msk].sum())
             tot += int(msk.sum())
-        print(f"act_split={act_split}: teacher-forced mismatch {bad}/{tot} = {bad / tot:.2e}")
+        print(f"act_split={act_split} cfg_pair={cfg_pair}: teacher-forced mismatch {bad}/{tot} = {bad / tot:.2e}")
         assert bad / tot < bound
 
 

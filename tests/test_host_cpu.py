@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from maskbit_amd import _lib
-    assert ctypes.sizeof(_lib.GenCfg) == 12 * 4
+    assert ctypes.sizeof(_lib.GenCfg) == 13 * 4
     assert ctypes.sizeof(_lib.DecCfg) == (5 + 8 + 1 + 3) * 4
     assert ctypes.sizeof(_lib.SamplePlan) == 8 + 3 * 8
 
