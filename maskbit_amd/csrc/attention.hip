@@ -445,6 +445,34 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
   else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
 }
 
+// ---- diagnostic (BASELINE configs[4] "fp8 MFMA attention", measured and rejected -- profiles/r02_fp8_attention.md): round the Q, K, V rows the
+// attention kernel is about to read to OCP e4m3 with one power-of-two scale per (token, head, operand), in place.  The values an fp8 MFMA would
+// multiply are exactly these (products of e4m3 values are exact in the fp32 accumulator on either MFMA), so running the fp16 attention kernel on
+// them measures the token parity an e4m3 Q/K/V attention would have, with the most favourable (dynamic, per-row) scaling.
+__global__ __launch_bounds__(256) void qkv_e4m3_round_kernel(h16* __restrict__ qkv, int rows, int width) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  h16* r = qkv + (size_t)row * width;
+  for (int c0 = 0; c0 < width; c0 += 256) {                     // 256 columns = 4 head slices of 64; a head slice = 16 lanes x 4 columns
+    const h16x4 v = *(const h16x4*)(r + c0 + lane * 4);
+    float f[4] = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    float am = fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3])));
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+    int ex = 0;
+    if (am > 0.f) (void)frexpf(am, &ex);                       // am = m * 2^ex, m in [0.5, 1) -> am * 2^(8 - ex) in [128, 256) (e4m3 max 448)
+    const float up = ldexpf(1.0f, 8 - ex), dn = ldexpf(1.0f, ex - 8);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * up, f[1] * up, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * up, f[3] * up, w, true);
+    *(h16x4*)(r + c0 + lane * 4) = h16x4{(h16)(__builtin_amdgcn_cvt_f32_fp8(w, 0) * dn), (h16)(__builtin_amdgcn_cvt_f32_fp8(w, 1) * dn),
+                                          (h16)(__builtin_amdgcn_cvt_f32_fp8(w, 2) * dn), (h16)(__builtin_amdgcn_cvt_f32_fp8(w, 3) * dn)};
+  }
+}
+void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width) {
+  hipLaunchKernelGGL(qkv_e4m3_round_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, qkv, rows, width);
+}
+
 int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads) {
   const int dh = d / heads;
   if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -144,6 +145,12 @@ int galloc(mb_gen* g, T** p, size_t n) {
   return rc;
 }
 
+// MASKBIT_AMD_ATTN_F8=1 (diagnostic, profiles/r02_fp8_attention.md): Q/K/V rounded to e4m3 before the attention kernel reads them
+bool attn_f8_diag() {
+  static const bool on = getenv("MASKBIT_AMD_ATTN_F8") && atoi(getenv("MASKBIT_AMD_ATTN_F8")) != 0;
+  return on;
+}
+
 int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits,
                      int nb, hipStream_t s, float* attn = nullptr) {
   using namespace mb;
@@ -196,7 +203,8 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s, wm); }
       { ProfScope p("gemm_qkv", s, true);
         xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
-      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
+      if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
+    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
       attn_rc |= attn_maps(l);
       { ProfScope p("gemm_attn_out", s, true);
         GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
@@ -216,6 +224,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     const mb_gen::Layer& L = g->layers[l];
     { ProfScope p("gemm_qkv", s, true);
       xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
+    if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
     { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
     attn_rc |= attn_maps(l);
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
@@ -288,6 +297,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     { ProfScope p("gemm_qkv", s, true);
       GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wmode);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
+    if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
     { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads); }
     { ProfScope p("gemm_attn_out", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, false);

@@ -31,6 +31,7 @@
 // (Tried and rejected: starting the CUs 1/4 tile apart to de-synchronise those bursts -- slower by the delay itself,
 // i.e. the epilogue is bound per CU, not by aggregate HBM bandwidth.)
 #include <algorithm>
+#include <cstdlib>
 
 #include "mb_kernels.h"
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   static_assert(!PAIR || (SEQ && XP != 4), "pair tiles are sequence-aligned (fp16 or fp4 lo pass)");
   // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
   // inside the K loop): those GEMMs run one tile per workgroup, everything else walks the tile list persistently.
-  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4 && XP != 5;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
+  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
   constexpr int AUX = 0;   // DMA cache policy: default beats nt (-14 %) and sc1 (-6 %) here, sc0 is equal (measured)
   constexpr int BM = 32 * MT, MH = MT / 2;
   constexpr int AH_ROWS = BM / 2;
@@ -233,7 +234,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #define MB_F4_ONE(AH, BH, I, N)                                                                     \
   if constexpr (F4) acc[(BH) * 2 + (N)][(AH) * MH + (I)] =                                          \
       mma_f4<(BH) * 2 + (N), (I)>(acc[(BH) * 2 + (N)][(AH) * MH + (I)], wb[BH][N], xa[I], wsc, (AH) ? xsc1 : xsc0);
-#define MB_MMA(AH, BH)                                                                              \
+#define MB_MMA_END                                                                                  \
+  __builtin_amdgcn_s_setprio(0);                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_barrier();
+#define MB_MMA(AH, BH) MB_MMA_DO(AH, BH) MB_MMA_END
+#define MB_MMA_DO(AH, BH)                                                                           \
   {                                                                                                 \
     if (F4 && f8t) {                                                                                \
       MB_F4_ONE(AH, BH, 0, 0) MB_F4_ONE(AH, BH, 0, 1) MB_F4_ONE(AH, BH, 1, 0) MB_F4_ONE(AH, BH, 1, 1)  \
@@ -250,40 +256,38 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
         acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], false); \
     }                                                                                               \
-  }                                                                                                 \
-  __builtin_amdgcn_s_setprio(0);                                                                    \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  __builtin_amdgcn_s_barrier();
+  }
 
   Plan cur;
   int vb = blockIdx.x;
   make_plan(vb, cur);
   uint32_t sb[8] = {};                                 // F4: raw scale bytes of this lane's 8 token rows
-  if constexpr (F4) {
+  auto scales_load = [&](const Plan& p) {             // plain loads; scales_pack() after a vmcnt(0) that the loaded registers are tied through
     int lo_ = lane; asm volatile("" : "+v"(lo_));
     const int r15 = lo_ & 15;
-    wsc = ((const int*)a.w_scale)[((cur.n0 >> 6) + wn) * 16 + r15];
+    wsc = ((const int*)a.w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
     if (PAIR) {
-      const uint8_t* sp = a.a_scale + cur.m0 + wm * 64 + r15;
+      const uint8_t* sp = a.a_scale + p.m0 + wm * 64 + r15;
 #pragma unroll
       for (int i = 0; i < 8; ++i) sb[i] = sp[(i >> 2) * a.pair_rows + (i & 3) * 16];
-      xscc = a.a_scale[cur.cls + (r15 == 1 ? a.pair_rows : 0)];
+      xscc = a.a_scale[p.cls + (r15 == 1 ? a.pair_rows : 0)];
     } else {
-      const uint8_t* sp = a.a_scale + cur.m0 + wm * (16 * MT) + r15;
+      const uint8_t* sp = a.a_scale + p.m0 + wm * (16 * MT) + r15;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sb[i] = sp[min((i >> 2) * (8 * MT) + (i & 3) * 16, a.M - 1 - (cur.m0 + wm * (16 * MT) + r15))];   // rows past M (ragged last tile) re-read row M-1
-      if (SEQ) xscc = a.a_scale[cur.m0 + 256];
+      for (int i = 0; i < 8; ++i) sb[i] = sp[min((i >> 2) * (8 * MT) + (i & 3) * 16, a.M - 1 - (p.m0 + wm * (16 * MT) + r15))];   // rows past M (ragged last tile) re-read row M-1
+      if (SEQ) xscc = a.a_scale[p.m0 + 256];
     }
-  }
-  prologue(cur);
-  if constexpr (F4) {
+  };
+  auto scales_pack = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc), "+v"(xscc), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]) :: "memory");
     xsc0 = sb[0] | (sb[1] << 8) | (sb[2] << 16) | (sb[3] << 24);
     xsc1 = sb[4] | (sb[5] << 8) | (sb[6] << 16) | (sb[7] << 24);
     asm volatile("" : "+v"(wsc), "+v"(xsc0), "+v"(xsc1), "+v"(xscc));   // held in VGPRs of their own through the K loops (cf. sc_ab)
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  };
+  if constexpr (F4) scales_load(cur);
+  prologue(cur);
+  if constexpr (F4) scales_pack();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // K-tiles 0 and 1 of the first tile are in LDS for everyone
 
   while (true) {
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1 */ \
       MB_LOAD_B(1) \
       if (SEQ && wm == 1) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
-      if (n1) dma_a(cur, t + 1, 1); \
+      /* PAIR: the difference rows (A1) take no part in the lo pass (their scale byte is 0): lo K-tiles neither stage nor multiply them */ \
+      if (n1 && !(PAIR && LO && t + 1 >= nka)) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
       if (SEQ && wm == 1) { \
         if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<2, 0>(acce[0], wb[1][0], xe, wsc, xscc); acce[1] = mma_f4<3, 0>(acce[1], wb[1][1], xe, wsc, xscc); } } \
@@ -343,9 +348,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       } \
       MB_MMA(0, 1) \
       /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
-      MB_LOAD_A(1) \
+      if (!(PAIR && f8t)) { MB_LOAD_A(1) } \
       if (n2) dma_a(cur, t + 2, 0); \
-      MB_SYNC_L() MB_MMA(1, 1) \
+      MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 1) } MB_MMA_END \
       /* ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed. */ \
       /* In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output */ \
       /* stores stay in flight until the wait of K-tile 1. */ \
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
       } \
-      MB_SYNC_L() MB_MMA(1, 0) \
+      MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 0) } MB_MMA_END \
       if (F8) asm volatile("" :: "v"(sc_ab)); \
       if (F4) asm volatile("" :: "v"(wsc), "v"(xsc0), "v"(xsc1), "v"(xscc)); \
     }
@@ -404,7 +409,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       for (int nt = 0; nt < 4; ++nt) bias4[nt] = *(const f32x4*)(a.bias + col_of(0, nt));
       if (SEQ) { bcls[0] = *(const f32x4*)(a.bias + col_of(MT, 0)); bcls[1] = *(const f32x4*)(a.bias + col_of(MT, 1)); }
       else { bcls[0] = bias4[0]; bcls[1] = bias4[1]; }
+      if constexpr (F4) { if (has_next) scales_load(nxt); }                  // this tile's K loops are over: the scale registers are free
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]), "+v"(bcls[0]), "+v"(bcls[1]) :: "memory");
+      if constexpr (F4) { if (has_next) scales_pack(); }
       if (has_next) prologue_rest(nxt);
     } else {
 #define MB_LDG16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
@@ -581,6 +588,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #undef MB_LOAD_B
 #undef MB_SYNC_L
 #undef MB_MMA
+#undef MB_MMA_DO
+#undef MB_MMA_END
 #undef MB_F4_ONE
 }
 
@@ -605,7 +614,9 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
     configured = true;
   }
   const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = a.N / 256;
-  const int grid = (EPI != EPI_RES_F32 && XP != 4 && XP != 5 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
+  static const bool f4_persist = !getenv("MASKBIT_AMD_F4_PERSIST") || atoi(getenv("MASKBIT_AMD_F4_PERSIST")) != 0;   // A/B switch (experiments)
+  if (XP == 5 && !f4_persist) persistent = false;
+  const int grid = (EPI != EPI_RES_F32 && XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
   hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 

@@ -119,6 +119,7 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
 // "CFG pair" attention: sequences [0, P) are conditional, [P, 2P) their unconditional twins.  Two launches: the conditional sequences also
 // store their fp32 output rows to `aux` [P*N, d]; the unconditional ones then write out[r + P*N] = fp16(att_u - att_c) (difference operand of
 // the out-proj pair GEMM).  Short-sequence kernel only (N <= 288): returns -1 otherwise.
+void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width);   // diagnostic: Q/K/V rows -> e4m3 values (per token, head, operand scale), in place; width % 256 == 0
 int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads);
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
