@@ -136,6 +136,10 @@ int mb_dec_load(mb_dec* d, const char* name, const float* data, const int64_t* s
 /* tokens int64 [B, n] (K-bit codes) -> img_nchw fp32 [B,3,H,W] unclamped (may be NULL) and/or
  * img_nhwc_u8 uint8 [B,H,W,3] = trunc(clamp(x,0,1)*255) (scripts/eval_maskbit.py:134-135; may be NULL). */
 int mb_dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_nhwc_u8, int B, mb_stream stream);
+/* The decoder / encoder keep activations in fp16 (saturating stores).  Number of 4-channel output groups that were clamped at +-65504 since the last
+ * reset, over all conv layers (0 for every configuration tested; a trained checkpoint that needs more range shows up here instead of being
+ * clipped silently).  Synchronises `stream`. */
+int mb_dec_saturation_count(mb_dec* d, unsigned* count, int reset, mb_stream stream);
 /* ---- encoder half: ConvVQModel.encode, modeling/conv_vqgan.py:70-83 (ConvEncoder autoencoder.py:264-286 +
  * LookupFreeQuantizer sign/pack lookup_free.py:57-62,113-127).  img fp32 [B,C,H,W] -> indices int64 [B, h*w];
  * zq (+-1 latent, fp32 [B,K,h,w]) and zraw (pre-sign encoder output) may be NULL.  Needs build_encoder = 1. */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mb_dec_destroy": (None, [C.c_void_p]),
     "mb_dec_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     "mb_dec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_dec_saturation_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
     "mb_enc_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SamplePlan), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -164,6 +164,20 @@ class ConvVQModel(BaseModel):
         dev = self._require_cuda("decode_tokens")
         return self._decode_codes(tokens.to(dev).long().contiguous())
 
+    def saturation_count(self, reset: bool = True) -> int:
+        """Number of 4-channel activation groups the engine clamped at the fp16 range (+-65504) since the last reset, over every conv layer
+        of decode / encode calls on the current engine.  0 for every configuration tested; a checkpoint whose activations need more range
+        shows up here (the activations are stored as fp16) instead of being clipped silently.  Synchronises the current stream."""
+        if self._engine is None:
+            return 0
+        import ctypes as C
+        n = C.c_uint(0)
+        dev = self._require_cuda("saturation_count")
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mb_dec_saturation_count(self._engine, C.byref(n), 1 if reset else 0, torch.cuda.current_stream().cuda_stream),
+                       "mb_dec_saturation_count")
+        return int(n.value)
+
     @torch.no_grad()
     def decode_tokens_uint8(self, tokens: torch.Tensor):
         """-> (image fp32 NCHW, uint8 NHWC = trunc(clamp(x,0,1)*255)) in one pass (eval_maskbit.py:134-135 fused)."""

@@ -34,6 +34,7 @@ struct ConvArgs {
   float* img_nchw;       // final conv only
   uint8_t* img_u8;       // final conv only
   int B, H, W, Cin, Cout, Cout_pad;
+  unsigned* sat;         // counts output groups of 4 whose value left the fp16 range and was clamped (mb_dec_saturation_count)
 };
 
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -176,6 +177,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
           const h16x4 rv = *(const h16x4*)(a.residual + pix * a.Cout + n);
           v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
         }
+        // activations are stored as fp16: values beyond +-65504 are clamped by to_h -- counted, so that a checkpoint whose decoder needs a
+        // wider residual stream is noticed instead of silently clipped (random-init weights stay far inside the range)
+        if (fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > MB_H16_MAX) atomicAdd(a.sat, 1u);
         *(h16x4*)(a.out + pix * a.Cout + n) = h16x4{to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
       }
     }
@@ -339,6 +343,7 @@ struct Conv {
   int cout_w = 0;          // output channels in the checkpoint (cout may be rounded up for 8-byte stores)
   int cin_pad = 0, cout_pad = 0;
   h16* w = nullptr; float* b = nullptr;
+  unsigned* sat = nullptr; // the engine's saturation counter
 };
 struct Norm { std::string name; int c = 0; float *g = nullptr, *b = nullptr; };
 struct ResBlock { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; };
@@ -361,6 +366,7 @@ struct mb_dec {
   std::vector<mb::Stage> e_down;
   h16* buf[3] = {nullptr, nullptr, nullptr};
   h16* z = nullptr;
+  unsigned* sat = nullptr;  // device counter: fp16 clamps in the conv epilogues since the last read
   float* gn_part = nullptr;
   float2* gn_ss = nullptr;
   std::vector<void*> owned;
@@ -381,7 +387,7 @@ bool dalloc(mb_dec* d, T** p, size_t n, std::string& err) {
 
 bool init_conv(mb_dec* d, Conv& c, const std::string& name, int cin, int cout, int ks, bool bias, bool up, bool final_,
                std::string& err) {
-  c.name = name; c.cin = cin; c.cout = cout; c.cout_w = cout; c.ks = ks; c.has_bias = bias; c.up = up;
+  c.name = name; c.cin = cin; c.cout = cout; c.cout_w = cout; c.ks = ks; c.has_bias = bias; c.up = up; c.sat = d->sat;
   c.cin_pad = (cin + CK - 1) / CK * CK;
   c.cout_pad = final_ ? 16 : (cout + 127) / 128 * 128;
   if (!dalloc(d, &c.w, (size_t)ks * ks * c.cout_pad * c.cin_pad, err)) return false;
@@ -405,7 +411,7 @@ bool init_block(mb_dec* d, ResBlock& rb, const std::string& p, int cin, int cout
 
 void launch_conv(hipStream_t s, const Conv& c, const h16* in, const float2* gn, const h16* residual, h16* out,
                  float* img, uint8_t* u8, int B, int H, int W, bool final_) {
-  ConvArgs a{in, gn, c.w, c.has_bias ? c.b : nullptr, residual, out, img, u8, B, H, W, c.cin_pad, c.cout, c.cout_pad};
+  ConvArgs a{in, gn, c.w, c.has_bias ? c.b : nullptr, residual, out, img, u8, B, H, W, c.cin_pad, c.cout, c.cout_pad, c.sat};
   const int bn = final_ ? 16 : 128;
   dim3 grid((unsigned)((size_t)B * (H / TH) * (W / TW) * (c.cout_pad / bn))), block(256);
   if (final_) hipLaunchKernelGGL((conv_kernel<1, 1, 3, false, true>), grid, block, 0, s, a);
@@ -458,6 +464,8 @@ mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
   if (cfg.num_channels > 4) { err = "num_channels > 4 unsupported"; return nullptr; }
   mb_dec* d = new mb_dec();
   d->c = cfg; d->max_batch = max_batch; d->out_res = cfg.latent_size << (R - 1);
+  if (!dalloc(d, &d->sat, 1, err)) { dec_destroy(d); return nullptr; }
+  (void)hipMemset(d->sat, 0, sizeof(unsigned));
   const int hc = cfg.hidden_channels;
   std::vector<int> mult(cfg.channel_mult, cfg.channel_mult + R);
   mult.push_back(cfg.channel_mult[R - 1]);
@@ -610,6 +618,12 @@ int dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_n
 }
 
 // ConvVQModel.encode (conv_vqgan.py:70-83): image [B,C,H,W] fp32 -> code indices [B, h*w] (+ optional +-1 latent / raw z, fp32 NCHW)
+int dec_saturation_count(mb_dec* d, unsigned* count, bool reset, hipStream_t s) {
+  if (hipMemcpyAsync(count, d->sat, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return -10;
+  if (reset && hipMemsetAsync(d->sat, 0, sizeof(unsigned), s) != hipSuccess) return -10;
+  return hipStreamSynchronize(s) == hipSuccess ? 0 : -10;
+}
+
 int enc_encode(mb_dec* d, const float* img, int64_t* indices, float* zq, float* zraw, int B, hipStream_t s, std::string& err) {
   if (!d->has_enc) { err = "this engine was created without the encoder half (mb_dec_cfg.build_encoder)"; return -1; }
   if (B <= 0 || B > d->max_batch) { err = "batch outside [1, max_batch]"; return -1; }

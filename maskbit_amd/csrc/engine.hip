@@ -758,6 +758,12 @@ int mb_dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* im
   return 0;
 }
 
+int mb_dec_saturation_count(mb_dec* d, unsigned* count, int reset, mb_stream stream) {
+  if (!d || !count) return fail(-1, "mb_dec_saturation_count: null argument");
+  if (mb::dec_saturation_count(d, count, reset != 0, (hipStream_t)stream)) return fail(-10, "mb_dec_saturation_count: copy failed");
+  return 0;
+}
+
 int mb_enc_encode(mb_dec* d, const float* img_nchw, int64_t* indices, float* zq, float* zraw, int B, mb_stream stream) {
   if (!d || !img_nchw || !indices) return fail(-1, "mb_enc_encode: null argument");
   std::string err;

@@ -8,7 +8,8 @@ shapes of SURVEY.md 8b), runs them on CPU in fp32 and stores inputs + outputs as
 Nothing of the reference's source travels: fixtures hold tensors only.
 
     python oracle/make_golden.py            # writes tests/golden/*.npz (all but the one below)
-    python oracle/make_golden.py full64     # tests/golden/sample_full12_64.npz: the reference's full-size 64-step CFG run
+    python oracle/make_golden.py full64     # tests/golden/sample_full12_64.npz: the reference's full-size 64-step CFG run (BASELINE configs[2])
+    python oracle/make_golden.py sample_full10_16_nocfg sample_full14_256    # the same for BASELINE configs[1] and configs[4]
 
 Weights for the tiny cases are stored inside the fixtures; the full-size cases regenerate
 weights from a seed with oracle.make_*_weights and guard them with a sha256 sentinel.
@@ -102,55 +103,70 @@ def masked_test_tokens(cfg: O.GenCfg, b: int, seed: int) -> torch.Tensor:
 
 FULL64 = dict(num_steps=64, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2,
               mask_schedule_strategy="arccos")      # configs/generator/maskbit_generator_12bit.yaml (BASELINE configs[2])
+# BASELINE configs[1]: 10-bit generator, 16 steps, no guidance (configs/generator/maskbit_generator_10bit.yaml sampler block with num_steps 16,
+# guidance off as BASELINE.json names it); configs[4]: 14-bit generator, configs/generator/maskbit_generator_14bit_256steps.yaml:38-44
+CFG1_16 = dict(num_steps=16, guidance_scale=0.0, guidance_annealing="none", scale_pow=4.0, randomize_temperature=10.5, mask_schedule_strategy="arccos")
+CFG5_256 = dict(num_steps=256, guidance_scale=5.8, guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=10.3, mask_schedule_strategy="arccos")
+RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs, with decode)
+    "sample_full12_64": (12, 100, 12.0, 4, FULL64, True),
+    "sample_full10_16_nocfg": (10, 101, 12.0, 16, CFG1_16, False),
+    "sample_full14_256": (14, 102, 12.0, 2, CFG5_256, False),
+}
 
 
-def full64(LFQBert, ConvVQModel, ref_sample, B: int = 4, seed: int = 1234):
-    """Full-size, free-running golden: the REAL reference's sample() (sampling.py:55-136) on the 12-bit generator,
-    64 steps, CFG 7.1 cosine, arccos schedule, seed fixed, on CPU fp32.  Stored per step: the predicted tokens
-    (l_full_tokens, int16) and the masked-token state the model saw (bit-packed mask: what a teacher-forced replay
-    needs), plus the final codes, pixel crops, a 4x-subsampled uint8 image and hashes.  Weights are regenerated from
-    seeds (sha-guarded), noise from the seed (torch CPU generator, draw order of the reference on a CPU model)."""
-    gsd = O.make_generator_weights(FULL_GEN12, seed=100, head_gain=12.0)
-    tsd = O.make_tokenizer_weights(FULL_TOK12, seed=200)
-    gen = build_ref_gen(LFQBert, FULL_GEN12, gsd)
-    tok = build_ref_tok(ConvVQModel, FULL_TOK12, O.make_tokenizer_weights(FULL_TOK12, seed=200, with_encoder=True))
-    labels = torch.tensor([7, 282, 604, 980, 1, 404, 850, 33][:B])
+def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
+    """Full-size, free-running golden: the REAL reference's sample() (sampling.py:55-136) on a full-size generator with the sampler settings
+    of a BASELINE configuration, seed fixed, on CPU fp32.  Stored per step: the predicted tokens (l_full_tokens, int16) and the masked-token
+    state the model saw (bit-packed mask: what a teacher-forced replay needs); for the 12-bit run also the final codes, pixel crops, a
+    4x-subsampled uint8 image and hashes.  Weights are regenerated from seeds (sha-guarded), noise from the seed (torch CPU generator,
+    draw order of the reference on a CPU model)."""
+    bits, gseed, gain, B, kw, decode = RUNS[name]
+    gcfg = O.GenCfg(bits=bits, splits=2)
+    C_ = gcfg.group_codes
+    gsd = O.make_generator_weights(gcfg, seed=gseed, head_gain=gain)
+    gen = build_ref_gen(LFQBert, gcfg, gsd)
+    tcfg = O.TokCfg(token_size=bits)
+    tsd = O.make_tokenizer_weights(tcfg, seed=200)
+    tok = build_ref_tok(ConvVQModel, tcfg, O.make_tokenizer_weights(tcfg, seed=200, with_encoder=True))
+    labels = torch.tensor([7, 282, 604, 980, 1, 404, 850, 33, 512, 111, 927, 65, 340, 771, 208, 999][:B])
     seen = []
     inner = gen.forward
 
     def spy(tokens, y, drop, *a, **k):                 # the model's input at every step = the masked-token state
-        seen.append(tokens[: tokens.shape[0] // 2].clone())
+        seen.append(tokens[:B].clone())
         return inner(tokens, y, drop, *a, **k)
 
     gen.forward = spy
     torch.manual_seed(seed)
-    image, steps = ref_sample(gen, tok, num_samples=B, labels=labels.clone(), softmax_temperature=1.0, mask_token=64,
-                              patch_size=16, codebook_size=4096, codebook_splits=2, **FULL64)
+    image, steps = ref_sample(gen, tok, num_samples=B, labels=labels.clone(), softmax_temperature=1.0, mask_token=C_,
+                              patch_size=16, codebook_size=2 ** bits, codebook_splits=2, **kw)
     gen.forward = inner
-    steps = torch.stack(steps)                          # [64, B, 256, 2]
-    masks = torch.stack(seen) == 64                     # [64, B, 256, 2] positions masked when step i ran
-    assert masks[0].all() and steps.max() < 64 + 1
-    assert torch.equal(torch.where(masks[1:], torch.full_like(steps[:-1], 64), steps[:-1]), torch.stack(seen)[1:])
-    codes = O.combine_groups(steps[-1], 12, 2)
-    u8 = (torch.clamp(image, 0.0, 1.0) * 255.0).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8)
-    crops = {f"crop_{y}_{x}": image[:, :, y:y + 16, x:x + 16].numpy() for (y, x) in ((0, 0), (120, 120), (240, 240), (37, 201))}
-    np.savez_compressed(os.path.join(OUT, "sample_full12_64.npz"), seed=seed, gen_seed=100, head_gain=12.0, tok_seed=200,
-                        labels=labels.numpy(), steps=steps.numpy().astype(np.int16),
-                        masks=np.packbits(masks.numpy().reshape(64, -1), axis=1), codes=codes.numpy().astype(np.int16),
-                        image_u8_q=u8[:, ::4, ::4].numpy(), image_u8_sha=sha(u8), image_mean=image.mean((0, 2, 3)).numpy(),
-                        image_std=image.std((0, 2, 3)).numpy(),
-                        w_sha_in_proj0=sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]),
-                        w_sha_conv_in=sha(tsd["decoder.conv_in.weight"]),
-                        kw_keys=np.array(list(FULL64.keys())), kw_vals=np.array([str(v) for v in FULL64.values()]), **crops)
-    print("sample_full12_64: sampled positions", int(masks.sum()), "final mask tokens left:", int((steps[-1] == 64).sum()))
+    steps = torch.stack(steps)                          # [S, B, 256, 2]
+    S = steps.shape[0]
+    masks = torch.stack(seen) == C_                     # [S, B, 256, 2] positions masked when step i ran
+    assert masks[0].all() and steps.max() < C_
+    assert torch.equal(torch.where(masks[1:], torch.full_like(steps[:-1], C_), steps[:-1]), torch.stack(seen)[1:])
+    out = dict(seed=seed, gen_seed=gseed, head_gain=gain, tok_seed=200, bits=bits, labels=labels.numpy(), steps=steps.numpy().astype(np.int16),
+               masks=np.packbits(masks.numpy().reshape(S, -1), axis=1), w_sha_in_proj0=sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]),
+               w_sha_conv_in=sha(tsd["decoder.conv_in.weight"]), kw_keys=np.array(list(kw.keys())), kw_vals=np.array([str(v) for v in kw.values()]))
+    if decode:
+        codes = O.combine_groups(steps[-1], bits, 2)
+        u8 = (torch.clamp(image, 0.0, 1.0) * 255.0).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8)
+        out.update(codes=codes.numpy().astype(np.int16), image_u8_q=u8[:, ::4, ::4].numpy(), image_u8_sha=sha(u8),
+                   image_mean=image.mean((0, 2, 3)).numpy(), image_std=image.std((0, 2, 3)).numpy(),
+                   **{f"crop_{y}_{x}": image[:, :, y:y + 16, x:x + 16].numpy() for (y, x) in ((0, 0), (120, 120), (240, 240), (37, 201))})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, ": sampled positions", int(masks.sum()), "final mask tokens left:", int((steps[-1] == C_).sum()))
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     LFQBert, ConvVQModel, ref_sample, ref_ratio, ref_combine, ref_split = _import_reference()
-    if "full64" in sys.argv[1:]:                        # only the (2-minute) full-size free-running run
-        full64(LFQBert, ConvVQModel, ref_sample)
+    picked = [n for n in RUNS if n in sys.argv[1:]] + (["sample_full12_64"] if "full64" in sys.argv[1:] else [])
+    if picked:                                          # only the (minutes-long) full-size free-running runs named on the command line
+        for n in picked:
+            full_run(LFQBert, ConvVQModel, ref_sample, n)
         return
 
     # ---- 1. tiny generator forward --------------------------------------------------------

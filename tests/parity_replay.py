@@ -19,24 +19,36 @@ from typing import Dict, Tuple
 import numpy as np
 import torch
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_full12_64.npz")
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = os.path.join(GOLDEN_DIR, "sample_full12_64.npz")
+# the other full-size runs of the reference (oracle/make_golden.py RUNS): BASELINE configs[1] and configs[4] with their own sampler settings
+RUN_CFG1 = "sample_full10_16_nocfg"
+RUN_CFG5 = "sample_full14_256"
 
 
-def load_full64() -> Dict[str, object]:
-    z = np.load(GOLDEN)
-    steps = torch.from_numpy(z["steps"].astype(np.int64))                      # [64, B, 256, 2] predicted tokens per step
+def load_run(name: str = "sample_full12_64") -> Dict[str, object]:
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    steps = torch.from_numpy(z["steps"].astype(np.int64))                      # [S, B, 256, 2] predicted tokens per step
     S, B = steps.shape[0], steps.shape[1]
     masks = torch.from_numpy(np.unpackbits(z["masks"], axis=1)[:, : B * 512].reshape(S, B, 256, 2).astype(bool))
     kw = {str(k): str(v) for k, v in zip(z["kw_keys"], z["kw_vals"])}
-    return {"z": z, "steps": steps, "masks": masks, "labels": torch.from_numpy(z["labels"].astype(np.int64)), "kw": kw,
-            "seed": int(z["seed"]), "codes": torch.from_numpy(z["codes"].astype(np.int64))}
+    bits = int(z["bits"]) if "bits" in z.files else 12
+    g = {"z": z, "name": name, "steps": steps, "masks": masks, "labels": torch.from_numpy(z["labels"].astype(np.int64)), "kw": kw,
+         "seed": int(z["seed"]), "bits": bits, "C": 1 << (bits // 2)}
+    if "codes" in z.files:
+        g["codes"] = torch.from_numpy(z["codes"].astype(np.int64))
+    return g
+
+
+def load_full64() -> Dict[str, object]:
+    return load_run("sample_full12_64")
 
 
 def tokens_in(g, i: int) -> torch.Tensor:
     """The masked-token state the reference's model saw at step i."""
     if i == 0:
-        return torch.full_like(g["steps"][0], 64)
-    return torch.where(g["masks"][i], torch.full_like(g["steps"][0], 64), g["steps"][i - 1])
+        return torch.full_like(g["steps"][0], g["C"])
+    return torch.where(g["masks"][i], torch.full_like(g["steps"][0], g["C"]), g["steps"][i - 1])
 
 
 def reference_noise(g, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -47,7 +59,7 @@ def reference_noise(g, device) -> Tuple[torch.Tensor, torch.Tensor]:
     gum = torch.distributions.Gumbel(0.0, 1.0)
     qs, cs = [], []
     for i in range(S):
-        qs.append(torch.empty(B * 512, 64).exponential_(1))
+        qs.append(torch.empty(B * 512, g["C"]).exponential_(1))
         cs.append(gum.sample((B, 256, 2)) * rt * (1 - (i + 1) / S))
     return torch.stack(qs).to(device), torch.stack(cs).to(device)
 
@@ -59,15 +71,16 @@ def plan_of(g):
                       kw["mask_schedule_strategy"])
 
 
-def build_models(device, with_tokenizer: bool = True):
+def build_models(device, with_tokenizer: bool = True, name: str = "sample_full12_64"):
     """The fixture's generator / tokenizer on the HIP engine (weights regenerated from the seeds, sha-checked)."""
     import hashlib
     from maskbit_amd import ConvVQModel, LFQBert, synth
-    z = np.load(GOLDEN)
-    gsd = synth.make_generator_weights(synth.GenCfg(bits=12, splits=2), seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]))
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    bits = int(z["bits"]) if "bits" in z.files else 12
+    gsd = synth.make_generator_weights(synth.GenCfg(bits=bits, splits=2), seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]))
     sha = lambda t: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
     assert sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]) == str(z["w_sha_in_proj0"]), "synthetic generator weights changed"
-    gen = LFQBert(img_size=256, hidden_dim=1024, codebook_size=4096, codebook_splits=2, depth=24, heads=16, mlp_dim=4096, dropout=0.1,
+    gen = LFQBert(img_size=256, hidden_dim=1024, codebook_size=2 ** bits, codebook_splits=2, depth=24, heads=16, mlp_dim=4096, dropout=0.1,
                   nclass=1000, input_stride=16)
     gen.load_state_dict(gsd, strict=True)
     gen = gen.eval().requires_grad_(False).to(device)
@@ -102,12 +115,15 @@ def teacher_forced(gen, g=None, noise=None):
     for i in range(S):
         tin_cpu = tokens_in(g, i)
         tin = tin_cpu.to(dev).contiguous()
-        lg = gen.forward_cfg(tin, y, scale[i])                       # the guided forward of the loop (cond | label-dropped)
-        lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
+        if float(g["kw"]["guidance_scale"]) != 0.0:
+            lg = gen.forward_cfg(tin, y, scale[i])                   # the guided forward of the loop (cond | label-dropped)
+            lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
+        else:
+            lc, lu = gen(tin, y, torch.zeros(B, dtype=torch.bool, device=dev)), None
         tout, pred = torch.empty_like(tin), torch.empty_like(tin)
-        _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr(), scale[i], temp[i], q[i].data_ptr(), c[i].data_ptr(), mask_len[i],
-                                      tin.data_ptr(), tout.data_ptr(), pred.data_ptr(), B, 256, 2, 64, torch.cuda.current_stream().cuda_stream),
-                   "mb_sample_step")
+        _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr() if lu is not None else None, scale[i], temp[i], q[i].data_ptr(), c[i].data_ptr(),
+                                      mask_len[i], tin.data_ptr(), tout.data_ptr(), pred.data_ptr(), B, 256, 2, g["C"],
+                                      torch.cuda.current_stream().cuda_stream), "mb_sample_step")
         msk = g["masks"][i]
         per_step.append(int((pred.cpu() != g["steps"][i])[msk].sum()))
         total += int(msk.sum())

@@ -252,3 +252,21 @@ def test_decoder_config1_10bit():
     rec = tk.decode_tokens(torch.from_numpy(z["indices"]).reshape(1, -1).to(DEV))
     assert float((rec[:, :, 100:132, 100:132].cpu() - torch.from_numpy(z["recon_crop"])).abs().max()) < 0.03
     # (the encode half of this configuration: tests/test_hip_encoder.py)
+
+
+def test_decoder_fp16_saturation_is_counted():
+    """The decoder keeps activations in fp16 with saturating stores: values that leave +-65504 are clamped AND counted, so a
+    checkpoint that needs more range is noticed.  Seeded weights: 0 clamps; the same weights with conv_in scaled by 1e6: clamps reported."""
+    tz = load_golden("tok_tiny.npz")
+    tsd = O.make_tokenizer_weights(TINY_TOK, seed=int(tz["seed"]), with_encoder=True)
+    tm = hip_tokenizer(TINY_TOK, tsd)
+    toks = torch.from_numpy(tz["tokens"]).to(DEV)
+    tm.decode_tokens(toks)
+    assert tm.saturation_count() == 0
+    big = dict(tsd)
+    big["decoder.conv_in.weight"] = tsd["decoder.conv_in.weight"] * 1e6
+    tb = hip_tokenizer(TINY_TOK, big)
+    out = tb.decode_tokens(toks)
+    n = tb.saturation_count()
+    assert n > 0 and torch.isfinite(out).all()          # clamped, never inf / NaN
+    assert tb.saturation_count() == 0                   # reading resets the counter
