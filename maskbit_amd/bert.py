@@ -25,9 +25,10 @@ DEFAULT_WEIGHT_SPLIT = 0
 # (act_split 3 where the lo-pass kernels take the shape, i.e. hidden and mlp multiples of 256; act_split 2 otherwise).
 DEFAULT_ACT_SPLIT = -1
 STRICT_LEVEL = int(os.environ.get("MASKBIT_AMD_STRICT_LEVEL", "3"))   # lo-pass format behind "strict": 3 = e4m3, 4 = MX-fp4 for the LayerNorm outputs
-# Differential classifier-free guidance (mb_gen_cfg.cfg_pair): -1 = auto (2 where the shape allows it), 0 = off, 1 = differential operands,
-# 2 = + MX-fp4 correction of the QKV / FFN-up weight rounding where it dominates.  Where it applies it REPLACES the hi + lo activation pairs
-# (act_split resolves to 0): same parity class at the cost of the plain fp16 forward.
+# Differential classifier-free guidance (mb_gen_cfg.cfg_pair) for the GUIDED forward (forward_cfg / sample() with guidance): -1 = auto (1 where
+# the shape allows it), 0 = off, 1 = differential operands -- the hi + lo pairs' parity class at the cost of the plain fp16 forward --,
+# 2 = + an MX-fp4 correction of the QKV / FFN-up weight rounding (experiment: no parity gain measured).  act_split keeps governing the plain
+# (unguided) forward.
 DEFAULT_CFG_PAIR = -1
 
 
@@ -124,19 +125,17 @@ class LFQBert(BaseModel):
         return h
 
     def resolved_precision(self):
-        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch the cheapest way":
-        differential CFG + weight-rounding correction where the shape allows it, hi + lo activation pairs otherwise."""
-        capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm) and not self.weight_split
+        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch of the headline configuration
+        the cheapest way": guided forwards in differential form where the shape allows it, plain forwards with hi + lo activation pairs."""
+        capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm)
         pair, act = int(self.cfg_pair), int(self.act_split)
+        if act < 0:
+            act = 0 if self.weight_split else resolve_act_split(act, self.hidden_dim, self.mlp_dim)   # fp16x2 weights are not combined with act_split
         if pair < 0:
-            pair = 2 if (capable and act <= 0) else 0
-        if pair and not (capable and act <= 0):
+            pair = 1
+        if not capable or (pair == 2 and (act or self.weight_split)):
             pair = 0
-        if pair:
-            return 0, pair
-        if self.weight_split and act < 0:
-            return 0, 0                                            # fp16x2 weights (opt-in experiment) are not combined with act_split
-        return resolve_act_split(act, self.hidden_dim, self.mlp_dim), 0
+        return act, pair
 
     def _engine_destroy(self, h) -> None:
         _lib.load().mb_gen_destroy(h)

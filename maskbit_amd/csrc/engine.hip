@@ -280,7 +280,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   uint8_t* const x4 = wmode ? g->x4 : nullptr;
   uint8_t* const x4s = wmode ? g->x4s : nullptr;
   auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo) {
-    GemmArgs ga{A, W, bias, res, res, out16, M, Nout, K, 0, 0, nullptr};
+    GemmArgs ga{A, W, bias, res, res, out16, M, Nout, g->split ? 2 * K : K, 0, g->split ? K : 0, g->sc(widx)};   // fp16x2 weights: A swept twice
     ga.pair_rows = P;
     if (lo) { ga.K = K + K / 4; ga.kw = K; ga.A4 = g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4los[widx]; }
     return ga;
@@ -312,18 +312,18 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     { ProfScope p("layernorm", s, true);
-      if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi + lo rows
+      if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi (+ lo) rows
       else rc |= layernorm_pair(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_h16, g->ln_stats, P, d, x4, x4s); }
   }
   { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 2 * d, 0, 0, nullptr};
-    ga.A2 = g->x_lo; ga.kw = d;
+    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 2 * d, 0, g->split ? d : 0, g->sc(4 * c.depth)};
+    if (!g->split) { ga.A2 = g->x_lo; ga.kw = d; }
     rc |= gemm_tn(s, EPI_GELU_F32, ga); }
   { ProfScope p("layernorm", s, true);
     layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
   { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, 2 * d, N, 0, nullptr};
-    ga.A2 = g->x_lo; ga.kw = d;
+    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, 2 * d, N, g->split ? d : 0, g->sc(4 * c.depth + 1)};
+    if (!g->split) { ga.A2 = g->x_lo; ga.kw = d; }
     ga.bias_per_pos = c.embed_tables;
     rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
   hipError_t e = hipGetLastError();
@@ -528,6 +528,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (c.act_split == 4 && c.hidden != 768 && c.hidden != 1024) return fail(-1, "act_split = 4 (MX-fp4 lo pass) is built for hidden = 768 or 1024");
   if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
   if (c.cfg_pair < 0 || c.cfg_pair > 2) return fail(-1, "cfg_pair must be 0, 1 or 2");
+  if (c.cfg_pair == 2 && (c.act_split || c.weight_split)) return fail(-1, "cfg_pair = 2 (weight-correction pass) is not combined with act_split / weight_split");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
@@ -577,8 +578,10 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   }
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
-  g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && !c.prenorm && !c.act_split && !c.weight_split &&
-               g->chunk_seqs >= 2;
+  // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice; the weight-correction pass of
+  // cfg_pair 2 needs plain fp16 operands)
+  g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && !c.prenorm && g->chunk_seqs >= 2 &&
+               (c.cfg_pair == 1 || (!c.act_split && !c.weight_split));
   if (g->pair_ok) {
     rc |= galloc(g, &g->att_aux, (M / 2) * d);
     if (c.cfg_pair == 2) {

@@ -622,7 +622,7 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
-  if (a.pair_rows && (a.pair_rows % 257 || a.M != 2 * a.pair_rows || a.A8 || a.A2 || a.ka || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
+  if (a.pair_rows && (a.pair_rows % 257 || a.M != 2 * a.pair_rows || a.A8 || a.A2 || (a.ka && a.A4) || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
   if (a.A4 && (a.A8 || !a.W4 || !a.a_scale || !a.w_scale || a.kw % 256 || a.K != a.kw + a.kw / 4 || epi == EPI_GELU_F32)) return false;
   return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8 || a.A4) &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&

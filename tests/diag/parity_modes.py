@@ -6,8 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import parity_replay as R
 
-MODES = [("default (-1,-1)", -1, -1), ("single fp16 (0,0)", 0, 0), ("differential only (0,1)", 0, 1), ("differential + W (0,2)", 0, 2),
-         ("hi+lo e4m3 (3,0)", 3, 0), ("hi+lo fp4 x (4,0)", 4, 0)]
+MODES = [("default (-1,-1)", -1, -1, 0), ("single fp16 (0,0)", 0, 0, 0), ("differential only (0,1)", 0, 1, 0), ("differential + W (0,2)", 0, 2, 0),
+         ("hi+lo e4m3 (3,0)", 3, 0, 0), ("hi+lo fp4 x (4,0)", 4, 0, 0), ("fp16x2 weights (0,0,ws)", 0, 0, 1), ("differential + fp16x2 weights", 0, 1, 1)]
+if os.environ.get("PM_MODES"):
+    MODES = [m for i, m in enumerate(MODES) if str(i) in os.environ["PM_MODES"].split(",")]
 
 
 def main():
@@ -17,8 +19,8 @@ def main():
         gen, _ = R.build_models("cuda", with_tokenizer=False, name=name)
         noise = R.reference_noise(g, gen.device)
         nb = max(1, len(g["steps"]) // 8)
-        for tag, act, pair in MODES:
-            gen.weight_split, gen.act_split, gen.cfg_pair = 0, act, pair
+        for tag, act, pair, ws in MODES:
+            gen.weight_split, gen.act_split, gen.cfg_pair = ws, act, pair
             t0 = time.time()
             bad, tot, per, _ = R.teacher_forced(gen, g, noise)
             print(f"{name:24s} {tag:26s}: {bad:4d}/{tot} = {bad / tot:.2e}   per eighth {[sum(per[i:i + nb]) for i in range(0, len(per), nb)]}  ({time.time() - t0:.1f}s)", flush=True)
