@@ -126,6 +126,7 @@ struct mb_gen {
   bool pair_ok = false;
   float* att_aux = nullptr;
   float* logits_tmp = nullptr;                          // guided forwards over more pairs than one pass holds
+  h16 *wl_plain = nullptr, *wp_plain = nullptr;         // fp16x2 weights + pair forward: single-fp16 copies of the two head weights (the head takes hi + lo INPUTS there)
   std::vector<uint8_t*> w4lo, w4los;                                                     // [4 * layer + {qkv, -, 1, -}]
   int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
   // loop state for mb_sample
@@ -248,14 +249,14 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   }
   { ProfScope p("gemm_head", s, true);
     GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)};
-    split2(ga, g->x_lo, d);   // the two head GEMMs always take their LayerNorm inputs as hi + lo pairs: their rounding lands on the logits
+    if (!g->split) split2(ga, g->x_lo, d);   // the two head GEMMs always take their LayerNorm inputs as hi + lo pairs: their rounding lands on the logits
                               // un-averaged and is amplified by the guidance scale, and the two GEMMs are 0.4 % of a forward (DESIGN.md "Precision")
     gemm_rc |= gemm_tn(s, EPI_GELU_F32, ga); }
   { ProfScope p("layernorm", s, true);
     layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
   { ProfScope p("gemm_head", s, true);
     GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)};
-    split2(ga, g->x_lo, d);
+    if (!g->split) split2(ga, g->x_lo, d);
     ga.bias_per_pos = c.embed_tables;
     gemm_rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
   hipError_t e = hipGetLastError();
@@ -315,15 +316,16 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi (+ lo) rows
       else rc |= layernorm_pair(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_h16, g->ln_stats, P, d, x4, x4s); }
   }
+  // head: hi + lo INPUT pairs in every mode (that rounding reaches the logits un-averaged and guidance multiplies it); single-fp16 head weights
   { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 2 * d, 0, g->split ? d : 0, g->sc(4 * c.depth)};
-    if (!g->split) { ga.A2 = g->x_lo; ga.kw = d; }
+    GemmArgs ga{g->x_h16, g->split ? g->wl_plain : g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 2 * d, 0, 0, nullptr};
+    ga.A2 = g->x_lo; ga.kw = d;
     rc |= gemm_tn(s, EPI_GELU_F32, ga); }
   { ProfScope p("layernorm", s, true);
     layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
   { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, 2 * d, N, g->split ? d : 0, g->sc(4 * c.depth + 1)};
-    if (!g->split) { ga.A2 = g->x_lo; ga.kw = d; }
+    GemmArgs ga{g->x_h16, g->split ? g->wp_plain : g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, 2 * d, N, 0, nullptr};
+    ga.A2 = g->x_lo; ga.kw = d;
     ga.bias_per_pos = c.embed_tables;
     rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
   hipError_t e = hipGetLastError();
@@ -556,7 +558,8 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   rc |= galloc(g, &g->wl, ws * d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
   rc |= galloc(g, &g->wp, ws * c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
   rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->ln_stats, M * 2); rc |= galloc(g, &g->x_h16, M * d);
-  if (!c.weight_split) rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, act_split >= 1 for the trunk
+  if (!c.weight_split || c.cfg_pair) rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, act_split >= 1 for the trunk
+  if (c.weight_split && c.cfg_pair) { rc |= galloc(g, &g->wl_plain, d * d); rc |= galloc(g, &g->wp_plain, (size_t)c.splits * C * d); }
   if (c.act_split == 2) { rc |= galloc(g, &g->att_lo, M * d); rc |= galloc(g, &g->h_lo, M * f); }
   if (c.act_split >= 3) {
     const bool x4m = c.act_split == 4;
@@ -679,7 +682,11 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   if (!dst_f && !dst_h) return fail(-2, "mb_gen_load: unknown checkpoint entry '%s'", name);
   if (numel != want) return fail(-4, "mb_gen_load: '%s' has %zu elements, expected %zu", name, numel, want);
   if (dst_f == g->w_in) mb::transpose_f32(s, data, g->w_in, (int)d, c.bits);       // [d,K] -> [K,d] for the embed kernel
-  else if (dst_h && g->split) mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
+  else if (dst_h && g->split) {
+    mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
+    if (dst_h == g->wl && g->wl_plain) mb::cast_f32_to_h16(s, data, g->wl_plain, numel);
+    if (dst_h == g->wp && g->wp_plain) mb::cast_f32_to_h16(s, data, g->wp_plain, numel);
+  }
   else if (dst_h) {
     mb::cast_f32_to_h16(s, data, dst_h, numel);
     if (g->pair_ok && c.cfg_pair == 2 && sidx >= 0 && sidx < 4 * c.depth && g->w4lo[sidx]) mb::w4lo_from_f32(s, data, g->w4lo[sidx], wrows, wcols, g->w4los[sidx]);
