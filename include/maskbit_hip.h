@@ -182,6 +182,8 @@ int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const
  * (a_scale[m], as mb_layernorm_f4 writes them), W4 / w_scale from mb_w4_from_f32 (per-row scales in the kernel's lane order); both 4-bit
  * operands with the row stride of their fp16 siblings (2*kw bytes, first kw/2 used); kw % 256 == 0, N % 64 == 0. */
 int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
+/* the same layout for the weight's fp16 rounding error W - fp16(W) (operand of the weight-correction pass, mb_gen_cfg.cfg_pair == 2) */
+int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
 int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x4, void* x4_scale,
                     int M, int d, mb_stream stream);
 int mb_gemm_f4lo(int epi, const void* A_hi, const void* A4, const void* a_scale, const void* W, const void* W4, const void* w_scale,

@@ -466,6 +466,13 @@ int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
+int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream) {
+  if (!W || !dst4 || !scale_out || N <= 0 || K <= 0 || N % 64 || K % 4) return fail(-1, "mb_w4lo_from_f32: bad arguments");
+  mb::w4lo_from_f32((hipStream_t)stream, W, (uint8_t*)dst4, N, K, (uint8_t*)scale_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
 int mb_gemm_f4lo(int epi, const void* A_hi, const void* A4, const void* a_scale, const void* W, const void* W4, const void* w_scale, const float* bias,
                  const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
   if (!A_hi || !A4 || !a_scale || !W || !W4 || !w_scale || !bias || epi < 0 || epi > 2 || kw <= 0 || kw % 256) return fail(-1, "mb_gemm_f4lo: bad arguments");

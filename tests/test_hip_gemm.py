@@ -385,3 +385,44 @@ def test_f4_lo_pass_gemm(variant, epi, M, N, K):
         assert e_asked < 3e-5 and rms_true < rms_hi / 4
     else:
         assert float((got - asked).abs().max()) < 2e-3 * max(1.0, float(asked.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(1028, 512, 1024), (771, 1024, 1024)])
+def test_f4_weight_correction_pass(M, N, K):
+    """The weight-correction use of the MX-fp4 pass (mb_gen_cfg.cfg_pair == 2): A4 = e2m1 of the activation VALUES, W4 = e2m1 of the weight's fp16
+    rounding error (mb_w4lo_from_f32).  x.W16^T + x4.Wlo4^T must be several times closer to x.W32^T than x.W16^T alone."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M)
+    st = torch.cuda.current_stream().cuda_stream
+    x = (torch.randn(M, K, device=DEV) * 1.2).half()
+    W32 = torch.randn(N, K, device=DEV) * 0.02
+    W = W32.half()
+    xv = x.double()
+    amax = xv.abs().amax(1, keepdim=True)
+    e = torch.floor(torch.log2(amax)).to(torch.int64) + 127
+    sbyte = (e - 2).clamp(min=0).to(torch.uint8).reshape(M)
+    codes = _f4_codes(xv * 2.0 ** (129 - e).double())
+    x4 = torch.zeros(M, 2 * K, device=DEV, dtype=torch.uint8)
+    x4[:, : K // 2] = (codes[:, 0::2] | (codes[:, 1::2] << 4)).to(torch.uint8)
+    w4 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8)
+    wsb = torch.zeros(N, device=DEV, dtype=torch.uint8)
+    _lib.check(lib.mb_w4lo_from_f32(W32.data_ptr(), N, K, w4.data_ptr(), wsb.data_ptr(), st))
+    torch.cuda.synchronize()
+    n = torch.arange(N, device=DEV)
+    wscale_row = wsb[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)].to(torch.float64)
+    wlo_dec = _f4_decode(w4, K).to(DEV) * (2.0 ** (wscale_row - 127)).reshape(N, 1)
+    wlo = (W32.double() - W.double())
+    rel = float(((wlo_dec - wlo) ** 2).sum() / (wlo ** 2).sum())
+    assert rel < 0.05, f"fp4 copy of the weight rounding error: residual variance ratio {rel:.3f}"
+    bias = torch.zeros(N, device=DEV)
+    res = torch.zeros(M, N, device=DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _lib.check(lib.mb_gemm_f4lo(2, x.data_ptr(), x4.data_ptr(), sbyte.data_ptr(), W.data_ptr(), w4.data_ptr(), wsb.data_ptr(), bias.data_ptr(),
+                                res.data_ptr(), out.data_ptr(), None, M, N, K, 0, st))
+    torch.cuda.synchronize()
+    true = xv @ W32.double().t()
+    plain = xv @ W.double().t()
+    e_corr, e_plain = float((out.double() - true).pow(2).mean().sqrt()), float((plain - true).pow(2).mean().sqrt())
+    print(f"rms error vs fp32 weights: fp16 weights {e_plain:.3e}, with the fp4 correction pass {e_corr:.3e}")
+    assert e_corr < e_plain / 3
