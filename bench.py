@@ -286,8 +286,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "precision": {"timed_mode": args.mode,
                           "strict": "the product default: fp16 MFMA, fp32 accumulate, classifier-free guidance in differential form (the unconditional "
-                                    "stream's operands carried as fp16(x_u - x_c)) + an MX-fp4 correction pass for the QKV / FFN-up weight rounding "
-                                    "in the steps with guidance scale < 1",
+                                    "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u)",
                           "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
             "precision_modes": modes,
             "kernels_note": f"HIP events on the launch stream inside the timed region; generator kernels sampled on every {PROF_EVERY}th forward",

@@ -44,15 +44,16 @@ def test_teacher_forced_mismatch_vs_reference_run(setup):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("act,pair", [(2, 0), (3, 0), (4, 0), (0, 1), (0, 2)])
-def test_every_strict_mode_meets_the_bound(setup, act, pair):
-    """act_split 2 (fp16 lo halves), 3 (e4m3 lo halves), 4 (MX-fp4 lo halves for the LayerNorm outputs); cfg_pair 1 (differential CFG operands)
-    and 2 (+ MX-fp4 weight-rounding correction, the product default at this shape) against the reference's run."""
+@pytest.mark.parametrize("ws,act,pair", [(0, 2, 0), (0, 3, 0), (0, 4, 0), (0, 0, 1), (0, 0, 2), (1, 0, 1)])
+def test_every_strict_mode_meets_the_bound(setup, ws, act, pair):
+    """act_split 2 (fp16 lo halves), 3 (e4m3 lo halves), 4 (MX-fp4 lo halves for the LayerNorm outputs) with independent streams; cfg_pair 1
+    (differential CFG operands: the guided forward of the product default), 2 (+ MX-fp4 correction of the QKV / FFN-up weight rounding), and
+    fp16x2 weights composed with the differential operands (the maximum-precision mode: 4.7e-4) against the reference's run."""
     g, gen, tok, noise = setup
-    gen.weight_split, gen.act_split, gen.cfg_pair = 0, act, pair
+    gen.weight_split, gen.act_split, gen.cfg_pair = ws, act, pair
     bad, tot, per_step, _ = R.teacher_forced(gen, g, noise)
-    gen.act_split, gen.cfg_pair = -1, -1
-    print(f"act_split = {act}, cfg_pair = {pair}: teacher-forced mismatch vs the reference's run {bad}/{tot} = {bad / tot:.2e}; "
+    gen.weight_split, gen.act_split, gen.cfg_pair = 0, -1, -1
+    print(f"weight_split = {ws}, act_split = {act}, cfg_pair = {pair}: teacher-forced mismatch vs the reference's run {bad}/{tot} = {bad / tot:.2e}; "
           f"per 8 steps {[sum(per_step[i:i + 8]) for i in range(0, 64, 8)]}")
     assert bad / tot <= 1e-3
 

@@ -82,9 +82,9 @@ def test_guided_forward_full_size_vs_oracle():
             print(f"cfg_pair = {pair}, scale hint {scale}: rel-Frobenius logit error {rel:.2e}; mean |guided logit error| {e_pair:.4f} (plain fp16 forward: {e_plain:.4f})")
             assert rel < 2e-3 and e_pair < 0.6 * e_plain
     # the plain forward() of a cfg_pair = 2 engine carries the weight-correction pass: closer to the oracle than single fp16
-    m.cfg_pair = 2
+    m.act_split, m.cfg_pair = 0, 2
     w = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV)).cpu()
     e_w, e_0 = float((w - ref).abs().mean()), float((plain.cpu() - ref).abs().mean())
     print(f"plain forward: mean |logit error| single fp16 {e_0:.4f}, with the MX-fp4 weight-rounding correction of QKV / FFN-up {e_w:.4f}")
     assert e_w < e_0
-    m.cfg_pair = -1
+    m.act_split, m.cfg_pair = -1, -1

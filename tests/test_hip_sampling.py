@@ -59,7 +59,7 @@ def test_teacher_forced_token_parity_full_size():
     The CPU oracle drives an 8-step CFG run of the full 12-bit model; the HIP path redoes every step
     from the oracle's inputs and noise.  Mismatch is counted over the positions that are sampled
     (masked) at that step.  Engine modes against the same oracle run:
-      * the product default (differential CFG operands + MX-fp4 weight-rounding correction at this width): must meet the north star's 1e-3;
+      * the product default (guided forward with differential CFG operands at this width): must meet the north star's 1e-3;
       * act_split = 0 (single fp16 operands -- the 10-bit mantissa of the TF32 matmuls the reference's configs enable): ~1.2e-3 on this
         8-step stress schedule (CFG scale up to 5.4 while 30% of the tokens are still masked); context only, bound 3e-3;
       * act_split = 2 (every GEMM activation as an fp16 hi+lo pair) and act_split = 3 (the lo halves and a copy of the weights as e4m3, a
@@ -79,7 +79,7 @@ def test_teacher_forced_token_parity_full_size():
                   guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2, mask_schedule_strategy="arccos",
                   mask_token=64, codebook_splits=2, record=rec)
     drop = torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(DEV)
-    # (act_split, cfg_pair): (-1, -1) = the product default (differential CFG + weight-rounding correction at this shape); (0, 0) = single
+    # (act_split, cfg_pair): (-1, -1) = the product default (differential CFG operands for the guided forward at this shape); (0, 0) = single
     # fp16, reported with a loose bound as context; (2, 0) / (3, 0) = hi + lo activation pairs (fp16 / e4m3 lo halves)
     for act_split, cfg_pair, bound in ((-1, -1, 1e-3), (0, 0, 3e-3), (2, 0, 1e-3), (3, 0, 1e-3)):
         m.act_split, m.cfg_pair = act_split, cfg_pair
