@@ -1,0 +1,25 @@
+"""Run one trunk GEMM shape as the engine's guided forward runs it (CFG pair tiles, B = 64 pairs) a few times: target for rocprofv3 --pmc passes.
+usage: python tools/pair_one.py <qkv|attn_out|ffn_up|ffn_down> [iters]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maskbit_amd import _lib
+lib = _lib.load()
+name = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+epi, N, K = {"qkv": (0, 3072, 1024), "attn_out": (2, 1024, 1024), "ffn_up": (1, 4096, 1024), "ffn_down": (2, 1024, 4096)}[name]
+P = 64 * 257
+M = 2 * P
+dev = torch.device("cuda")
+torch.manual_seed(0)
+A = torch.randn(M, K, device=dev).half(); A[P:] *= 0.01
+W = (torch.randn(N, K, device=dev) * 0.05).half()
+bias = torch.randn(N, device=dev) * 0.1
+res = torch.randn(M, N, device=dev) if epi == 2 else None
+o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
+ptr = lambda t: t.data_ptr() if t is not None else None
+for _ in range(iters):
+    _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(res), ptr(o16), P, N, K, None, None, None, None,
+                                torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
+print("done")
