@@ -142,8 +142,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU per step (default: the C3 batch, 64)")
-    ap.add_argument("--mode", choices=("strict", "fp16"), default="strict",
-                    help="precision mode of the TIMED region: strict (default; the product default, meets <= 1e-3 token mismatch) or single fp16")
+    ap.add_argument("--mode", choices=("strict", "fp16", "wcorr", "max"), default="strict",
+                    help="precision mode of the TIMED region: strict (default; the product default, meets <= 1e-3 token mismatch), single fp16, "
+                         "wcorr (strict + MX-fp4 weight-rounding correction in the second half of the trunk) or max (strict + fp16x2 weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurements: parity replay and the other precision mode")
@@ -177,9 +178,8 @@ def main():
 
     B = args.batch
     gen, tok = build_models(dev)
-    MODES = {"strict": (-1, -1), "fp16": (0, 0)}        # LFQBert (act_split, cfg_pair): (-1, -1) = the product default
-    gen.weight_split = 0
-    gen.act_split, gen.cfg_pair = MODES[args.mode]
+    MODES = {"strict": (0, -1, -1), "fp16": (0, 0, 0), "wcorr": (0, 0, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
+    gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
     torch.manual_seed(1234 + rank)
     plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
                       SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])
@@ -219,14 +219,14 @@ def main():
     # (2) the same workload and the same parity measurement in the other precision mode, one batch.
     modes = None
     if world == 1 and not args.no_modes:
-        other = "fp16" if args.mode == "strict" else "strict"
+        other = "fp16" if args.mode != "fp16" else "strict"
         modes = {args.mode: {"images_per_s": B * world * args.steps / elapsed, "timed": True, "parity": measured_parity(gen)}}
-        gen.act_split, gen.cfg_pair = MODES[other]
+        gen.weight_split, gen.act_split, gen.cfg_pair = MODES[other]
         one_batch(10_000); torch.cuda.synchronize()
         ts = time.perf_counter()
         one_batch(10_001); torch.cuda.synchronize()
         modes[other] = {"images_per_s": B / (time.perf_counter() - ts), "timed": False, "parity": measured_parity(gen)}
-        gen.act_split, gen.cfg_pair = MODES[args.mode]
+        gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
 
     if rank == 0:
         total_images = B * world * args.steps
