@@ -176,7 +176,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc, h16* out_lo = nullptr,
                    const uint8_t* w8 = nullptr, const int* w8e = nullptr, uint8_t* out_lo8 = nullptr, int widx = -1) {
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
-    if (wm && widx / 4 >= c.depth / 2) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4los[widx]; }
+    if (wm) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4los[widx]; }
     else if (x4m) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4s[widx]; ga.out_lo8 = out_lo8; }
     else if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
     else if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
@@ -280,7 +280,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   int rc = 0;
   // measured (tests/diag/weight_subset_study.py): the weight rounding of the SECOND half of the trunk is what costs token parity (exact weights in
   // layers 0..11 alone: no gain; in layers 12..23: most of the gain) -> the correction pass runs in layers >= depth / 2 only
-  const int wfrom = c.depth / 2;
+  const int wfrom = getenv("MASKBIT_AMD_WFROM") ? atoi(getenv("MASKBIT_AMD_WFROM")) : 0;   // first layer with the correction pass (experiments)
   auto x4_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4 : nullptr; };
   auto x4s_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4s : nullptr; };
   auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo) {

@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256) void w4lo_kernel(const float* __restrict__ W, 
   if (lane == 0) red[wv] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float mul = fp4_scale_mul(mx);
-  if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)fp4_scale_byte(mx);
+  const float mul = fp4_scale_mul_nosat(mx);
+  if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)fp4_scale_byte_nosat(mx);
   uint8_t* o = out + (size_t)n * 2 * K;
   for (int k = tid * 4; k < K; k += 1024) {
     const float4 v = *(const float4*)(w + k);

@@ -95,6 +95,17 @@ __device__ __forceinline__ float fp4_scale_mul(float maxlo) {                // 
   const int e = (__float_as_int(maxlo) >> 23) & 0xff;
   return e >= 2 ? __int_as_float((256 - e) << 23) : 0.0f;                    // 2^(129 - e): biased exponent 256 - e in [2, 254]
 }
+// The same for operands whose LARGEST elements must not be clipped (activation values, weight rounding errors: a saturated outlier is a
+// systematic error on exactly the products that dominate the big outputs): 3 < max|v| <= 6, i.e. one binade lower when the mantissa exceeds 1.5.
+__device__ __forceinline__ int fp4_nosat_exp(float amax) {                  // biased exponent E with amax * 2^(129 - E) in (3, 6]
+  const int b = __float_as_int(amax);
+  return ((b >> 23) & 0xff) + (((b & 0x7fffff) > 0x400000) ? 1 : 0);
+}
+__device__ __forceinline__ uint32_t fp4_scale_byte_nosat(float amax) { const int e = fp4_nosat_exp(amax); return (uint32_t)(e >= 2 ? e - 2 : 0); }
+__device__ __forceinline__ float fp4_scale_mul_nosat(float amax) {
+  const int e = fp4_nosat_exp(amax);
+  return (e >= 2 && e <= 254) ? __int_as_float((256 - e) << 23) : 0.0f;
+}
 __device__ __forceinline__ uint32_t fp4_code(float v) {                      // v already scaled; round to nearest e2m1, saturating at 6
   const float a = fminf(fabsf(v), 6.0f);
   int k = ((__float_as_int(a) >> 23) & 0xff) - 127;                          // floor(log2 a) for a >= 1

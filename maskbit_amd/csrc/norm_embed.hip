@@ -61,8 +61,8 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
     }
     if (x4) {
       maxlo = wave_max(maxlo);
-      const float mul = fp4_scale_mul(maxlo);
-      if (lane == 0) *x4s = (uint8_t)fp4_scale_byte(maxlo);
+      const float mul = x4_values ? fp4_scale_mul_nosat(maxlo) : fp4_scale_mul(maxlo);
+      if (lane == 0) *x4s = (uint8_t)(x4_values ? fp4_scale_byte_nosat(maxlo) : fp4_scale_byte(maxlo));
 #pragma unroll
       for (int q = 0; q < nv; ++q) *(uint16_t*)(x4 + q * 128 + lane * 2) = (uint16_t)fp4_pack4(v[q].x, v[q].y, v[q].z, v[q].w, mul);
     }
@@ -143,8 +143,8 @@ __device__ __forceinline__ void pair_store(const float4* xc, const float4* xu, i
   }
   if (x4) {
     amax = wave_max(amax);
-    const float mul = fp4_scale_mul(amax);
-    if (lane == 0) { *x4s_c = (uint8_t)fp4_scale_byte(amax); *x4s_u = 0; }
+    const float mul = fp4_scale_mul_nosat(amax);
+    if (lane == 0) { *x4s_c = (uint8_t)fp4_scale_byte_nosat(amax); *x4s_u = 0; }
 #pragma unroll
     for (int q = 0; q < NV; ++q) *(uint16_t*)(x4 + q * 128 + lane * 2) = (uint16_t)fp4_pack4(xc[q].x, xc[q].y, xc[q].z, xc[q].w, mul);
   }

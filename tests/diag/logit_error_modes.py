@@ -23,8 +23,13 @@ ref = O.lfq_bert_forward(sd, cfg, t, y, torch.zeros(B, dtype=torch.bool))
 msk = (t == cfg.group_codes)
 top2 = ref.topk(2, dim=-1)
 gap_ref = top2.values[..., 0] - top2.values[..., 1]
-for tag, act, pair in [("single fp16", 0, 0), ("W mode (QKV, FFN-up weights)", 0, 2), ("hi+lo fp16 (2)", 2, 0), ("hi+lo e4m3 (3)", 3, 0), ("fp16x2 weights", -2, 0)]:
-    if act == -2:
+for tag, act, pair in [("single fp16", 0, 0), ("W mode (QKV, FFN-up weights)", 0, 2), ("exact qkv + w1 weights (host-rounded rest)", -3, 0), ("hi+lo fp16 (2)", 2, 0), ("hi+lo e4m3 (3)", 3, 0), ("fp16x2 weights", -2, 0)]:
+    if act == -3:
+        sd2 = {k: (v.half().float() if (v.dim() == 2 and k.startswith("transformer.layers.") and not ("in_proj_weight" in k or "net.0.weight" in k)) else v) for k, v in sd.items()}
+        m = hip_generator(cfg, sd2)
+        m.weight_split, m.act_split, m.cfg_pair = 1, 0, 0
+    elif act == -2:
+        m = hip_generator(cfg, sd)
         m.weight_split, m.act_split, m.cfg_pair = 1, 0, 0
     else:
         m.weight_split, m.act_split, m.cfg_pair = 0, act, pair
