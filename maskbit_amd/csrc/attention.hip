@@ -19,6 +19,7 @@
 // even mask, so the two slots of a 32-byte tr-read segment stay adjacent) on the DMA source address
 // and on the reads.  The tr reads are inline asm (no builtin), software-pipelined one k-block ahead
 // with counted lgkmcnt waits.
+#include <cstdlib>
 #include <type_traits>
 
 #include "mb_kernels.h"
@@ -34,9 +35,12 @@ constexpr int ATT_MAXQT = (ATT_NKT + ATT_NW - 1) / ATT_NW;   // q-tiles per wave
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // AUX (CFG pair attention, mb_kernels.h attention_pair): 1 = also store the fp32 output rows to aux (conditional sequences), 2 = subtract the
-// conditional twin's fp32 rows (aux) and store the DIFFERENCE as the fp16 output (unconditional sequences, sq_off = P)
+// conditional twin's fp32 rows (aux) and store the DIFFERENCE as the fp16 output (unconditional sequences, sq_off = P).
+// AUX = 3: both streams of a (sequence pair, head) in ONE workgroup of 8 waves -- waves 0-3 the conditional sequence, waves 4-7 its unconditional
+// twin (sq + sq_off), each half with its own K / V image in LDS (4 x 36 KiB) -- and the conditional wave hands its fp32 output tile to its twin wave
+// through a 4 KiB LDS mailbox (4 x 36 + 4 x 4 KiB = all 160 KiB): no aux traffic, one launch.
 template <int DH, int AUX = 0>
-__global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
+__global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
                                                           int N, int d, int heads, float scale_log2e, float* __restrict__ aux = nullptr, int sq_off = 0) {
   constexpr int ROW = DH * 2;            // bytes per K / V row
   constexpr int SL = DH / 8;             // 16-byte slots per row (8 or 4)
@@ -44,14 +48,23 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
   constexpr int NT = DH / 16;            // output dh tiles
   constexpr int RPI = 64 / SL;           // rows covered by one 1 KiB DMA instruction (8 or 16)
   constexpr int NINST = ATT_NP / RPI;    // DMA instructions per operand (36 or 18)
-  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_NP * ROW];
-  char* Ks = smem;
-  char* Vs = smem + ATT_NP * ROW;
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  char* smem;
+  if constexpr (AUX == 3) smem = dyn_smem;
+  else {
+    __shared__ __attribute__((aligned(16))) char static_smem[2 * ATT_NP * ROW];
+    smem = static_smem;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = AUX == 3 ? (wave8 & (ATT_NW - 1)) : wave8;      // wave index inside its stream
+  const int strm = AUX == 3 ? (wave8 >> 2) : 0;                   // 0 = conditional, 1 = unconditional half of the workgroup
+  char* Ks = smem + strm * 2 * ATT_NP * ROW;
+  char* Vs = Ks + ATT_NP * ROW;
+  float* const mbox = (float*)(dyn_smem + 4 * ATT_NP * ROW) + wave * (NT * 64 * 4);   // AUX 3: this wave pair's mailbox (NT x 64 lanes x f32x4)
   const int sq0 = blockIdx.x / heads, h = blockIdx.x - sq0 * heads;
-  const int sq = sq0 + sq_off;
+  const int sq = sq0 + (AUX == 3 ? strm * sq_off : sq_off);
   const size_t rs = (size_t)3 * d;                                   // qkv row stride (elements)
   const h16* base = qkv + (size_t)sq * N * rs + h * DH;
 
@@ -92,7 +105,11 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 #pragma unroll
   for (int i = 0; i < ATT_MAXQT; ++i) {
     const int qt = wave + ATT_NW * i;
-    if (qt >= nqt) break;
+    if (AUX != 3 && qt >= nqt) break;
+    if (AUX == 3 && qt >= nqt) {          // the two hand-off barriers of this round are taken by every wave of the workgroup
+      __syncthreads(); __syncthreads();
+      continue;
+    }
     // ---- S^T tiles: s[kt][r] = S[q = l15][key = kt*16 + g*4 + r]
     f32x4 s[ATT_NKT];
 #pragma unroll
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
     sum += __shfl_xor(sum, 32);
     float inv = 1.0f / sum;
     asm volatile("" : "+v"(inv));          // every cross-lane op of the softmax has retired before the asm LDS reads start
-    f32x4 twin[DH / 16];                   // AUX 2: the conditional twin's output rows, requested now, used after the PV loop
+    f32x4 twin[DH / 16] = {};              // AUX 2: the conditional twin's output rows, requested now, used after the PV loop (AUX 3: from the mailbox)
     if constexpr (AUX == 2) {
       const int qq = min(qt * 16 + l15, N - 1);
 #pragma unroll
@@ -201,6 +218,18 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
     static_assert(NKB <= 10, "add steps");
     // ---- o[nt][r] = O[q = l15][dh = nt*16 + g*4 + r]
     const int q = qt * 16 + l15;
+    if constexpr (AUX == 3) {            // hand the conditional tile to the twin wave (same query tile, same lane mapping)
+      if (strm == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *(f32x4*)(mbox + (nt * 64 + lane) * 4) = f32x4{o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+      }
+      __syncthreads();
+      if (strm == 1) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) twin[nt] = *(const f32x4*)(mbox + (nt * 64 + lane) * 4);
+      }
+      __syncthreads();                   // the mailbox may be overwritten by the next round
+    }
     if (q < N) {
       const size_t ooff = ((size_t)sq * N + q) * d + h * DH;
 #pragma unroll
@@ -208,6 +237,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         f32x4 v = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
         if constexpr (AUX == 1) *(f32x4*)(aux + ((size_t)sq0 * N + q) * d + h * DH + nt * 16 + g * 4) = v;
         if constexpr (AUX == 2) v = v - twin[nt];
+        if constexpr (AUX == 3) { if (strm == 1) v = v - twin[nt]; }
         const h16x4 hi = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
         *(h16x4*)(out + ooff + nt * 16 + g * 4) = hi;
         if (out_lo)                                             // split activations: the fp16 lo halves v - fp16(v)
@@ -478,7 +508,13 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
   if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   dim3 grid(P * heads), block(64 * ATT_NW);
-  if (dh == 64) {
+  static const bool one_launch = !getenv("MASKBIT_AMD_ATT_PAIR_2L") || atoi(getenv("MASKBIT_AMD_ATT_PAIR_2L")) == 0;   // A/B switch (experiments)
+  if (dh == 64 && one_launch) {
+    constexpr int LDS = 4 * ATT_NP * 128 + ATT_NW * 4 * 64 * 16;      // 4 K/V images + 4 mailboxes = 160 KiB
+    static bool configured = false;
+    if (!configured) { (void)hipFuncSetAttribute((const void*)attention_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); configured = true; }
+    hipLaunchKernelGGL((attention_kernel<64, 3>), grid, dim3(128 * ATT_NW), LDS, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P);
+  } else if (dh == 64) {
     hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);
     hipLaunchKernelGGL((attention_kernel<64, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
   } else {
