@@ -70,9 +70,9 @@ template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>   //
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   static_assert(!PAIR || (SEQ && XP != 4), "pair tiles are sequence-aligned (fp16 or fp4 lo pass)");
-  // The fp32+residual epilogue does not fit the 256-VGPR budget together with the next-tile prefetch state (it spilled
-  // inside the K loop): those GEMMs run one tile per workgroup, everything else walks the tile list persistently.
-  constexpr bool PERSIST = EPI != EPI_RES_F32 && XP != 4;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
+  // Every fp16 / fp4 instance walks the tile list persistently (round 1 kept the fp32+residual epilogue at one tile per workgroup: it spilled
+  // VGPRs inside the K loop then; with the present epilogue it does not: 244-248 VGPRs, no scratch).
+  constexpr bool PERSIST = XP != 4;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
   constexpr int AUX = 0;   // DMA cache policy: default beats nt (-14 %) and sc1 (-6 %) here, sc0 is equal (measured)
   constexpr int BM = 32 * MT, MH = MT / 2;
   constexpr int AH_ROWS = BM / 2;
@@ -615,8 +615,10 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
   }
   const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = a.N / 256;
   static const bool f4_persist = !getenv("MASKBIT_AMD_F4_PERSIST") || atoi(getenv("MASKBIT_AMD_F4_PERSIST")) != 0;   // A/B switch (experiments)
+  static const bool res_persist = !getenv("MASKBIT_AMD_RES_PERSIST") || atoi(getenv("MASKBIT_AMD_RES_PERSIST")) != 0;   // A/B switch (experiments)
   if (XP == 5 && !f4_persist) persistent = false;
-  const int grid = (EPI != EPI_RES_F32 && XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
+  if (EPI == EPI_RES_F32 && !res_persist) persistent = false;
+  const int grid = (XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
   hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
