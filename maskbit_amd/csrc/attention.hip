@@ -508,7 +508,10 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
   if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   dim3 grid(P * heads), block(64 * ATT_NW);
-  static const bool one_launch = !getenv("MASKBIT_AMD_ATT_PAIR_2L") || atoi(getenv("MASKBIT_AMD_ATT_PAIR_2L")) == 0;   // A/B switch (experiments)
+  // One-launch variant (AUX = 3): measured equal on average (116-120 us against 117-123 us for the two launches, B = 64 pairs) -- what it saves in aux traffic
+  // it loses by running both halves' K/V staging and compute in lockstep (two 72 KiB workgroups per CU overlap one's staging with the other's compute;
+  // one 160 KiB workgroup cannot) -- and with a worse tail (a sampled run averaged 199 us).  Kept behind a switch.
+  static const bool one_launch = getenv("MASKBIT_AMD_ATT_PAIR_1L") && atoi(getenv("MASKBIT_AMD_ATT_PAIR_1L")) != 0;
   if (dh == 64 && one_launch) {
     constexpr int LDS = 4 * ATT_NP * 128 + ATT_NW * 4 * 64 * 16;      // 4 K/V images + 4 mailboxes = 160 KiB
     static bool configured = false;
