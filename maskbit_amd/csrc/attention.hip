@@ -41,7 +41,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // through a 4 KiB LDS mailbox (4 x 36 + 4 x 4 KiB = all 160 KiB): no aux traffic, one launch.
 template <int DH, int AUX = 0>
 __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
-                                                          int N, int d, int heads, float scale_log2e, float* __restrict__ aux = nullptr, int sq_off = 0) {
+                                                          int N, int d, int heads, float scale_log2e, float* __restrict__ aux = nullptr, int sq_off = 0,
+                                                          uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr) {
+  // out4 / out4s (AUX 1, optional): e2m1 of the conditional output VALUES (row stride 2d bytes) with one E8M0 scale byte per (row, head) --
+  // out4s[row][d / 64], DH = 64 -- the token operand of the out-proj GEMM's weight-correction pass
   constexpr int ROW = DH * 2;            // bytes per K / V row
   constexpr int SL = DH / 8;             // 16-byte slots per row (8 or 4)
   constexpr int KS = DH / 32;            // k-steps of the QK^T MFMA
@@ -229,6 +232,25 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
         for (int nt = 0; nt < NT; ++nt) twin[nt] = *(const f32x4*)(mbox + (nt * 64 + lane) * 4);
       }
       __syncthreads();                   // the mailbox may be overwritten by the next round
+    }
+    if constexpr (AUX == 1 && DH == 64) {
+      if (out4) {                          // block (row, head) = this lane's 16 values x its 4 lane groups
+        float am = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(o[nt][r] * inv));
+        am = fmaxf(am, __shfl_xor(am, 16));
+        am = fmaxf(am, __shfl_xor(am, 32));
+        const float mul = fp4_scale_mul_nosat(am);
+        if (q < N) {
+          const size_t row = (size_t)sq * N + q;
+          if (g == 0) out4s[row * (d / 64) + h] = (uint8_t)fp4_scale_byte_nosat(am);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            *(uint16_t*)(out4 + row * 2 * d + (h * DH + nt * 16 + g * 4) / 2) = (uint16_t)fp4_pack4(o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv, mul);
+        }
+      }
     }
     if (q < N) {
       const size_t ooff = ((size_t)sq * N + q) * d + h * DH;
@@ -503,7 +525,7 @@ void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width) {
   hipLaunchKernelGGL(qkv_e4m3_round_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, qkv, rows, width);
 }
 
-int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads) {
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads, uint8_t* out4, uint8_t* out4s) {
   const int dh = d / heads;
   if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
@@ -512,15 +534,16 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
   // it loses by running both halves' K/V staging and compute in lockstep (two 72 KiB workgroups per CU overlap one's staging with the other's compute;
   // one 160 KiB workgroup cannot) -- and with a worse tail (a sampled run averaged 199 us).  Kept behind a switch.
   static const bool one_launch = getenv("MASKBIT_AMD_ATT_PAIR_1L") && atoi(getenv("MASKBIT_AMD_ATT_PAIR_1L")) != 0;
-  if (dh == 64 && one_launch) {
+  if (dh == 64 && one_launch && !out4) {
     constexpr int LDS = 4 * ATT_NP * 128 + ATT_NW * 4 * 64 * 16;      // 4 K/V images + 4 mailboxes = 160 KiB
     static bool configured = false;
     if (!configured) { (void)hipFuncSetAttribute((const void*)attention_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); configured = true; }
     hipLaunchKernelGGL((attention_kernel<64, 3>), grid, dim3(128 * ATT_NW), LDS, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P);
   } else if (dh == 64) {
-    hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);
+    hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0, out4, out4s);
     hipLaunchKernelGGL((attention_kernel<64, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
   } else {
+    if (out4) return -1;                  // the fp4 output exists for head dimension 64
     hipLaunchKernelGGL((attention_kernel<32, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);
     hipLaunchKernelGGL((attention_kernel<32, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
   }

@@ -127,7 +127,8 @@ struct mb_gen {
   float* att_aux = nullptr;
   float* logits_tmp = nullptr;                          // guided forwards over more pairs than one pass holds
   h16 *wl_plain = nullptr, *wp_plain = nullptr;         // fp16x2 weights + pair forward: single-fp16 copies of the two head weights (the head takes hi + lo INPUTS there)
-  std::vector<uint8_t*> w4lo, w4los;                                                     // [4 * layer + {qkv, -, 1, -}]
+  std::vector<uint8_t*> w4lo, w4los;                                                     // [4 * layer + {qkv, o, 1, 2}]
+  uint8_t *att4 = nullptr, *att4s = nullptr, *h4 = nullptr, *h4s = nullptr;              // e2m1 of the conditional attention outputs / FFN hiddens + block scales
   int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
   // loop state for mb_sample
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
@@ -283,10 +284,11 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   const int wfrom = getenv("MASKBIT_AMD_WFROM") ? atoi(getenv("MASKBIT_AMD_WFROM")) : 0;   // first layer with the correction pass (experiments)
   auto x4_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4 : nullptr; };
   auto x4s_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4s : nullptr; };
-  auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo) {
+  auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo,
+                   const uint8_t* a4 = nullptr, const uint8_t* a4s = nullptr) {
     GemmArgs ga{A, W, bias, res, res, out16, M, Nout, g->split ? 2 * K : K, 0, g->split ? K : 0, g->sc(widx)};   // fp16x2 weights: A swept twice
     ga.pair_rows = P;
-    if (lo) { ga.K = K + K / 4; ga.kw = K; ga.A4 = g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4los[widx]; }
+    if (lo) { ga.K = K + K / 4; ga.kw = K; ga.A4 = a4 ? a4 : g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = a4s ? a4s : g->x4s; ga.w_scale = g->w4los[widx]; }
     return ga;
   };
   {
@@ -302,17 +304,19 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wmode && l >= wfrom);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
     if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads); }
+    const bool wl = wmode && l >= wfrom;
+    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads, wl ? g->att4 : nullptr, wl ? g->att4s : nullptr); }
     { ProfScope p("gemm_attn_out", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, false);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl, g->att4, g->att4s);
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     { ProfScope p("layernorm", s, true); rc |= layernorm_pair(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_h16, g->ln_stats, P, d, x4_for(l), x4s_for(l)); }
     { ProfScope p("gemm_ffn_up", s, true);
-      GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, wmode && l >= wfrom);
+      GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, wl);
+      if (wl) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
       rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
     { ProfScope p("gemm_ffn_down", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, false);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl, g->h4, g->h4s);
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     { ProfScope p("layernorm", s, true);
@@ -599,12 +603,22 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (g->pair_ok) {
     rc |= galloc(g, &g->att_aux, (M / 2) * d);
     if (c.cfg_pair == 2) {
-      rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, M + 256);
-      if (!rc) { (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, M + 256); }
+      // x4s: per-row bytes in the plain forward (M), block bytes [row][d / 64] of the conditional rows in the pair forward (M / 2 * d / 64)
+      const size_t x4s_n = std::max<size_t>(M + 256, (M / 2) * (d / 64) + 256);
+      rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, x4s_n);
+      rc |= galloc(g, &g->att4, (M / 2) * 2 * d); rc |= galloc(g, &g->att4s, (M / 2) * (d / 64) + 256);
+      rc |= galloc(g, &g->h4, (M / 2) * 2 * f); rc |= galloc(g, &g->h4s, (M / 2) * (f / 64) + 256);
+      if (!rc) {
+        (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, x4s_n);
+        (void)hipMemset(g->att4, 0, (M / 2) * 2 * d); (void)hipMemset(g->att4s, 0, (M / 2) * (d / 64) + 256);
+        (void)hipMemset(g->h4, 0, (M / 2) * 2 * f); (void)hipMemset(g->h4s, 0, (M / 2) * (f / 64) + 256);
+      }
       g->w4lo.assign((size_t)4 * c.depth, nullptr); g->w4los.assign((size_t)4 * c.depth, nullptr);
       for (int l = 0; l < c.depth; ++l) {
         rc |= galloc(g, &g->w4lo[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4los[4 * l], 3 * d);
+        rc |= galloc(g, &g->w4lo[4 * l + 1], 2 * d * d); rc |= galloc(g, &g->w4los[4 * l + 1], d);
         rc |= galloc(g, &g->w4lo[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4los[4 * l + 2], f);
+        rc |= galloc(g, &g->w4lo[4 * l + 3], 2 * d * f); rc |= galloc(g, &g->w4los[4 * l + 3], d);
       }
     }
   }

@@ -53,6 +53,17 @@ __device__ __forceinline__ f32x4 mma_f4(f32x4 c, const h16x16& w, const h16x16& 
                                                           __builtin_shufflevector(xv, xv, 4, 5, 6, 7, -1, -1, -1, -1), c, 4, 4, SW, wsc, SX, xsc);
 }
 
+// The same with per-(row, 64 columns) block scales of the token operand (pair tiles): the lane's scale register of this m-tile holds the block
+// of k-step 0 in byte 0 and the block of k-step 1 in byte 2 (gemm_ht_kernel shifts the loaded dword by the lane group's block).
+template <int SW>
+__device__ __forceinline__ f32x4 mma_f4bs(f32x4 c, const h16x16& w, const h16x16& x, int wsc, int xsc) {
+  const i32x8 wv = __builtin_bit_cast(i32x8, w), xv = __builtin_bit_cast(i32x8, x);
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 0, 1, 2, 3, -1, -1, -1, -1),
+                                                        __builtin_shufflevector(xv, xv, 0, 1, 2, 3, -1, -1, -1, -1), c, 4, 4, SW, wsc, 0, xsc);
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 4, 5, 6, 7, -1, -1, -1, -1),
+                                                          __builtin_shufflevector(xv, xv, 4, 5, 6, 7, -1, -1, -1, -1), c, 4, 4, SW, wsc, 2, xsc);
+}
+
 // SEQ = true: "sequence-aligned" tiles.  The trunk's M is nb*257 (256 image tokens + the class token per
 // sequence) and 257 is prime, so every ordinary tiling leaves a nearly empty CU round.  With SEQ a tile covers exactly
 // one sequence: 256 rows through the regular MT = 8 machinery plus the class-token row as a 17th, one-row m-tile whose
@@ -94,6 +105,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   constexpr bool F8 = XP == 4;                         // e4m3 lo pass: K-tiles >= nka come from (A8, W8), 128 K-elements per tile
   constexpr bool F4 = XP == 5;                         // MX-fp4 lo pass: K-tiles >= nka come from (A4, W4), 256 K-elements per tile, fp16 fragment reads
   constexpr bool LO = F8 || F4;
+  // pair tiles + fp4 pass: the token operand's scales are per (row, 64 K-elements) -- a_scale[row][kw / 64] -- and reloaded per lo K-tile (one dword
+  // per m-tile = the tile's 4 blocks), so that producers whose rows span several workgroups (attention heads, FFN-up column tiles) can scale locally
+  constexpr bool BS = PAIR && F4;
   static_assert(!F4 || MT == 8, "the fp4 lo pass is written for the 256-row machinery");
   // Sequence-aligned e4m3 kernels: the DMA of an e4m3 K-tile permutes the 16-byte chunks of a row on the way into LDS (position ks*4+g
   // receives chunk 2g+ks, the 32 bytes lane group g feeds to the K = 128 MFMA), so the fragment reads are the fp16 ones -- reading
@@ -208,6 +222,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // MX-fp4 pass: per-lane E8M0 scale bytes of this tile's rows -- wsc: the 4 weight rows (n-tiles) of this lane, xsc0 / xsc1: the 4 + 4 token rows
   // (m-tiles of the two A halves), xscc: the class-token row.  Loaded once per tile by plain loads that complete under the prologue's wait.
   int wsc = 0, xsc0 = 0, xsc1 = 0, xscc = 0;
+  int xs_cur[5] = {}, xs_nxt[5] = {};       // BS: block scales of this lane's 4 conditional m-tiles + the class row, current / next lo K-tile
+  uint32_t bs_off[5] = {};                  // BS: byte offsets of those rows' scale records
+  const int bs_shift = (g >> 1) * 8;        // BS: lane groups 0,1 read the first 64 K-elements of a k-step, 2,3 the second
   const int xbase = wm * (8 * MT) * 128;              // this wave's rows inside an A half-tile
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
 
@@ -232,7 +249,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     return MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 8, 9, 10, 11, 12, 13, 14, 15), __builtin_shufflevector(x, x, 8, 9, 10, 11, 12, 13, 14, 15), c);
   };
 #define MB_F4_ONE(AH, BH, I, N)                                                                     \
-  if constexpr (F4) acc[(BH) * 2 + (N)][(AH) * MH + (I)] =                                          \
+  if constexpr (BS) acc[(BH) * 2 + (N)][(AH) * MH + (I)] =                                          \
+      mma_f4bs<(BH) * 2 + (N)>(acc[(BH) * 2 + (N)][(AH) * MH + (I)], wb[BH][N], xa[I], wsc, xs_cur[I]);  \
+  else if constexpr (F4) acc[(BH) * 2 + (N)][(AH) * MH + (I)] =                                     \
       mma_f4<(BH) * 2 + (N), (I)>(acc[(BH) * 2 + (N)][(AH) * MH + (I)], wb[BH][N], xa[I], wsc, (AH) ? xsc1 : xsc0);
 #define MB_MMA_END                                                                                  \
   __builtin_amdgcn_s_setprio(0);                                                                    \
@@ -266,7 +285,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     int lo_ = lane; asm volatile("" : "+v"(lo_));
     const int r15 = lo_ & 15;
     wsc = ((const int*)a.w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
-    if (PAIR) {
+    if (BS) {
+      const uint32_t nb = (uint32_t)(a.kw >> 6);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bs_off[i] = (uint32_t)(p.m0 + wm * 64 + i * 16 + r15) * nb;
+      bs_off[4] = (uint32_t)p.cls * nb;            // (lane row 1 of the class m-tile = the difference row: takes no part in the lo pass)
+    } else if (PAIR) {
       const uint8_t* sp = a.a_scale + p.m0 + wm * 64 + r15;
 #pragma unroll
       for (int i = 0; i < 8; ++i) sb[i] = sp[(i >> 2) * a.pair_rows + (i & 3) * 16];
@@ -278,7 +302,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       if (SEQ) xscc = a.a_scale[p.m0 + 256];
     }
   };
+  // BS: request the 4 block scales of lo K-tile kt for this lane's rows (inline asm: counted by the K loop's own vmcnt waits, which the registers are tied through)
+  auto bs_issue = [&](int kt) {
+    const uint8_t* base = a.a_scale + 4 * kt;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) asm volatile("global_load_dword %0, %1, %2" : "=v"(xs_nxt[i]) : "v"(bs_off[i]), "s"(base) : "memory");
+  };
   auto scales_pack = [&]() {
+    if (BS) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc) :: "memory"); asm volatile("" : "+v"(wsc)); return; }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc), "+v"(xscc), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]) :: "memory");
     xsc0 = sb[0] | (sb[1] << 8) | (sb[2] << 16) | (sb[3] << 24);
     xsc1 = sb[4] | (sb[5] << 8) | (sb[6] << 16) | (sb[7] << 24);
@@ -318,13 +349,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3 */ \
       /* (no reads).  Every half-tile is re-filled >= 2 phases after its last reader; K-tile 1 came with the prologue. */ \
       const bool n1 = t >= 1 && t + 1 < nk, n2 = t + 2 < nk; \
+      if (BS && f8t) { _Pragma("unroll") for (int i = 0; i < 5; ++i) xs_cur[i] = (int)((uint32_t)xs_nxt[i] >> bs_shift); }   /* landed under the previous K-tile's counted wait */ \
+      if (BS && t + 1 >= nka && t + 1 < nk) bs_issue(t + 1 - nka); \
       /* ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0] */ \
       MB_LOAD_B(0) MB_LOAD_A(0)                          /* B first: the first MFMAs need both B fragments and only xa[0] */ \
       h16x16 xe; \
       if (SEQ && wm == 0) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       MB_SYNC_L() \
       if (SEQ && wm == 0) { \
-        if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<0, 0>(acce[0], wb[0][0], xe, wsc, xscc); acce[1] = mma_f4<1, 0>(acce[1], wb[0][1], xe, wsc, xscc); } } \
+        if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<0>(acce[0], wb[0][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<1>(acce[1], wb[0][1], xe, wsc, xs_cur[4]); } } \
+        else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<0, 0>(acce[0], wb[0][0], xe, wsc, xscc); acce[1] = mma_f4<1, 0>(acce[1], wb[0][1], xe, wsc, xscc); } } \
         else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, true); } \
         else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, false); } \
         /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
@@ -339,7 +373,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       if (n1 && !(PAIR && LO && t + 1 >= nka)) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
       if (SEQ && wm == 1) { \
-        if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<2, 0>(acce[0], wb[1][0], xe, wsc, xscc); acce[1] = mma_f4<3, 0>(acce[1], wb[1][1], xe, wsc, xscc); } } \
+        if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<2>(acce[0], wb[1][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<3>(acce[1], wb[1][1], xe, wsc, xs_cur[4]); } } \
+        else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<2, 0>(acce[0], wb[1][0], xe, wsc, xscc); acce[1] = mma_f4<3, 0>(acce[1], wb[1][1], xe, wsc, xscc); } } \
         else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, true); } \
         else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, false); } \
         /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
@@ -356,14 +391,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* stores stay in flight until the wait of K-tile 1. */ \
       if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); dma_b(cur, t + 2, 0); } \
       if (t >= 1) { \
-        if (n2) {                                        /* A0, B1, (X,) B0 of K-tile t+2 may stay in flight */ \
+        if (BS) {                                        /* the next lo K-tile's block scales (requested in phase 0) are older than those: tied through */ \
+          if (n2) { \
+            if (wave == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) :: "memory"); \
+            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) :: "memory"); \
+          } else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) :: "memory"); \
+        } else if (n2) {                                 /* A0, B1, (X,) B0 of K-tile t+2 may stay in flight */ \
           if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
       } \
       MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 0) } MB_MMA_END \
       if (F8) asm volatile("" :: "v"(sc_ab)); \
-      if (F4) asm volatile("" :: "v"(wsc), "v"(xsc0), "v"(xsc1), "v"(xscc)); \
+      if (F4 && !BS) asm volatile("" :: "v"(wsc), "v"(xsc0), "v"(xsc1), "v"(xscc)); \
+      if (BS) asm volatile("" :: "v"(wsc)); \
     }
     {
       int t = 0;
@@ -486,6 +527,29 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     if (has_next) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (PAIR && EPI == EPI_GELU_H16) {
+      if (a.out4) {
+        // e2m1 copy of the conditional GELU outputs for the next GEMM's weight-correction pass: this wave's 64 columns of a row are one scale block
+        // (4 n-tiles x 4 lane groups x 4 columns); class-token rows are skipped (their scale bytes stay 0)
+        const uint32_t nb = (uint32_t)a.N >> 6, blk = (uint32_t)(n0 >> 6) + wn;
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+          float am = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(acc[nt][i][e]));
+          am = fmaxf(am, __shfl_xor(am, 16));
+          am = fmaxf(am, __shfl_xor(am, 32));
+          const float mul = fp4_scale_mul_nosat(am);
+          const uint32_t row = (uint32_t)row_of(i);
+          if (ge == 0) a.out4_scale[row * nb + blk] = (uint8_t)fp4_scale_byte_nosat(am);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            *(uint16_t*)(a.out4 + (size_t)row * 2 * a.N + (col_of(i, nt) >> 1)) = (uint16_t)fp4_pack4(acc[nt][i][0], acc[nt][i][1], acc[nt][i][2], acc[nt][i][3], mul);
+        }
+      }
     }
     if (EPI == EPI_RES_F32) {
       // fp32 + residual: two sweeps over the rows, each covering ONE full 128-byte line per row (n-tiles 2p, 2p+1), the

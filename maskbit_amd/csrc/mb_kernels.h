@@ -67,6 +67,11 @@ struct GemmArgs {
   // rows: out_c = f(A_c . W), out_u = f(A_c . W + A_delta . W) -- with the GELU epilogue the unconditional rows receive gelu(u) - gelu(c),
   // i.e. the next GEMM's difference operand.  See gemm_ht.hip and DESIGN.md "Precision".
   int pair_rows = 0;
+  // pair tiles + fp4 pass: a_scale is a_scale[row][kw / 64] (one E8M0 byte per 64 K-elements of a conditional row).  GELU epilogue (pair tiles):
+  // out4 / out4_scale (optional) receive e2m1 of the conditional OUTPUT values (row stride 2N bytes) and their block bytes out4_scale[row][N / 64],
+  // the token operand of the next GEMM's weight-correction pass; class-token rows are left untouched (their bytes stay 0: no correction).
+  uint8_t* out4 = nullptr;
+  uint8_t* out4_scale = nullptr;
 };
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   // 0, or -1: lo-pass request outside the half-tile kernel's shapes
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -86,7 +91,8 @@ void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const flo
                     uint8_t* x4 = nullptr, uint8_t* x4_scale = nullptr, bool x4_values = false);   // x4: e2m1 lo halves -- or, x4_values, the values -- (row stride 2d bytes) + one E8M0 byte per row   // x8: e4m3(lo * 2^15), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
 
 // "CFG pair" forms (hidden = 768 / 1024 only; -1 otherwise): rows r < P are conditional, r + P their unconditional twins.  Writes
-// x_h16[r] = fp16(x_c), x_h16[r + P] = fp16(x_u - x_c), both rows' {mean, rstd}; optional x4 / x4s: e2m1 of the conditional VALUES + scale bytes.
+// x_h16[r] = fp16(x_c), x_h16[r + P] = fp16(x_u - x_c), both rows' {mean, rstd}; optional x4 / x4s: e2m1 of the conditional VALUES + their scale
+// bytes in the pair GEMM's block layout x4s[r][d / 64].
 int layernorm_pair(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps, h16* x_h16, float* stats, int P, int d,
                    uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
 int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
@@ -120,7 +126,8 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
 // store their fp32 output rows to `aux` [P*N, d]; the unconditional ones then write out[r + P*N] = fp16(att_u - att_c) (difference operand of
 // the out-proj pair GEMM).  Short-sequence kernel only (N <= 288): returns -1 otherwise.
 void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width);   // diagnostic: Q/K/V rows -> e4m3 values (per token, head, operand scale), in place; width % 256 == 0
-int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads);
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads, uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);
+// (out4 / out4s, head dimension 64 only: e2m1 of the conditional output values, row stride 2d bytes, + E8M0 scale bytes out4s[row][d / 64])
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 // ---- "CFG pair" LayerNorm (differential classifier-free guidance, DESIGN.md "Precision"): one wave normalises row r of the conditional
 // stream and its unconditional twin r + P together and writes  x_h16[r] = fp16(x_c),  x_h16[r + P] = fp16(x_u - x_c)  -- the operands of
 // the pair GEMM (gemm_ht.hip): the rounding error of x_c is then common to both streams and cancels in (c - u).  Row statistics of both rows
-// go to `stats` (the residual GEMMs re-derive LayerNorm(y) from them).  x4 / x4s (optional, "W mode"): e2m1(x_c * 2^s) of the conditional row
-// with its E8M0 scale byte (the unconditional row's byte is 0: its products vanish) for the weight-rounding correction pass.
+// go to `stats` (the residual GEMMs re-derive LayerNorm(y) from them).  x4 / x4s (optional, weight-correction pass): e2m1(x_c * 2^s) of the
+// conditional row and its E8M0 scale byte in the pair GEMM's block layout x4s[row][d / 64] (the difference rows take no part in that pass).
 template <int NV>
 __device__ __forceinline__ float2 ln_normalize(float4* v, int d, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int lane) {
   float s = 0.f;
@@ -144,7 +144,8 @@ __device__ __forceinline__ void pair_store(const float4* xc, const float4* xu, i
   if (x4) {
     amax = wave_max(amax);
     const float mul = fp4_scale_mul_nosat(amax);
-    if (lane == 0) { *x4s_c = (uint8_t)fp4_scale_byte_nosat(amax); *x4s_u = 0; }
+    // block-scale layout of the pair GEMM (a_scale[row][d / 64]): one scale for the whole row, replicated into its d / 64 = 4 * NV block bytes
+    if (lane < NV) ((uint32_t*)x4s_c)[lane] = fp4_scale_byte_nosat(amax) * 0x01010101u;
 #pragma unroll
     for (int q = 0; q < NV; ++q) *(uint16_t*)(x4 + q * 128 + lane * 2) = (uint16_t)fp4_pack4(xc[q].x, xc[q].y, xc[q].z, xc[q].w, mul);
   }
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void ln_pair_kernel(const float* __restrict__ 
   const float2 sc = ln_normalize<NV>(vc, d, gamma, beta, eps, lane), su = ln_normalize<NV>(vu, d, gamma, beta, eps, lane);
   if (stats && lane == 0) { *(float2*)(stats + 2 * (size_t)row) = sc; *(float2*)(stats + 2 * (size_t)(row + P)) = su; }
   pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
-                 x4s ? x4s + row : nullptr, x4s ? x4s + row + P : nullptr);
+                 x4s ? x4s + (size_t)row * (d / 64) : nullptr, nullptr);
 }
 
 // pair operands from fp32 rows that already exist (the embedding LayerNorm's output, the first residual): x32 [2P, d] -> x_h16 as above
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void pairify_kernel(const float* __restrict__ 
 #pragma unroll
   for (int q = 0; q < NV; ++q) { vc[q] = *(const float4*)(x32 + (size_t)row * d + q * 256 + lane * 4); vu[q] = *(const float4*)(x32 + (size_t)(row + P) * d + q * 256 + lane * 4); }
   pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
-                 x4s ? x4s + row : nullptr, x4s ? x4s + row + P : nullptr);
+                 x4s ? x4s + (size_t)row * (d / 64) : nullptr, nullptr);
 }
 
 int layernorm_pair(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps, h16* x_h16, float* stats, int P, int d,

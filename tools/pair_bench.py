@@ -36,14 +36,15 @@ def main():
         o32 = torch.empty(M, N, device=dev) if epi == 2 else None
         o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
         x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8)
-        xs = torch.full((M + 256,), 100, device=dev, dtype=torch.uint8); xs[P:] = 0
+        xs = torch.full((M + 256,), 100, device=dev, dtype=torch.uint8); xs[P:] = 0                    # plain tiles: one byte per row
+        xsb = torch.full((P * (K // 64) + 256,), 100, device=dev, dtype=torch.uint8)                    # pair tiles: one byte per (row, 64 K-elements)
         w4 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); ws = torch.zeros(N, device=dev, dtype=torch.uint8)
         _lib.check(lib.mb_w4_from_f32(W32.data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), st()))
         flops = 2.0 * M * N * K
         plain = lambda: _lib.check(lib.mb_gemm(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), M, N, K, 0, 257, st()))
         pair = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K, None, None, None, None, st()))
         pair4 = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K,
-                                                    x4.data_ptr(), xs.data_ptr(), w4.data_ptr(), ws.data_ptr(), st()))
+                                                    x4.data_ptr(), xsb.data_ptr(), w4.data_ptr(), ws.data_ptr(), st()))
         f4 = lambda: _lib.check(lib.mb_gemm_f4lo(epi, A.data_ptr(), x4.data_ptr(), xs.data_ptr(), W.data_ptr(), w4.data_ptr(), ws.data_ptr(), bias.data_ptr(),
                                                  ptr(res), ptr(o32), ptr(o16), M, N, K, 257, st()))
         for tag, fn in (("plain", plain), ("pair", pair), ("pair+f4", pair4), ("plain+f4", f4)):
