@@ -349,7 +349,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3 */ \
       /* (no reads).  Every half-tile is re-filled >= 2 phases after its last reader; K-tile 1 came with the prologue. */ \
       const bool n1 = t >= 1 && t + 1 < nk, n2 = t + 2 < nk; \
-      if (BS && f8t) { _Pragma("unroll") for (int i = 0; i < 5; ++i) xs_cur[i] = (int)((uint32_t)xs_nxt[i] >> bs_shift); }   /* landed under the previous K-tile's counted wait */ \
+      if (BS && f8t) {                                     /* landed under the previous K-tile's counted wait */ \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i) xs_cur[i] = (int)((uint32_t)xs_nxt[i] >> bs_shift); \
+        if (l15 != 0) xs_cur[4] = 0;                       /* class m-tile: only lane row 0 (the conditional class row) takes part; scale 2^-127 silences the rest */ \
+      } \
       if (BS && t + 1 >= nka && t + 1 < nk) bs_issue(t + 1 - nka); \
       /* ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0] */ \
       MB_LOAD_B(0) MB_LOAD_A(0)                          /* B first: the first MFMAs need both B fragments and only xa[0] */ \
