@@ -606,12 +606,13 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
       // x4s: per-row bytes in the plain forward (M), block bytes [row][d / 64] of the conditional rows in the pair forward (M / 2 * d / 64)
       const size_t x4s_n = std::max<size_t>(M + 256, (M / 2) * (d / 64) + 256);
       rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, x4s_n);
-      rc |= galloc(g, &g->att4, (M / 2) * 2 * d); rc |= galloc(g, &g->att4s, (M / 2) * (d / 64) + 256);
-      rc |= galloc(g, &g->h4, (M / 2) * 2 * f); rc |= galloc(g, &g->h4s, (M / 2) * (f / 64) + 256);
+      // (all M rows: the class-row DMA of a pair tile also stages the twin's row of the 4-bit operand; it is multiplied with scale 2^-127)
+      rc |= galloc(g, &g->att4, M * 2 * d); rc |= galloc(g, &g->att4s, (M / 2) * (d / 64) + 256);
+      rc |= galloc(g, &g->h4, M * 2 * f); rc |= galloc(g, &g->h4s, (M / 2) * (f / 64) + 256);
       if (!rc) {
         (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, x4s_n);
-        (void)hipMemset(g->att4, 0, (M / 2) * 2 * d); (void)hipMemset(g->att4s, 0, (M / 2) * (d / 64) + 256);
-        (void)hipMemset(g->h4, 0, (M / 2) * 2 * f); (void)hipMemset(g->h4s, 0, (M / 2) * (f / 64) + 256);
+        (void)hipMemset(g->att4, 0, M * 2 * d); (void)hipMemset(g->att4s, 0, (M / 2) * (d / 64) + 256);
+        (void)hipMemset(g->h4, 0, M * 2 * f); (void)hipMemset(g->h4s, 0, (M / 2) * (f / 64) + 256);
       }
       g->w4lo.assign((size_t)4 * c.depth, nullptr); g->w4los.assign((size_t)4 * c.depth, nullptr);
       for (int l = 0; l < c.depth; ++l) {
