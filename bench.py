@@ -178,7 +178,7 @@ def main():
 
     B = args.batch
     gen, tok = build_models(dev)
-    MODES = {"strict": (0, -1, -1), "fp16": (0, 0, 0), "wcorr": (0, 0, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
+    MODES = {"strict": (0, -1, -1), "fp16": (0, 0, 0), "wcorr": (0, -1, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
     gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
     torch.manual_seed(1234 + rank)
     plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],

@@ -61,10 +61,11 @@ typedef struct {
   /* Classifier-free guidance in differential form (mb_gen_forward_cfg / mb_sample; DESIGN.md "Precision"): 0 = off (the guided forward is
    * the plain forward over [cond | uncond]); 1 = the unconditional stream's GEMM operands are carried as fp16(x_u - x_c) next to fp16(x_c),
    * so the operand rounding of x_c is common to both streams and cancels in (c - u), the term the guidance scale multiplies -- at no
-   * extra GEMM work (act_split then only concerns the plain forward; weight_split = 1 composes: the pair GEMMs sweep twice); 2 (experiment,
-   * no parity gain measured -- profiles/r02_parity_modes.md) = additionally an MX-fp4 correction pass for the fp16 rounding of the QKV /
-   * FFN-up WEIGHTS (e2m1(x_c) against e2m1(W - fp16(W)), a quarter sweep) in the steps whose guidance scale is below 1 and in every plain
-   * forward; needs act_split = weight_split = 0.
+   * extra GEMM work (act_split then only concerns the plain forward; weight_split = 1 composes: the pair GEMMs sweep twice); 2 = additionally an
+   * MX-fp4 correction pass for the fp16 rounding of the WEIGHTS of all four trunk GEMMs in the guided forward (e2m1 of the conditional operand
+   * values with per-(row, 64 columns) scales against e2m1(W - fp16(W)) with per-row scales; a quarter sweep over the conditional half of every
+   * tile): measured token mismatch of the fp16x2-weight mode (5.8e-4 / 7.1e-4 against 4.7e-4 / 6.6e-4 on the 12-bit / 14-bit runs) for +17 % time;
+   * not combined with act_split = 4 or weight_split.
    * Pair forwards need seq = 256, hidden 768 / 1024, mlp % 256 == 0, post-norm; otherwise the engine falls back to the plain forward. */
   int cfg_pair;
 } mb_gen_cfg;

@@ -27,8 +27,8 @@ DEFAULT_ACT_SPLIT = -1
 STRICT_LEVEL = int(os.environ.get("MASKBIT_AMD_STRICT_LEVEL", "3"))   # lo-pass format behind "strict": 3 = e4m3, 4 = MX-fp4 for the LayerNorm outputs
 # Differential classifier-free guidance (mb_gen_cfg.cfg_pair) for the GUIDED forward (forward_cfg / sample() with guidance): -1 = auto (1 where
 # the shape allows it), 0 = off, 1 = differential operands -- the hi + lo pairs' parity class at the cost of the plain fp16 forward --,
-# 2 = + an MX-fp4 correction of the QKV / FFN-up weight rounding (experiment: no parity gain measured).  act_split keeps governing the plain
-# (unguided) forward.
+# 2 = "precise": + an MX-fp4 correction pass for the fp16 rounding of every trunk weight (+17 % time; token mismatch 5.8e-4 instead of 9.0e-4
+# on the 12-bit / 64-step configuration, 7.1e-4 instead of 1.44e-3 on the 14-bit / 256-step one).  act_split keeps governing the plain (unguided) forward.
 DEFAULT_CFG_PAIR = -1
 
 
@@ -133,8 +133,10 @@ class LFQBert(BaseModel):
             act = 0 if self.weight_split else resolve_act_split(act, self.hidden_dim, self.mlp_dim)   # fp16x2 weights are not combined with act_split
         if pair < 0:
             pair = 1
-        if not capable or (pair == 2 and (act or self.weight_split)):
+        if not capable:
             pair = 0
+        if pair == 2 and (act == 4 or self.weight_split):
+            pair = 1                                               # the weight-correction pass shares buffers with act_split 4; fp16x2 weights do not need it
         return act, pair
 
     def _engine_destroy(self, h) -> None:

@@ -169,7 +169,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   uint8_t* const x8p = x4m ? nullptr : g->x8;
   // cfg_pair == 2 outside a guided forward (plain forward(), sampling without guidance): weight rounding is the dominant logit error there, so the
   // QKV / FFN-up GEMMs always carry the MX-fp4 weight-correction pass (x4 = e2m1 of the LayerNorm VALUES against e2m1(W - fp16(W)))
-  const bool wm = g->pair_ok && c.cfg_pair == 2;
+  const bool wm = g->pair_ok && c.cfg_pair == 2 && !c.act_split && !c.weight_split;   // (with act_split the plain forward runs its hi + lo pairs instead)
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
@@ -545,7 +545,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (c.act_split == 4 && c.hidden != 768 && c.hidden != 1024) return fail(-1, "act_split = 4 (MX-fp4 lo pass) is built for hidden = 768 or 1024");
   if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
   if (c.cfg_pair < 0 || c.cfg_pair > 2) return fail(-1, "cfg_pair must be 0, 1 or 2");
-  if (c.cfg_pair == 2 && (c.act_split || c.weight_split)) return fail(-1, "cfg_pair = 2 (weight-correction pass) is not combined with act_split / weight_split");
+  if (c.cfg_pair == 2 && (c.act_split == 4 || c.weight_split)) return fail(-1, "cfg_pair = 2 (weight-correction pass) is not combined with act_split = 4 / weight_split");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
@@ -599,7 +599,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice; the weight-correction pass of
   // cfg_pair 2 needs plain fp16 operands)
   g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && !c.prenorm && g->chunk_seqs >= 2 &&
-               (c.cfg_pair == 1 || (!c.act_split && !c.weight_split));
+               (c.cfg_pair == 1 || (c.act_split != 4 && !c.weight_split));      // (act_split 4 owns the x4 buffers; fp16x2 weights need no correction pass)
   if (g->pair_ok) {
     rc |= galloc(g, &g->att_aux, (M / 2) * d);
     if (c.cfg_pair == 2) {

@@ -113,8 +113,14 @@ __device__ __forceinline__ uint32_t fp4_code(float v) {                      // 
   const float r = rintf(a * __int_as_float((128 - k) << 23));                // a / 2^(k-1): grid step 0.5 below 2, 1 below 4, 2 above
   return (uint32_t)((int)r + 2 * k) | (v < 0.0f ? 8u : 0u);
 }
-__device__ __forceinline__ uint32_t fp4_pack4(float v0, float v1, float v2, float v3, float mul) {   // 4 consecutive columns -> 16 bits
-  return fp4_code(v0 * mul) | (fp4_code(v1 * mul) << 4) | (fp4_code(v2 * mul) << 8) | (fp4_code(v3 * mul) << 12);
+// 4 consecutive columns -> 16 bits, on the hardware converter: v_cvt_scalef32_pk_fp4_f32 DIVIDES its two inputs by the scale operand, rounds to
+// nearest even on the e2m1 grid and saturates at 6 (probed: tools/micro/mfma_f4_probe.hip) -- bit for bit what fp4_code does, in one
+// instruction per pair (the software form costs ~20 VALU operations per value, which the GELU epilogue and the LayerNorm kernels felt).
+__device__ __forceinline__ uint32_t fp4_pack4(float v0, float v1, float v2, float v3, float mul) {
+  const float inv = mul > 0.f ? __builtin_amdgcn_rcpf(mul) : 1.0f;          // powers of two: exact
+  const float z = mul > 0.f ? 1.0f : 0.0f;                                  // all-zero block (mul = 0): codes 0
+  uint32_t w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(0u, v0 * z, v1 * z, inv, 0);
+  return __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v2 * z, v3 * z, inv, 1) & 0xffffu;
 }
 
 // LayerNorm affine of one element, written with explicit roundings: the LayerNorm kernel and the GEMM epilogue that

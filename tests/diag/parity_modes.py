@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import parity_replay as R
 
-MODES = [("default (-1,-1)", -1, -1, 0), ("single fp16 (0,0)", 0, 0, 0), ("differential only (0,1)", 0, 1, 0), ("differential + W (0,2)", 0, 2, 0),
+MODES = [("default (-1,-1)", -1, -1, 0), ("single fp16 (0,0)", 0, 0, 0), ("differential only (0,1)", 0, 1, 0), ("precise: differential + W (3,2)", 3, 2, 0),
          ("hi+lo e4m3 (3,0)", 3, 0, 0), ("hi+lo fp4 x (4,0)", 4, 0, 0), ("fp16x2 weights (0,0,ws)", 0, 0, 1), ("differential + fp16x2 weights", 0, 1, 1)]
 if os.environ.get("PM_MODES"):
     MODES = [m for i, m in enumerate(MODES) if str(i) in os.environ["PM_MODES"].split(",")]
