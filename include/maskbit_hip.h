@@ -92,6 +92,10 @@ typedef struct {
   const float* scale;          /* [num_steps] guidance_scale * a_i (sampling.py:91-98)            */
   const float* temperature;    /* [num_steps] softmax temperature (sampling.py:103-105)           */
   const int* mask_len;         /* [num_steps] floor(mask_ratio * n*m) (sampling.py:120-123)       */
+  /* Step chunk of this call: step_end = 0 -> the whole run; otherwise steps [step_begin, step_end) -- the first chunk (step_begin 0) starts from the
+   * all-masked state, later chunks continue from the state the engine kept, the last one (step_end = num_steps) combines and decodes.  The noise and
+   * step_tokens pointers of a call hold the steps of ITS chunk (chunk-relative), the arrays above the whole run. */
+  int step_begin, step_end;
 } mb_sample_plan;
 
 int mb_abi_version(void);

@@ -27,7 +27,7 @@ class DecCfg(C.Structure):
 
 class SamplePlan(C.Structure):
     _fields_ = [("num_steps", C.c_int), ("use_guidance", C.c_int), ("scale", C.POINTER(C.c_float)),
-                ("temperature", C.POINTER(C.c_float)), ("mask_len", C.POINTER(C.c_int))]
+                ("temperature", C.POINTER(C.c_float)), ("mask_len", C.POINTER(C.c_int)), ("step_begin", C.c_int), ("step_end", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/maskbit_hip.h declares

@@ -131,6 +131,7 @@ struct mb_gen {
   uint8_t *att4 = nullptr, *att4s = nullptr, *h4 = nullptr, *h4s = nullptr;              // e2m1 of the conditional attention outputs / FFN hiddens + block scales
   int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
   // loop state for mb_sample
+  int loop_B = 0;                                       // samples of the run mb_sample is in the middle of (step chunks)
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
   uint8_t* drop_cfg = nullptr;
   float* logits = nullptr;
@@ -827,11 +828,16 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
   const int n = c.seq, m = c.splits, C = g->C;
   const size_t P = (size_t)n * m;
   // state init (sampling.py:65-71): every position masked; CFG batch = [cond | label-dropped]
-  mb::fill_i64(s, g->tok_a, (int64_t)C, (size_t)B * P);
-  int64_t* cur = g->tok_a;
-  int64_t* nxt = g->tok_b;
+  // A run may be fed in step chunks (plan->step_begin / step_end: the noise of a whole 256-step run at batch 100 is 6.7 GB): chunk [0, e) starts from
+  // the all-masked state, later chunks continue from the token state the engine kept; exp_noise / conf_noise / step_tokens hold THIS chunk's steps.
+  const int s0 = plan->step_end > 0 ? plan->step_begin : 0, s1 = plan->step_end > 0 ? plan->step_end : plan->num_steps;
+  if (s0 < 0 || s1 > plan->num_steps || s0 >= s1) return fail(-1, "mb_sample: step chunk [%d, %d) outside [0, %d)", s0, s1, plan->num_steps);
+  if (s0 == 0) { mb::fill_i64(s, g->tok_a, (int64_t)C, (size_t)B * P); g->loop_B = B; }
+  else if (g->loop_B != B) return fail(-1, "mb_sample: step chunk [%d, %d) continues a run of %d samples with B = %d", s0, s1, g->loop_B, B);
+  int64_t* cur = (s0 & 1) ? g->tok_b : g->tok_a;
+  int64_t* nxt = (s0 & 1) ? g->tok_a : g->tok_b;
   int64_t* last_pred = g->pred;
-  for (int i = 0; i < plan->num_steps; ++i) {
+  for (int i = s0; i < s1; ++i) {
     const float* lc = g->logits;
     const float* lu = nullptr;
     int rc;
@@ -842,12 +848,18 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
       rc = gen_forward(g, cur, labels, nullptr, g->logits, B, s);
     }
     if (rc) return rc;
-    int64_t* pred = step_tokens ? step_tokens + (size_t)i * B * P : g->pred;
-    rc = mb_sample_step(lc, lu, plan->scale[i], plan->temperature[i], exp_noise + (size_t)i * B * P * C,
-                        conf_noise + (size_t)i * B * P, plan->mask_len[i], cur, nxt, pred, B, n, m, C, stream);
+    const size_t k = (size_t)(i - s0);                 // the noise / step_tokens buffers hold this chunk's steps
+    int64_t* pred = step_tokens ? step_tokens + k * B * P : g->pred;
+    rc = mb_sample_step(lc, lu, plan->scale[i], plan->temperature[i], exp_noise + k * B * P * C,
+                        conf_noise + k * B * P, plan->mask_len[i], cur, nxt, pred, B, n, m, C, stream);
     if (rc) return rc;
     last_pred = pred;
     int64_t* t = cur; cur = nxt; nxt = t;
+  }
+  if (s1 < plan->num_steps) {                          // more chunks follow: keep the last predictions only if they are the engine's own buffer
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
   }
   // combine_factorized_tokens (factorization.py:7-24) on the LAST step's predictions, kept as integers
   int64_t* codes = tokens_out ? tokens_out : g->codes;

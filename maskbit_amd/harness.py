@@ -19,7 +19,7 @@ import torch
 
 from .bert import LFQBert
 from .conv_vqgan import ConvVQModel
-from .sampling import build_plan, draw_noise, run_loop, _ForcedPlan
+from .sampling import build_plan, run_chunked, _ForcedPlan
 
 
 def eval_labels(device, nclass: int = 1000, repeats: int = 50) -> torch.Tensor:
@@ -70,8 +70,7 @@ def generate_uint8(model: LFQBert, vqgan_model: ConvVQModel, labels: torch.Tenso
 
     for i in range(nbatch):
         y = labels[batchsize * i: batchsize * (i + 1)].long()
-        exp_noise, conf_noise = draw_noise(batchsize, n, m, model.effective_codebook_size, num_steps, randomize_temperature, dev)
-        _, u8, _, codes = run_loop(model, vqgan_model, y, plan, exp_noise, conf_noise, want_steps=False, want_image=False, want_u8=True)
+        _, u8, _, codes = run_chunked(model, vqgan_model, y, plan, randomize_temperature, want_steps=False, want_image=False, want_u8=True)
         slot = i & 1
         if pinned[slot] is None or pinned[slot].shape != u8.shape:
             pinned[slot] = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)

@@ -66,7 +66,7 @@ def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: st
     """Sample ``len(global_labels)`` images across the process group; every rank returns all images,
     uint8 NHWC, identical on every rank (and, with ``noise="batch"``, identical to a 1-GPU run)."""
     import torch.distributed as dist
-    from .sampling import _ForcedPlan, build_plan, draw_noise, run_loop
+    from .sampling import _ForcedPlan, build_plan, draw_noise, run_loop, step_chunks
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     B = int(global_labels.numel())
@@ -77,17 +77,22 @@ def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: st
     if guidance_scale != 0.0 and not any(a != 0.0 for a in plan[0]):
         plan = _ForcedPlan(plan)                      # as sample(): the CFG forward runs even when every annealed scale is 0
     dev = model.device
+    if noise not in ("batch", "rank"):
+        raise ValueError("noise must be 'batch' or 'rank'")
+    nb = B if noise == "batch" else hi - lo           # the batch the noise is drawn for; chunked by steps to bound its memory (sampling.step_chunks)
     if hi == lo:                                      # more ranks than samples: this rank contributes an empty block to the gather
         if noise == "batch":
-            draw_noise(B, n, m, C_, num_steps, randomize_temperature, dev)      # keep the generators in step with the other ranks
+            for (b0, b1) in step_chunks(nb, n, m, C_, num_steps):               # keep the generators in step with the other ranks
+                draw_noise(nb, n, m, C_, num_steps, randomize_temperature, dev, b0, b1)
         side = int(round(n ** 0.5)) << (vqgan_model.num_resolutions - 1)
         return gather_images(torch.empty((0, side, side, vqgan_model.num_channels), dtype=torch.uint8, device=dev), group)
-    if noise == "batch":
-        e, c = draw_noise(B, n, m, C_, num_steps, randomize_temperature, dev)
-        e, c = slice_noise(e, c, lo, hi, n * m)
-    elif noise == "rank":
-        e, c = draw_noise(hi - lo, n, m, C_, num_steps, randomize_temperature, dev)
-    else:
-        raise ValueError("noise must be 'batch' or 'rank'")
-    _, u8, _, _ = run_loop(model, vqgan_model, global_labels[lo:hi].to(dev), plan, e, c, want_steps=False, want_image=False, want_u8=True)
+    chunks = step_chunks(nb, n, m, C_, num_steps)
+    labels = global_labels[lo:hi].to(dev)
+    u8 = None
+    for (b0, b1) in chunks:
+        e, c = draw_noise(nb, n, m, C_, num_steps, randomize_temperature, dev, b0, b1)
+        if noise == "batch":
+            e, c = slice_noise(e, c, lo, hi, n * m)
+        _, u8, _, _ = run_loop(model, vqgan_model, labels, plan, e, c, want_steps=False, want_image=False, want_u8=True,
+                               step_range=(b0, b1) if len(chunks) > 1 else None)
     return gather_images(u8, group)

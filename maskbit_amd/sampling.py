@@ -45,28 +45,70 @@ def build_plan(num_steps: int, num_maskable: int, guidance_scale: float, guidanc
     return scale, temp, mask_len
 
 
+NOISE_CHUNK_BYTES = 1 << 30       # sample() / generate_uint8() draw and feed the Exp(1) noise in step chunks of at most this size
+
+
 def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, randomize_temperature: float,
-               device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Noise for a whole run, drawn in the reference's per-generator order.
+               device: torch.device, step_begin: int = 0, step_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Noise for steps [step_begin, step_end) of a run (default: the whole run), drawn in the reference's per-generator order: consecutive
+    chunks consume the generators exactly as one whole-run draw does.
     Returns exp_noise [steps, B*n*m, C] (device) and conf_noise [steps, B, n, m] (device) where
     conf_noise = gumbel * randomize_temperature * (1 - progress) (sampling.py:117)."""
-    exp_noise = torch.empty((num_steps, num_samples * n * m, C_), dtype=torch.float32, device=device)
-    for i in range(num_steps):
+    step_end = num_steps if step_end is None else step_end
+    exp_noise = torch.empty((step_end - step_begin, num_samples * n * m, C_), dtype=torch.float32, device=device)
+    for i in range(step_end - step_begin):
         exp_noise[i].exponential_(1)
     gumbel = torch.distributions.Gumbel(loc=0.0, scale=1.0)                     # python-float params => CPU draws
     conf = []
-    for i in range(num_steps):
+    for i in range(step_begin, step_end):
         progress = (i + 1) / num_steps
         conf.append(gumbel.sample((num_samples, n, m)) * randomize_temperature * (1 - progress))
     return exp_noise, torch.stack(conf).to(device, non_blocking=False)
 
 
+def step_chunks(num_samples: int, n: int, m: int, C_: int, num_steps: int):
+    """[(begin, end)] such that one chunk's Exp(1) noise stays under NOISE_CHUNK_BYTES (the reference holds one step at a time; a whole
+    256-step run at batch 100 would be 6.7 GB)."""
+    per_step = num_samples * n * m * C_ * 4
+    k = max(1, min(num_steps, NOISE_CHUNK_BYTES // max(per_step, 1)))
+    return [(b, min(b + k, num_steps)) for b in range(0, num_steps, k)]
+
+
+def run_chunked(model: "LFQBert", vqgan_model, labels: torch.Tensor, plan, randomize_temperature: float, **kw):
+    """run_loop over the whole run with the noise drawn chunk by chunk (same random streams as one whole-run draw)."""
+    scale = plan[0]
+    steps = len(scale)
+    B = labels.shape[0]
+    n, m = model.seq_len, model.splits
+    chunks = step_chunks(B, n, m, model.effective_codebook_size, steps)
+    if len(chunks) == 1:
+        e, c = draw_noise(B, n, m, model.effective_codebook_size, steps, randomize_temperature, model.device)
+        return run_loop(model, vqgan_model, labels, plan, e, c, **kw)
+    want_steps = kw.get("want_steps", True)
+    parts, out = [], None
+    for (b0, b1) in chunks:
+        e, c = draw_noise(B, n, m, model.effective_codebook_size, steps, randomize_temperature, model.device, b0, b1)
+        out = run_loop(model, vqgan_model, labels, plan, e, c, step_range=(b0, b1), **kw)
+        if want_steps:
+            parts.append(out[2])
+    img, u8, _, codes = out
+    return img, u8, (torch.cat(parts) if want_steps else None), codes
+
+
 def run_loop(model: LFQBert, vqgan_model: Optional[ConvVQModel], labels: torch.Tensor, plan, exp_noise: torch.Tensor,
-             conf_noise: torch.Tensor, want_steps: bool = True, want_image: bool = True, want_u8: bool = False):
-    """One ``mb_sample`` call.  -> (image or None, uint8 NHWC or None, step tokens [steps,B,n,m] or None, codes [B,n])."""
+             conf_noise: torch.Tensor, want_steps: bool = True, want_image: bool = True, want_u8: bool = False,
+             step_range: Optional[Tuple[int, int]] = None):
+    """One ``mb_sample`` call.  -> (image or None, uint8 NHWC or None, step tokens [steps,B,n,m] or None, codes [B,n]).
+    ``step_range`` = (begin, end): only those steps of the plan, with ``exp_noise`` / ``conf_noise`` holding that chunk's noise; chunk (0, e)
+    starts the run, later chunks continue from the engine's token state, the chunk ending at the last step combines and decodes (image / codes
+    are meaningful only then)."""
     dev = model._require_cuda("sample")
     scale, temp, mask_len = plan
-    steps = len(scale)
+    nsteps = len(scale)
+    sb, se = step_range if step_range is not None else (0, nsteps)
+    steps = se - sb
+    if exp_noise.shape[0] != steps or conf_noise.shape[0] != steps:
+        raise ValueError(f"noise holds {exp_noise.shape[0]} steps, the step range {steps}")
     B = labels.shape[0]
     n, m = model.seq_len, model.splits
     use_cfg = any(s != 0.0 for s in scale) or getattr(plan, "force_guidance", False)
@@ -84,10 +126,10 @@ def run_loop(model: LFQBert, vqgan_model: Optional[ConvVQModel], labels: torch.T
             u8 = torch.empty((B, res, res, vqgan_model.num_channels), dtype=torch.uint8, device=dev)
         hdec = vqgan_model.engine(B, side)
     hgen = model.engine(2 * B if use_cfg else B)
-    c_scale = (C.c_float * steps)(*scale)
-    c_temp = (C.c_float * steps)(*temp)
-    c_len = (C.c_int * steps)(*mask_len)
-    cplan = _lib.SamplePlan(steps, 1 if use_cfg else 0, c_scale, c_temp, c_len)
+    c_scale = (C.c_float * nsteps)(*scale)
+    c_temp = (C.c_float * nsteps)(*temp)
+    c_len = (C.c_int * nsteps)(*mask_len)
+    cplan = _lib.SamplePlan(nsteps, 1 if use_cfg else 0, c_scale, c_temp, c_len, sb if step_range is not None else 0, se if step_range is not None else 0)
     ptr = lambda t: t.data_ptr() if t is not None else None
     with torch.cuda.device(dev):
         _lib.check(_lib.load().mb_sample(hgen, hdec, C.byref(cplan), labels.data_ptr(), B, exp_noise.data_ptr(),
@@ -143,8 +185,7 @@ def sample(
                       use_sampling_annealing, mask_schedule_strategy)
     if guidance_scale != 0.0 and not any(s != 0.0 for s in plan[0]):
         plan = _ForcedPlan(plan)                      # CFG forward still runs when every a_i happens to be 0
-    exp_noise, conf_noise = draw_noise(num_samples, n, m, model.effective_codebook_size, num_steps, randomize_temperature, device)
-    img, _, step_tokens, _ = run_loop(model, vqgan_model, labels, plan, exp_noise, conf_noise)
+    img, _, step_tokens, _ = run_chunked(model, vqgan_model, labels, plan, randomize_temperature)
     return img, list(step_tokens.unbind(0))
 
 

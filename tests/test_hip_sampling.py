@@ -192,6 +192,36 @@ def test_sharded_noise_slices_reproduce_the_single_device_run():
     assert torch.equal(torch.cat([p[0] for p in parts], 0), u8_full)
 
 
+@pytest.mark.parametrize("scale", [7.1, 0.0])
+def test_step_chunked_run_equals_the_whole_run(scale, monkeypatch):
+    """mb_sample over step ranges (mb_sample_plan.step_begin / step_end) with the noise drawn chunk by chunk is bit-identical to one
+    whole-run call: same tokens at every step, same codes, same pixels; and sample() takes the chunked route when the noise is large."""
+    from maskbit_amd import sampling
+    from maskbit_amd.sampling import build_plan, draw_noise, run_chunked, run_loop
+    _, _, gm, tm = tiny_models()
+    B, N = 3, 7
+    y = torch.tensor([1, 4, 8], device=DEV)
+    plan = build_plan(N, 512, scale, "cosine", 3.0, 1.0, False, "arccos")
+    torch.manual_seed(5)
+    e, c = draw_noise(B, 256, 2, 64, N, 8.2, torch.device(DEV))
+    img_full, u8_full, steps_full, codes_full = run_loop(gm, tm, y, plan, e, c, want_u8=True)
+    parts = []
+    for (b0, b1) in ((0, 3), (3, 4), (4, 7)):                                   # odd / even chunk starts: both token-buffer parities
+        img, u8, st, codes = run_loop(gm, tm, y, plan, e[b0:b1], c[b0:b1], want_u8=True, step_range=(b0, b1))
+        parts.append(st)
+    assert torch.equal(torch.cat(parts), steps_full) and torch.equal(codes, codes_full)
+    assert torch.equal(u8, u8_full) and torch.equal(img, img_full)
+    monkeypatch.setattr(sampling, "NOISE_CHUNK_BYTES", 2 * B * 512 * 64 * 4)    # two steps per chunk
+    assert sampling.step_chunks(B, 256, 2, 64, N) == [(0, 2), (2, 4), (4, 6), (6, 7)]
+    torch.manual_seed(5)
+    img2, u82, steps2, codes2 = run_chunked(gm, tm, y, plan, 8.2, want_u8=True)  # draws the same streams chunk by chunk
+    assert torch.equal(steps2, steps_full) and torch.equal(codes2, codes_full) and torch.equal(u82, u8_full)
+    with pytest.raises(ValueError):
+        run_loop(gm, tm, y, plan, e, c, step_range=(0, 3))                      # noise does not match the range
+    with pytest.raises(RuntimeError):
+        run_loop(gm, tm, y[:2], plan, e[3:4, :2 * 512].contiguous(), c[3:4, :2].contiguous(), step_range=(3, 4))   # continuation with another batch
+
+
 @pytest.mark.parametrize("num_steps,B,scale", [(1, 1, 7.1), (2, 2, 0.0), (3, 5, 3.0)])
 def test_short_loops_and_odd_batches_vs_oracle(num_steps, B, scale):
     """Edge cases of the loop: a single step, no guidance, batch 1 / odd batches.  The oracle runs the same loop with the same

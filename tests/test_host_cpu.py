@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     from maskbit_amd import _lib
     assert ctypes.sizeof(_lib.GenCfg) == 13 * 4
     assert ctypes.sizeof(_lib.DecCfg) == (5 + 8 + 1 + 3) * 4
-    assert ctypes.sizeof(_lib.SamplePlan) == 8 + 3 * 8
+    assert ctypes.sizeof(_lib.SamplePlan) == 8 + 3 * 8 + 8
 
 
 def test_generator_state_dict_matches_reference_keys():
