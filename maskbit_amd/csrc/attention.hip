@@ -26,6 +26,9 @@
 
 namespace mb {
 
+#ifndef MB_ATT_SDEPTH
+#define MB_ATT_SDEPTH 3          // key tiles whose K fragments may be in flight ahead of their score MFMAs
+#endif
 constexpr int ATT_NKT = 18;              // key tiles of 16 -> up to 288 keys
 constexpr int ATT_NP = ATT_NKT * 16;     // padded key count
 constexpr int ATT_NW = 4;                // waves per workgroup (6 waves x 3 tiles measured slower: 104 vs 89 us; so did two query
@@ -33,6 +36,16 @@ constexpr int ATT_NW = 4;                // waves per workgroup (6 waves x 3 til
 constexpr int ATT_MAXQT = (ATT_NKT + ATT_NW - 1) / ATT_NW;   // q-tiles per wave
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// Timeline instrumentation (tools/att_trace.py builds its own copy with -DMB_ATT_TRACE; never in the product library): wave 0 of every workgroup
+// stamps the 100 MHz wall clock -> trace[workgroup][32]: 0 start, 1 loads issued, 2 K / V / Q landed, then per query tile 3+4i .. 6+4i = after the
+// score MFMAs, the softmax, the PV MFMAs, the stores.
+#ifdef MB_ATT_TRACE
+__device__ long long* g_att_trace = nullptr;
+#define MB_ATRACE(k) do { if (g_att_trace && tid == 0 && (k) < 32) g_att_trace[((size_t)blockIdx.x + (AUX == 2 ? gridDim.x : 0)) * 32 + (k)] = wall_clock64(); } while (0)
+#else
+#define MB_ATRACE(k) do { } while (0)
+#endif
 
 // AUX (CFG pair attention, mb_kernels.h attention_pair): 1 = also store the fp32 output rows to aux (conditional sequences), 2 = subtract the
 // conditional twin's fp32 rows (aux) and store the DIFFERENCE as the fp16 output (unconditional sequences, sq_off = P).
@@ -60,6 +73,7 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
   }
 
   const int tid = threadIdx.x, lane = tid & 63;
+  MB_ATRACE(0);
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = AUX == 3 ? (wave8 & (ATT_NW - 1)) : wave8;      // wave index inside its stream
   const int strm = AUX == 3 ? (wave8 >> 2) : 0;                   // 0 = conditional, 1 = unconditional half of the workgroup
@@ -91,8 +105,10 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[i][ks] = *(const h16x8*)(base + (size_t)qrow * rs + (ks * 4 + g) * 8);
   }
+  MB_ATRACE(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MB_ATRACE(2);
 
   // per-lane constant parts of the fragment addresses
   const int koff = l15 * ROW;                                       // K fragment: row kt*16 + l15
@@ -125,8 +141,9 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
         const h16x8 kf = *(const h16x8*)(Ks + kt * 16 * ROW + koff + (((ks * 4 + g) ^ kswz(row)) * 16));
         s[kt] = MB_MFMA_16x16x32(kf, qf[i][ks], s[kt]);
       }
-      if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound the fragment prefetch depth (VGPR budget)
+      if (kt % MB_ATT_SDEPTH == MB_ATT_SDEPTH - 1) __builtin_amdgcn_sched_barrier(0);   // bound the fragment prefetch depth (VGPR budget)
     }
+    MB_ATRACE(3 + 4 * i);
     // ---- softmax over keys (fp32); only the last two key tiles can hold keys >= N
     float mx = -INFINITY;
 #pragma unroll
@@ -161,6 +178,7 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
       for (int nt = 0; nt < DH / 16; ++nt) twin[nt] = *(const f32x4*)(aux + ((size_t)sq0 * N + qq) * d + h * DH + nt * 16 + g * 4);
     }
 
+    MB_ATRACE(4 + 4 * i);
     // ---- O^T = V^T P^T ; V^T fragments by transpose reads, one k-block ahead
     f32x4 o[NT];
 #pragma unroll
@@ -219,6 +237,7 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 4>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 8>{});
     static_assert(NKB <= 10, "add steps");
+    MB_ATRACE(5 + 4 * i);
     // ---- o[nt][r] = O[q = l15][dh = nt*16 + g*4 + r]
     const int q = qt * 16 + l15;
     if constexpr (AUX == 3) {            // hand the conditional tile to the twin wave (same query tile, same lane mapping)
@@ -268,6 +287,7 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
         if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4h(v[0], v[1], v[2], v[3], hi);
       }
     }
+    MB_ATRACE(6 + 4 * i);
   }
 }
 
@@ -551,3 +571,10 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
 }
 
 }  // namespace mb
+
+#ifdef MB_ATT_TRACE
+extern "C" int mb_debug_att_trace(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(mb::g_att_trace), &p, sizeof(p)); }
+extern "C" int mb_debug_attention_pair(const void* qkv, void* out, float* aux, int P, int N, int d, int heads, void* stream) {
+  return mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out, aux, P, N, d, heads, nullptr, nullptr);
+}
+#endif

@@ -445,6 +445,15 @@ int mb_gemm_pair(int epi, const void* A, const void* W, const float* bias, const
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
+int mb_attention_pair(const void* qkv, void* out_h16, float* aux, int pairs, int N, int d, int heads, mb_stream stream) {
+  if (!qkv || !out_h16 || !aux || pairs <= 0 || N <= 0 || heads <= 0 || d % heads) return fail(-1, "mb_attention_pair: bad arguments");
+  ProfScope p("attention", (hipStream_t)stream);
+  if (mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out_h16, aux, pairs, N, d, heads, nullptr, nullptr))
+    return fail(-3, "mb_attention_pair: N = %d tokens / head width %d is outside the on-chip attention kernel", N, d / heads);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
 int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual, float* out_f32,
                       void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
   if (!A_hi || !A_lo || !W || !bias || epi < 0 || epi > 3 || kw <= 0 || kw % 64) return fail(-1, "mb_gemm_act_split: bad arguments");

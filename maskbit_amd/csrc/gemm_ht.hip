@@ -28,8 +28,10 @@
 // the output stores are issued -- they drain behind the next tile's first two K-tiles (the first counted
 // wait that covers them is in K-tile 1).  Output bursts of all CUs are otherwise fully exposed: measured
 // 9 / 17 / 34 us per tile (fp16 / GELU / fp32+residual epilogue) next to a 26 us K = 1024 main loop.
-// (Tried and rejected: starting the CUs 1/4 tile apart to de-synchronise those bursts -- slower by the delay itself,
-// i.e. the epilogue is bound per CU, not by aggregate HBM bandwidth.)
+// (Tried and rejected, twice: starting half of the CUs 4 - 24 us late to de-synchronise those bursts -- slower by the delay itself, in every
+// epilogue form: the epilogue is bound per CU, like the main loop, not by aggregate HBM bandwidth.  Also rejected: 16 residual loads in flight per
+// lane instead of 4 in the fp32+residual epilogue -- same span per tile (tools/ht_trace.py), 23 - 60 spilled VGPRs; and the bias vector parked in
+// LDS instead of fetched per tile -- 0.2 us of a 32 us tile: "pass 1" is bound by the issue of the next tile's 128 KiB prologue DMA.)
 #include <algorithm>
 #include <cstdlib>
 
@@ -77,6 +79,15 @@ __device__ __forceinline__ f32x4 mma_f4bs(f32x4 c, const h16x16& w, const h16x16
 // epilogue emits out_c = f(acc_c), out_u = f(acc_c + acc_delta): the rounding error of the conditional operand is common to both
 // streams and cancels in (c - u), which is what the guidance scale multiplies.  The class-token m-tile carries two rows (lane rows 0 / 1 =
 // class row of c / its difference row); both tiles of a sequence pair compute it, the second one stores it.
+// Timeline instrumentation (tools/ht_trace.py builds its own copy with -DMB_HT_TRACE; never in the product library): wave 0 of every workgroup
+// stamps the 100 MHz wall clock at the phase boundaries of its first 8 tiles -> trace[workgroup][tile][8].
+#ifdef MB_HT_TRACE
+__device__ long long* g_ht_trace = nullptr;
+#define MB_TRACE(k) do { if (g_ht_trace && tid == 0 && trace_it < 8) g_ht_trace[((size_t)blockIdx.x * 8 + trace_it) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define MB_TRACE(k) do { } while (0)
+#endif
+
 template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
@@ -163,12 +174,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       p.d8 = (2 * (qa & 3) + (qa >> 2) - qa) * 8;
     }
   };
+  // trace builds, modes 3 / 4: the K loop's DMA is dropped / re-reads K-tiles 0 and 1 (always L2 hits) -- what the loop costs without (slow) memory
+#if defined(MB_HT_TRACE) && MB_HT_TRACE == 3
+#define MB_TRACE_DMA(t) if ((t) >= 2) return
+#elif defined(MB_HT_TRACE) && MB_HT_TRACE == 4
+#define MB_TRACE_DMA(t) t &= 1
+#else
+#define MB_TRACE_DMA(t)
+#endif
   auto dma_x = [&](const Plan& p, int t) {
+    MB_TRACE_DMA(t);
     int dx = 0;
     if (PERM && t >= nka) { int lo_ = lane; asm volatile("" : "+v"(lo_)); const int qx = (lo_ & 7) ^ (((lo_ >> 3) >> 1) & 7); dx = (2 * (qx & 3) + (qx >> 2) - qx) * 8; }
     if (SEQ && wave == 7) MB_GLDS16_AUX((t < nka ? a.A : Alo) + (p.offX + dx) + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
   };
   auto dma_a = [&](const Plan& p, int t, int h) {
+    MB_TRACE_DMA(t);
     char* buf = smem + (t & 1) * PAR_BYTES + h * AH_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -181,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
   };
   auto dma_b = [&](const Plan& p, int t, int h) {
+    MB_TRACE_DMA(t);
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -321,7 +343,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // K-tiles 0 and 1 of the first tile are in LDS for everyone
 
+  [[maybe_unused]] int trace_it = 0;
   while (true) {
+    MB_TRACE(0);
     f32x4 acc[4][MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -394,11 +418,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* stores stay in flight until the wait of K-tile 1. */ \
       if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); dma_b(cur, t + 2, 0); } \
       if (t >= 1) { \
-        if (BS) {                                        /* the next lo K-tile's block scales (requested in phase 0) are older than those: tied through */ \
-          if (n2) { \
-            if (wave == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) :: "memory"); \
-            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) :: "memory"); \
-          } else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) :: "memory"); \
+        if (BS) {                                        /* the next lo K-tile's block scales (requested in phase 0) are older than those: tied through. */ \
+          /* ONE asm statement for the three cases: with one statement per case the compiler copied the still-in-flight registers to their */ \
+          /* loop-carried homes AHEAD of two of the waits (v_mov ... ; s_waitcnt) -- stale block scales whenever the loads were slow */ \
+          const int wsel = __builtin_amdgcn_readfirstlane(n2 ? (wave == 7 ? 2 : 1) : 0); \
+          asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(7)\n\ts_branch 3f\n" \
+                       "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(6)\n3:" \
+                       : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) : [w] "s"(wsel) : "memory", "scc"); \
         } else if (n2) {                                 /* A0, B1, (X,) B0 of K-tile t+2 may stay in flight */ \
           if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
@@ -416,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
 #undef MB_KTILE
     if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the two groups
+    MB_TRACE(1);
 
     const float* __restrict__ resp = a.residual;
     float* __restrict__ out32 = a.out_f32;
@@ -526,11 +553,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         }
       }
     }
+    MB_TRACE(2);
     // the next tile's first K-tiles must be in LDS before anyone reads them; nothing of THIS tile is stored yet
     if (has_next) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    MB_TRACE(3);
     if constexpr (PAIR && EPI == EPI_GELU_H16) {
       if (a.out4) {
         // e2m1 copy of the conditional GELU outputs for the next GEMM's weight-correction pass: this wave's 64 columns of a row are one scale block
@@ -647,6 +676,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         }
       }
     }
+    MB_TRACE(4);
+#ifdef MB_HT_TRACE
+#if MB_HT_TRACE >= 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (mode 2 only: when the stores are acknowledged; changes the overlap with the next tile)
+    MB_TRACE(5);
+#endif
+    ++trace_it;
+#endif
     if (!has_next) break;
     cur = nxt;
     vb = nvb;
@@ -757,3 +794,7 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
 }
 
 }  // namespace mb
+
+#ifdef MB_HT_TRACE
+extern "C" int mb_debug_ht_trace(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(mb::g_ht_trace), &p, sizeof(p)); }
+#endif

@@ -147,3 +147,34 @@ def test_pair_gemm_with_weight_correction_pass(epi, pairs, N, K):
         e_plain = float((A[:P].double() @ W.double().t() + bias.double() + res[:P].double() - true_c).pow(2).mean().sqrt())
         print(f"rms error of the conditional rows vs fp32 weights: fp16 weights {e_plain:.3e}, with the correction pass {e_corr:.3e}")
         assert e_corr < e_plain / 3
+
+
+@pytest.mark.parametrize("pairs,heads,d", [(2, 16, 1024), (3, 4, 128)])
+def test_pair_attention_vs_fp32_reference(pairs, heads, d):
+    """mb_attention_pair (bert.py:84,137 on both CFG streams): conditional rows = softmax(QK^T / sqrt(dh)) V, unconditional rows = the DIFFERENCE to
+    their conditional twins, against fp64 attention on the same fp16 q / k / v.  The twin's rows are subtracted in fp32 (aux), not from its fp16
+    store, so the difference rows carry the two streams' fp16-probability rounding (a few 1e-5 absolute here) but no fp16 output rounding of
+    either stream: far below one fp16 ulp of the outputs themselves."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(pairs)
+    N, dh = 257, d // heads
+    qc = torch.randn(pairs * N, 3 * d, device=DEV) * 0.7
+    qu = qc + torch.randn(pairs * N, 3 * d, device=DEV) * 0.02          # the unconditional stream differs a little
+    qkv = torch.cat([qc, qu]).half().contiguous()
+    out = torch.full((2 * pairs * N, d), float("nan"), device=DEV, dtype=torch.float16)
+    aux = torch.empty(pairs * N, d, device=DEV)
+    _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), pairs, N, d, heads, torch.cuda.current_stream().cuda_stream),
+               "mb_attention_pair")
+    torch.cuda.synchronize()
+    x = qkv.double().view(2 * pairs, N, 3, heads, dh).permute(2, 0, 3, 1, 4)          # [3, seq, head, N, dh]
+    p = torch.softmax(x[0] @ x[1].transpose(-1, -2) / dh ** 0.5, dim=-1)
+    o = (p @ x[2]).permute(0, 2, 1, 3).reshape(2 * pairs * N, d)
+    oc, ou = o[: pairs * N], o[pairs * N:]
+    assert float((out[: pairs * N].double() - oc).abs().max()) < 2e-3 * float(oc.abs().max())               # fp16 probabilities and stores
+    diff = ou - oc
+    err = float((out[pairs * N:].double() - diff).abs().max())
+    assert err < 2e-4 * float(oc.abs().max()) and err < 2e-2 * float(diff.abs().max()), (err, float(diff.abs().max()), float(oc.abs().max()))
+    assert float((aux.double() - oc).abs().max()) < 1e-3 * float(oc.abs().max())                            # the fp32 rows the twins subtract
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), 1, 300, d, heads, torch.cuda.current_stream().cuda_stream), "mb_attention_pair")
