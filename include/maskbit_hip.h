@@ -200,7 +200,8 @@ int mb_gemm_pair(int epi, const void* A, const void* W, const float* bias, const
                  int pair_rows, int N, int kw, const void* A4, const void* a_scale, const void* W4, const void* w_scale, mb_stream stream);
 /* Attention of a CFG pair batch (the generator's guided forward, bert.py:84,137 on both streams): qkv [2 pairs N, 3d] fp16 packed in_proj rows, the
  * conditional sequences first, their unconditional twins `pairs` sequences later.  out rows of conditional sequences = softmax(QK^T/sqrt(dh))V in
- * fp16; rows of unconditional sequences = fp16(o_u - o_c), the difference operand of the out-proj pair GEMM.  aux [pairs N, d] fp32 scratch. */
+ * fp16; rows of unconditional sequences = fp16(o_u - o_c), the difference operand of the out-proj pair GEMM.  aux [pairs N, d] fp32: scratch of the
+ * two-launch form (MASKBIT_AMD_ATT_PAIR=2); the default form keeps the conditional rows in registers and leaves it untouched. */
 int mb_attention_pair(const void* qkv, void* out_h16, float* aux, int pairs, int N, int d, int heads, mb_stream stream);
 int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual,
                       float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);

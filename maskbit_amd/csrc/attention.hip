@@ -49,11 +49,11 @@ __device__ long long* g_att_trace = nullptr;
 
 // AUX (CFG pair attention, mb_kernels.h attention_pair): 1 = also store the fp32 output rows to aux (conditional sequences), 2 = subtract the
 // conditional twin's fp32 rows (aux) and store the DIFFERENCE as the fp16 output (unconditional sequences, sq_off = P).
-// AUX = 3: both streams of a (sequence pair, head) in ONE workgroup of 8 waves -- waves 0-3 the conditional sequence, waves 4-7 its unconditional
-// twin (sq + sq_off), each half with its own K / V image in LDS (4 x 36 KiB) -- and the conditional wave hands its fp32 output tile to its twin wave
-// through a 4 KiB LDS mailbox (4 x 36 + 4 x 4 KiB = all 160 KiB): no aux traffic, one launch.
+// AUX = 4 (the default pair form): one workgroup handles the conditional sequence of a (pair, head) and then its unconditional twin, the conditional
+// output tiles parked in registers in between: no aux traffic, one launch, two workgroups per CU as before.  (Tried and dropped: both streams side by
+// side in one 8-wave workgroup with an LDS mailbox -- 160 KiB of LDS, one workgroup per CU, no faster than the two launches.)
 template <int DH, int AUX = 0>
-__global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
+__global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
                                                           int N, int d, int heads, float scale_log2e, float* __restrict__ aux = nullptr, int sq_off = 0,
                                                           uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr) {
   // out4 / out4s (AUX 1, optional): e2m1 of the conditional output VALUES (row stride 2d bytes) with one E8M0 scale byte per (row, head) --
@@ -64,26 +64,28 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
   constexpr int NT = DH / 16;            // output dh tiles
   constexpr int RPI = 64 / SL;           // rows covered by one 1 KiB DMA instruction (8 or 16)
   constexpr int NINST = ATT_NP / RPI;    // DMA instructions per operand (36 or 18)
-  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
-  char* smem;
-  if constexpr (AUX == 3) smem = dyn_smem;
-  else {
-    __shared__ __attribute__((aligned(16))) char static_smem[2 * ATT_NP * ROW];
-    smem = static_smem;
-  }
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_NP * ROW];
 
   const int tid = threadIdx.x, lane = tid & 63;
   MB_ATRACE(0);
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = AUX == 3 ? (wave8 & (ATT_NW - 1)) : wave8;      // wave index inside its stream
-  const int strm = AUX == 3 ? (wave8 >> 2) : 0;                   // 0 = conditional, 1 = unconditional half of the workgroup
-  char* Ks = smem + strm * 2 * ATT_NP * ROW;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* Ks = smem;
   char* Vs = Ks + ATT_NP * ROW;
-  float* const mbox = (float*)(dyn_smem + 4 * ATT_NP * ROW) + wave * (NT * 64 * 4);   // AUX 3: this wave pair's mailbox (NT x 64 lanes x f32x4)
   const int sq0 = blockIdx.x / heads, h = blockIdx.x - sq0 * heads;
-  const int sq = sq0 + (AUX == 3 ? strm * sq_off : sq_off);
   const size_t rs = (size_t)3 * d;                                   // qkv row stride (elements)
+  // AUX = 4: the workgroup handles the conditional sequence and then its unconditional twin (two passes over the same code); the conditional
+  // output tiles stay in registers (oc) for the subtraction -- no aux traffic, one launch, and still two 72 KiB workgroups per CU
+  constexpr int NPASS = AUX == 4 ? 2 : 1;
+  // (the tiles of a wave's first ATT_MAXQT - 1 rounds; the <= 2 waves that own a tile in the last round -- N = 257: the class-token tile -- park it in
+  // a 4 KiB LDS slab each instead: with it in registers the kernel spilled 4 VGPRs, and a kernel with scratch costs more per launch than it saved)
+  f32x4 oc[AUX == 4 ? ATT_MAXQT - 1 : 1][DH / 16];
+  constexpr int LAST_WAVES = ATT_NKT - ATT_NW * (ATT_MAXQT - 1);       // waves with a tile in the last round
+  __shared__ __attribute__((aligned(16))) float oc_last[AUX == 4 ? LAST_WAVES * 64 * DH / 4 : 4];
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; ++pass) {
+  const int sq = sq0 + (AUX == 4 ? pass * sq_off : sq_off);
   const h16* base = qkv + (size_t)sq * N * rs + h * DH;
+  if (AUX == 4 && pass > 0) __syncthreads();                         // every wave is done with the first pass's K / V image
 
   auto kswz = [](int row) { return SL == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
   auto vswz = [](int row) { return SL == 8 ? (((row >> 1) & 3) << 1) : (((row >> 1) & 1) << 1); };
@@ -95,16 +97,24 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
     MB_GLDS16(src + d + (p ^ kswz(row)) * 8, Ks + j * 1024);
     MB_GLDS16(src + 2 * d + (p ^ vswz(row)) * 8, Vs + j * 1024);
   }
-  // ---- Q fragments of every q-tile this wave owns (in flight together with the DMA)
+  // ---- Q fragments of every q-tile this wave owns (in flight together with the DMA).  N = 257 makes 17 query tiles for 4 waves: the wave that
+  // owns a fifth one rotates with the head index, so that the two workgroups sharing a CU load different SIMDs with it.
+#ifdef MB_ATT_ROT
+  const int wq = (wave + (int)blockIdx.x) & (ATT_NW - 1);
+#else
+  const int wq = wave;
+#endif
   const int l15 = lane & 15, g = lane >> 4;
   const int nqt = (N + 15) / 16;
   h16x8 qf[ATT_MAXQT][KS];
-#pragma unroll
-  for (int i = 0; i < ATT_MAXQT; ++i) {
-    const int qrow = min((wave + ATT_NW * i) * 16 + l15, N - 1);
+  auto q_fetch = [&](int i) {
+    const int qrow = min((wq + ATT_NW * i) * 16 + l15, N - 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[i][ks] = *(const h16x8*)(base + (size_t)qrow * rs + (ks * 4 + g) * 8);
-  }
+  };
+  // (AUX 4 runs at the VGPR limit: it fetches the next tile's Q fragments one tile ahead instead of all up front)
+#pragma unroll
+  for (int i = 0; i < (AUX == 4 ? 1 : ATT_MAXQT); ++i) q_fetch(i);
   MB_ATRACE(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -123,12 +133,8 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
 
 #pragma unroll
   for (int i = 0; i < ATT_MAXQT; ++i) {
-    const int qt = wave + ATT_NW * i;
-    if (AUX != 3 && qt >= nqt) break;
-    if (AUX == 3 && qt >= nqt) {          // the two hand-off barriers of this round are taken by every wave of the workgroup
-      __syncthreads(); __syncthreads();
-      continue;
-    }
+    const int qt = wq + ATT_NW * i;
+    if (qt >= nqt) break;
     // ---- S^T tiles: s[kt][r] = S[q = l15][key = kt*16 + g*4 + r]
     f32x4 s[ATT_NKT];
 #pragma unroll
@@ -143,7 +149,13 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
       }
       if (kt % MB_ATT_SDEPTH == MB_ATT_SDEPTH - 1) __builtin_amdgcn_sched_barrier(0);   // bound the fragment prefetch depth (VGPR budget)
     }
+    if (AUX == 4 && i + 1 < ATT_MAXQT) q_fetch(i + 1);
     MB_ATRACE(3 + 4 * i);
+#ifdef MB_ATT_NOSM                                               // timing experiment only: no softmax at all
+    float inv = 1.0f;
+    asm volatile("" : "+v"(inv));
+    f32x4 twin[DH / 16] = {};
+#else
     // ---- softmax over keys (fp32); only the last two key tiles can hold keys >= N
     float mx = -INFINITY;
 #pragma unroll
@@ -162,7 +174,11 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
         const f32x2 arg = __builtin_elementwise_fma((f32x2){s[kt][r], s[kt][r + 1]}, (f32x2)(scale_log2e), (f32x2)(-mxs));
+#ifdef MB_ATT_NOEXP                                            // timing experiment only (tools/att_trace.py): what the transcendental costs
+        const f32x2 p = arg * arg;
+#else
         const f32x2 p = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};   // exp((s - max)/sqrt(dh)); arg <= 0: bare v_exp_f32
+#endif
         s[kt][r] = p.x; s[kt][r + 1] = p.y;
         sum2 += p;
       }
@@ -171,12 +187,13 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
     sum += __shfl_xor(sum, 32);
     float inv = 1.0f / sum;
     asm volatile("" : "+v"(inv));          // every cross-lane op of the softmax has retired before the asm LDS reads start
-    f32x4 twin[DH / 16] = {};              // AUX 2: the conditional twin's output rows, requested now, used after the PV loop (AUX 3: from the mailbox)
+    f32x4 twin[DH / 16] = {};              // AUX 2: the conditional twin's output rows, requested now, used after the PV loop
     if constexpr (AUX == 2) {
       const int qq = min(qt * 16 + l15, N - 1);
 #pragma unroll
       for (int nt = 0; nt < DH / 16; ++nt) twin[nt] = *(const f32x4*)(aux + ((size_t)sq0 * N + qq) * d + h * DH + nt * 16 + g * 4);
     }
+#endif
 
     MB_ATRACE(4 + 4 * i);
     // ---- O^T = V^T P^T ; V^T fragments by transpose reads, one k-block ahead
@@ -234,26 +251,20 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
         }
       }
     };
+#ifndef MB_ATT_NOPV                                              // (timing experiment only: no PV product)
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 4>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 8>{});
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] = s[nt] + s[nt + 4] + s[nt + 8] + s[nt + 12];
+#endif
     static_assert(NKB <= 10, "add steps");
     MB_ATRACE(5 + 4 * i);
     // ---- o[nt][r] = O[q = l15][dh = nt*16 + g*4 + r]
     const int q = qt * 16 + l15;
-    if constexpr (AUX == 3) {            // hand the conditional tile to the twin wave (same query tile, same lane mapping)
-      if (strm == 0) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) *(f32x4*)(mbox + (nt * 64 + lane) * 4) = f32x4{o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
-      }
-      __syncthreads();
-      if (strm == 1) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) twin[nt] = *(const f32x4*)(mbox + (nt * 64 + lane) * 4);
-      }
-      __syncthreads();                   // the mailbox may be overwritten by the next round
-    }
-    if constexpr (AUX == 1 && DH == 64) {
-      if (out4) {                          // block (row, head) = this lane's 16 values x its 4 lane groups
+    if constexpr ((AUX == 1 || AUX == 4) && DH == 64) {
+      if (out4 && (AUX == 1 || pass == 0)) {                          // block (row, head) = this lane's 16 values x its 4 lane groups
         float am = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -278,7 +289,10 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
         f32x4 v = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
         if constexpr (AUX == 1) *(f32x4*)(aux + ((size_t)sq0 * N + q) * d + h * DH + nt * 16 + g * 4) = v;
         if constexpr (AUX == 2) v = v - twin[nt];
-        if constexpr (AUX == 3) { if (strm == 1) v = v - twin[nt]; }
+        if constexpr (AUX == 4) {
+          if (i < ATT_MAXQT - 1) { f32x4& r = oc[i < ATT_MAXQT - 1 ? i : 0][nt]; if (pass == 0) r = v; else v = v - r; }
+          else { f32x4* slot = (f32x4*)oc_last + (wq * NT + nt) * 64 + lane; if (pass == 0) *slot = v; else v = v - *slot; }
+        }
         const h16x4 hi = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
         *(h16x4*)(out + ooff + nt * 16 + g * 4) = hi;
         if (out_lo)                                             // split activations: the fp16 lo halves v - fp16(v)
@@ -289,6 +303,7 @@ __global__ __launch_bounds__(AUX == 3 ? 128 * ATT_NW : 64 * ATT_NW, 2) void atte
     }
     MB_ATRACE(6 + 4 * i);
   }
+  }                                      // pass
 }
 
 // ---- long sequences (N > 288, e.g. the 512x512 models' 1025 tokens): K/V streamed in 128-key blocks, online softmax ------------
@@ -550,20 +565,19 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
   if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   dim3 grid(P * heads), block(64 * ATT_NW);
-  // One-launch variant (AUX = 3): measured equal on average (116-120 us against 117-123 us for the two launches, B = 64 pairs) -- what it saves in aux traffic
-  // it loses by running both halves' K/V staging and compute in lockstep (two 72 KiB workgroups per CU overlap one's staging with the other's compute;
-  // one 160 KiB workgroup cannot) -- and with a worse tail (a sampled run averaged 199 us).  Kept behind a switch.
-  static const bool one_launch = getenv("MASKBIT_AMD_ATT_PAIR_1L") && atoi(getenv("MASKBIT_AMD_ATT_PAIR_1L")) != 0;
-  if (dh == 64 && one_launch && !out4) {
-    constexpr int LDS = 4 * ATT_NP * 128 + ATT_NW * 4 * 64 * 16;      // 4 K/V images + 4 mailboxes = 160 KiB
-    static bool configured = false;
-    if (!configured) { (void)hipFuncSetAttribute((const void*)attention_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); configured = true; }
-    hipLaunchKernelGGL((attention_kernel<64, 3>), grid, dim3(128 * ATT_NW), LDS, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P);
-  } else if (dh == 64) {
+  const char* pm = getenv("MASKBIT_AMD_ATT_PAIR");                 // A/B switch, read per call (tools/forward_ab.py flips it inside one process):
+  const int pair_mode = pm ? atoi(pm) : 4;                         // 4 (default) / 2 (two launches through aux)
+  if (out4 && dh != 64) return -1;         // the fp4 output exists for head dimension 64
+  if (pair_mode == 4) {                    // one workgroup per (pair, head): conditional pass, then the twin; conditional outputs parked in registers
+    // 88 us against 119 us for the two launches (B = 64 pairs): a third of the traffic was the fp32 aux round trip
+    if (dh == 64) hipLaunchKernelGGL((attention_kernel<64, 4>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P, out4, out4s);
+    else hipLaunchKernelGGL((attention_kernel<32, 4>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P);
+    return 0;
+  }
+  if (dh == 64) {
     hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0, out4, out4s);
     hipLaunchKernelGGL((attention_kernel<64, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
   } else {
-    if (out4) return -1;                  // the fp4 output exists for head dimension 64
     hipLaunchKernelGGL((attention_kernel<32, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);
     hipLaunchKernelGGL((attention_kernel<32, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
   }
@@ -574,6 +588,8 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
 
 #ifdef MB_ATT_TRACE
 extern "C" int mb_debug_att_trace(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(mb::g_att_trace), &p, sizeof(p)); }
+#endif
+#if defined(MB_ATT_TRACE) || defined(MB_ATT_VARIANT)      // experimental builds of this file alone (tools/att_trace.py)
 extern "C" int mb_debug_attention_pair(const void* qkv, void* out, float* aux, int P, int N, int d, int heads, void* stream) {
   return mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out, aux, P, N, d, heads, nullptr, nullptr);
 }

@@ -23,7 +23,7 @@ def build():
     print("built", os.path.join(AB, "libatt_trace.so"))
 
 
-VARIANTS = {"sd6": ["-DMB_ATT_SDEPTH=6"], "sd9": ["-DMB_ATT_SDEPTH=9"], "sd99": ["-DMB_ATT_SDEPTH=99"]}
+VARIANTS = {"base": [], "sd3": ["-DMB_ATT_SDEPTH=3"], "noexp": ["-DMB_ATT_NOEXP=1"], "nosm": ["-DMB_ATT_NOSM=1"], "nopv": ["-DMB_ATT_NOPV=1"], "nosmpv": ["-DMB_ATT_NOSM=1", "-DMB_ATT_NOPV=1"]}
 
 
 def build_variants():
@@ -32,7 +32,7 @@ def build_variants():
     os.makedirs(AB, exist_ok=True)
     procs = []
     for name, flags in VARIANTS.items():
-        procs.append(subprocess.Popen([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-DMB_ATT_TRACE=1", *flags,
+        procs.append(subprocess.Popen([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-DMB_ATT_VARIANT=1", *flags,
                                        os.path.join(B.CSRC, "attention.hip"), "-o", os.path.join(AB, f"libatt_var_{name}.so")]))
     assert all(p.wait() == 0 for p in procs)
 
