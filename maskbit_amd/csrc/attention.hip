@@ -42,7 +42,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // score MFMAs, the softmax, the PV MFMAs, the stores.
 #ifdef MB_ATT_TRACE
 __device__ long long* g_att_trace = nullptr;
-#define MB_ATRACE(k) do { if (g_att_trace && tid == 0 && (k) < 32) g_att_trace[((size_t)blockIdx.x + (AUX == 2 ? gridDim.x : 0)) * 32 + (k)] = wall_clock64(); } while (0)
+#define MB_ATRACE(k) do { if (g_att_trace && tid == 0 && (k) < 32) g_att_trace[((size_t)blockIdx.x + ((AUX == 2 || (AUX == 4 && pass == 1)) ? gridDim.x : 0)) * 32 + (k)] = wall_clock64(); } while (0)
 #else
 #define MB_ATRACE(k) do { } while (0)
 #endif
@@ -67,7 +67,6 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_NP * ROW];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  MB_ATRACE(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* Ks = smem;
   char* Vs = Ks + ATT_NP * ROW;
@@ -85,30 +84,30 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
   for (int pass = 0; pass < NPASS; ++pass) {
   const int sq = sq0 + (AUX == 4 ? pass * sq_off : sq_off);
   const h16* base = qkv + (size_t)sq * N * rs + h * DH;
+  MB_ATRACE(0);
   if (AUX == 4 && pass > 0) __syncthreads();                         // every wave is done with the first pass's K / V image
 
   auto kswz = [](int row) { return SL == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
   auto vswz = [](int row) { return SL == 8 ? (((row >> 1) & 3) << 1) : (((row >> 1) & 1) << 1); };
 
   // ---- stage K and V by LDS-DMA: instruction j covers rows [j*RPI, (j+1)*RPI); rows >= N re-read row N-1
+  // (tried: K first and V waited for only after the first tile's scores and softmax -- no change, 88.9 vs 88.0 us)
   for (int j = wave; j < NINST; j += ATT_NW) {
     const int row = j * RPI + lane / SL, p = lane % SL;
     const h16* src = base + (size_t)min(row, N - 1) * rs;
     MB_GLDS16(src + d + (p ^ kswz(row)) * 8, Ks + j * 1024);
     MB_GLDS16(src + 2 * d + (p ^ vswz(row)) * 8, Vs + j * 1024);
   }
-  // ---- Q fragments of every q-tile this wave owns (in flight together with the DMA).  N = 257 makes 17 query tiles for 4 waves: the wave that
-  // owns a fifth one rotates with the head index, so that the two workgroups sharing a CU load different SIMDs with it.
-#ifdef MB_ATT_ROT
-  const int wq = (wave + (int)blockIdx.x) & (ATT_NW - 1);
-#else
-  const int wq = wave;
-#endif
+  // ---- Q fragments of every q-tile this wave owns (in flight together with the DMA).  N = 257 makes 17 query tiles for 4 waves: wave w owns
+  // tiles w, w+4, .., w+12, and the tiles of the last round (16, 17) go to waves 0, 1.  (Rotating that extra tile over the waves with the pass and
+  // the workgroup index, so that it lands on different SIMDs, changed nothing: 26.32 ms per forward either way.)
+  const int wlast = wave;
+  auto qt_of = [&](int i) { return i < ATT_MAXQT - 1 ? wave + ATT_NW * i : ATT_NW * (ATT_MAXQT - 1) + wlast; };
   const int l15 = lane & 15, g = lane >> 4;
   const int nqt = (N + 15) / 16;
   h16x8 qf[ATT_MAXQT][KS];
   auto q_fetch = [&](int i) {
-    const int qrow = min((wq + ATT_NW * i) * 16 + l15, N - 1);
+    const int qrow = min(qt_of(i) * 16 + l15, N - 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[i][ks] = *(const h16x8*)(base + (size_t)qrow * rs + (ks * 4 + g) * 8);
   };
@@ -133,10 +132,40 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 
 #pragma unroll
   for (int i = 0; i < ATT_MAXQT; ++i) {
-    const int qt = wq + ATT_NW * i;
+    const int qt = qt_of(i);
     if (qt >= nqt) break;
     // ---- S^T tiles: s[kt][r] = S[q = l15][key = kt*16 + g*4 + r]
     f32x4 s[ATT_NKT];
+#ifndef MB_ATT_NOSPIPE
+    // groups of GK key tiles; the K fragments of group n+1 are requested before the MFMAs of group n, and inside a group all first k-steps go
+    // before the second ones (no MFMA waits for the one issued just before it)
+    constexpr int GK = MB_ATT_SDEPTH, NG = ATT_NKT / GK;
+    static_assert(ATT_NKT % GK == 0, "whole groups");
+    h16x8 kfr[2][GK][KS];
+    auto k_fetch = [&](h16x8 (&dst)[GK][KS], int grp) {
+#pragma unroll
+      for (int j = 0; j < GK; ++j) {
+        const int kt = grp * GK + j, row = kt * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[j][ks] = *(const h16x8*)(Ks + kt * 16 * ROW + koff + (((ks * 4 + g) ^ kswz(row)) * 16));
+      }
+    };
+    k_fetch(kfr[0], 0);
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      if (grp + 1 < NG) k_fetch(kfr[(grp + 1) & 1], grp + 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < GK; ++j) {
+          const int kt = grp * GK + j;
+          if (ks == 0) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (kt == ATT_NKT - 1 && kt * 16 >= N) continue;    // the padding tile holds no key at N = 257
+          s[kt] = MB_MFMA_16x16x32(kfr[grp & 1][j][ks], qf[i][ks], s[kt]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int kt = 0; kt < ATT_NKT; ++kt) {
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -149,13 +178,9 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
       }
       if (kt % MB_ATT_SDEPTH == MB_ATT_SDEPTH - 1) __builtin_amdgcn_sched_barrier(0);   // bound the fragment prefetch depth (VGPR budget)
     }
+#endif
     if (AUX == 4 && i + 1 < ATT_MAXQT) q_fetch(i + 1);
     MB_ATRACE(3 + 4 * i);
-#ifdef MB_ATT_NOSM                                               // timing experiment only: no softmax at all
-    float inv = 1.0f;
-    asm volatile("" : "+v"(inv));
-    f32x4 twin[DH / 16] = {};
-#else
     // ---- softmax over keys (fp32); only the last two key tiles can hold keys >= N
     float mx = -INFINITY;
 #pragma unroll
@@ -174,11 +199,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
         const f32x2 arg = __builtin_elementwise_fma((f32x2){s[kt][r], s[kt][r + 1]}, (f32x2)(scale_log2e), (f32x2)(-mxs));
-#ifdef MB_ATT_NOEXP                                            // timing experiment only (tools/att_trace.py): what the transcendental costs
-        const f32x2 p = arg * arg;
-#else
         const f32x2 p = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};   // exp((s - max)/sqrt(dh)); arg <= 0: bare v_exp_f32
-#endif
         s[kt][r] = p.x; s[kt][r + 1] = p.y;
         sum2 += p;
       }
@@ -193,7 +214,6 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 #pragma unroll
       for (int nt = 0; nt < DH / 16; ++nt) twin[nt] = *(const f32x4*)(aux + ((size_t)sq0 * N + qq) * d + h * DH + nt * 16 + g * 4);
     }
-#endif
 
     MB_ATRACE(4 + 4 * i);
     // ---- O^T = V^T P^T ; V^T fragments by transpose reads, one k-block ahead
@@ -251,14 +271,8 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         }
       }
     };
-#ifndef MB_ATT_NOPV                                              // (timing experiment only: no PV product)
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 4>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 8>{});
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) o[nt] = s[nt] + s[nt + 4] + s[nt + 8] + s[nt + 12];
-#endif
     static_assert(NKB <= 10, "add steps");
     MB_ATRACE(5 + 4 * i);
     // ---- o[nt][r] = O[q = l15][dh = nt*16 + g*4 + r]
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         if constexpr (AUX == 2) v = v - twin[nt];
         if constexpr (AUX == 4) {
           if (i < ATT_MAXQT - 1) { f32x4& r = oc[i < ATT_MAXQT - 1 ? i : 0][nt]; if (pass == 0) r = v; else v = v - r; }
-          else { f32x4* slot = (f32x4*)oc_last + (wq * NT + nt) * 64 + lane; if (pass == 0) *slot = v; else v = v - *slot; }
+          else { f32x4* slot = (f32x4*)oc_last + ((qt - ATT_NW * (ATT_MAXQT - 1)) * NT + nt) * 64 + lane; if (pass == 0) *slot = v; else v = v - *slot; }
         }
         const h16x4 hi = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
         *(h16x4*)(out + ooff + nt * 16 + g * 4) = hi;

@@ -23,7 +23,7 @@ def build():
     print("built", os.path.join(AB, "libatt_trace.so"))
 
 
-VARIANTS = {"base": [], "sd3": ["-DMB_ATT_SDEPTH=3"], "noexp": ["-DMB_ATT_NOEXP=1"], "nosm": ["-DMB_ATT_NOSM=1"], "nopv": ["-DMB_ATT_NOPV=1"], "nosmpv": ["-DMB_ATT_NOSM=1", "-DMB_ATT_NOPV=1"]}
+VARIANTS = {"base": [], "nospipe": ["-DMB_ATT_NOSPIPE=1"], "gk2": ["-DMB_ATT_SDEPTH=2"], "gk6": ["-DMB_ATT_SDEPTH=6"], "gk9": ["-DMB_ATT_SDEPTH=9"]}
 
 
 def build_variants():
@@ -64,7 +64,21 @@ def run():
     e0.record()
     for _ in range(20): pfn()
     e1.record(); torch.cuda.synchronize()
-    print(f"product library: pair attention (two launches), {P} sequence pairs: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
+    print(f"product library: pair attention, {P} sequence pairs: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
+    prev = os.path.join(AB, "lib_prev.so")                                          # a copy of an earlier product build, for A/B in one process
+    if os.path.exists(prev):
+        qlib = C.CDLL(prev)
+        qlib.mb_attention_pair.restype = C.c_int
+        qlib.mb_attention_pair.argtypes = plib.mb_attention_pair.argtypes
+        qfn = lambda: qlib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), P, N, d, heads, st)
+        for rep in range(3):
+            for name, f in (("previous build", qfn), ("product library", pfn)):
+                for _ in range(3): assert f() == 0
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(20): f()
+                e1.record(); torch.cuda.synchronize()
+                print(f"  A/B {name:16s}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
     import glob
     ref = None
     for path in sorted(glob.glob(os.path.join(AB, "libatt_var_*.so"))):
@@ -97,7 +111,7 @@ def run():
     assert lib.mb_debug_att_trace(None) == 0
     t = trace.cpu().numpy().astype(np.float64) * 0.01
     t0 = t[:, 0].min()
-    for name, sl in (("conditional launch", slice(0, G)), ("unconditional launch", slice(G, 2 * G))):
+    for name, sl in (("conditional pass", slice(0, G)), ("unconditional pass", slice(G, 2 * G))):
         x = t[sl]
         print(f"== {name}: workgroups start {x[:, 0].min() - t0:.1f} .. {x[:, 0].max() - t0:.1f} us, last ends {x[:, 22].max() - t0:.1f} us")
         print(f"   issue of K/V DMA + Q loads {np.mean(x[:, 1] - x[:, 0]):.2f} | wait until landed + barrier {np.mean(x[:, 2] - x[:, 1]):.2f} us")
