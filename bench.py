@@ -174,7 +174,7 @@ def main():
 
     from maskbit_amd import _lib
     from maskbit_amd.parallel import gather_images
-    from maskbit_amd.sampling import build_plan, draw_noise, run_loop
+    from maskbit_amd.sampling import build_plan, run_chunked
 
     B = args.batch
     gen, tok = build_models(dev)
@@ -186,8 +186,8 @@ def main():
 
     def one_batch(i: int):
         labels = ((torch.arange(B) + (rank * B + i * world * B)) * 37 % 1000).to(dev)
-        exp_noise, conf_noise = draw_noise(B, 256, 2, 64, NUM_STEPS, SAMPLER["randomize_temperature"], dev)
-        _, u8, _, _ = run_loop(gen, tok, labels, plan, exp_noise, conf_noise, want_steps=False, want_image=False, want_u8=True)
+        # the product's own path (sample() / generate_uint8()): noise drawn chunk by chunk in the reference's generator order, overlapped with the loop
+        _, u8, _, _ = run_chunked(gen, tok, labels, plan, SAMPLER["randomize_temperature"], want_steps=False, want_image=False, want_u8=True)
         return gather_images(u8) if world > 1 else u8
 
     def fence():

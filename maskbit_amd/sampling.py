@@ -46,6 +46,7 @@ def build_plan(num_steps: int, num_maskable: int, guidance_scale: float, guidanc
 
 
 NOISE_CHUNK_BYTES = 1 << 30       # sample() / generate_uint8() draw and feed the Exp(1) noise in step chunks of at most this size
+OVERLAP_CHUNKS = 8                # ... and in at least this many chunks (+ a one-step head): the host draws chunk k+1 while the device runs chunk k
 
 
 def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, randomize_temperature: float,
@@ -68,9 +69,14 @@ def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, random
 
 def step_chunks(num_samples: int, n: int, m: int, C_: int, num_steps: int):
     """[(begin, end)] such that one chunk's Exp(1) noise stays under NOISE_CHUNK_BYTES (the reference holds one step at a time; a whole
-    256-step run at batch 100 would be 6.7 GB)."""
+    256-step run at batch 100 would be 6.7 GB) and that the run has a one-step head followed by >= OVERLAP_CHUNKS chunks: ``mb_sample`` only
+    enqueues work, so the host-side draws of a chunk (the reference's CPU Gumbel noise: ~1.5 ms per step at batch 64, 100 ms per 64-step run
+    when drawn up front) run while the device is busy with the previous chunk -- only the head's draw is exposed."""
     per_step = num_samples * n * m * C_ * 4
     k = max(1, min(num_steps, NOISE_CHUNK_BYTES // max(per_step, 1)))
+    if OVERLAP_CHUNKS > 1 and num_steps > 1:
+        k = max(1, min(k, -(-(num_steps - 1) // OVERLAP_CHUNKS)))
+        return [(0, 1)] + [(b, min(b + k, num_steps)) for b in range(1, num_steps, k)]
     return [(b, min(b + k, num_steps)) for b in range(0, num_steps, k)]
 
 

@@ -211,7 +211,9 @@ def test_step_chunked_run_equals_the_whole_run(scale, monkeypatch):
         parts.append(st)
     assert torch.equal(torch.cat(parts), steps_full) and torch.equal(codes, codes_full)
     assert torch.equal(u8, u8_full) and torch.equal(img, img_full)
-    monkeypatch.setattr(sampling, "NOISE_CHUNK_BYTES", 2 * B * 512 * 64 * 4)    # two steps per chunk
+    assert sampling.step_chunks(B, 256, 2, 64, 64) == [(0, 1)] + [(b, min(b + 8, 64)) for b in range(1, 64, 8)]   # one-step head + >= 8 chunks
+    monkeypatch.setattr(sampling, "OVERLAP_CHUNKS", 1)
+    monkeypatch.setattr(sampling, "NOISE_CHUNK_BYTES", 2 * B * 512 * 64 * 4)    # memory bound alone: two steps per chunk
     assert sampling.step_chunks(B, 256, 2, 64, N) == [(0, 2), (2, 4), (4, 6), (6, 7)]
     torch.manual_seed(5)
     img2, u82, steps2, codes2 = run_chunked(gm, tm, y, plan, 8.2, want_u8=True)  # draws the same streams chunk by chunk
