@@ -352,6 +352,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acce[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // SEQ: class row x this wave row's 2 n-tiles
+    // pair tiles: both 128-token halves of a sequence pair stage the class rows, only the second one (q == 1) stores them -- the first skips their MFMAs
+    const bool cls_on = !PAIR || __builtin_amdgcn_readfirstlane(cur.q) == 1;
     h16x16 xa[MH], wb[2][2];      // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
     if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
@@ -381,9 +383,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0] */ \
       MB_LOAD_B(0) MB_LOAD_A(0)                          /* B first: the first MFMAs need both B fragments and only xa[0] */ \
       h16x16 xe; \
-      if (SEQ && wm == 0) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
+      if (SEQ && wm == 0 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       MB_SYNC_L() \
-      if (SEQ && wm == 0) { \
+      if (SEQ && wm == 0 && cls_on) { \
         if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<0>(acce[0], wb[0][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<1>(acce[1], wb[0][1], xe, wsc, xs_cur[4]); } } \
         else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<0, 0>(acce[0], wb[0][0], xe, wsc, xscc); acce[1] = mma_f4<1, 0>(acce[1], wb[0][1], xe, wsc, xscc); } } \
         else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, true); } \
@@ -395,11 +397,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       MB_MMA(0, 0) \
       /* ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1 */ \
       MB_LOAD_B(1) \
-      if (SEQ && wm == 1) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
+      if (SEQ && wm == 1 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       /* PAIR: the difference rows (A1) take no part in the lo pass (their scale byte is 0): lo K-tiles neither stage nor multiply them */ \
       if (n1 && !(PAIR && LO && t + 1 >= nka)) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
-      if (SEQ && wm == 1) { \
+      if (SEQ && wm == 1 && cls_on) { \
         if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<2>(acce[0], wb[1][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<3>(acce[1], wb[1][1], xe, wsc, xs_cur[4]); } } \
         else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<2, 0>(acce[0], wb[1][0], xe, wsc, xscc); acce[1] = mma_f4<3, 0>(acce[1], wb[1][1], xe, wsc, xscc); } } \
         else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, true); } \
