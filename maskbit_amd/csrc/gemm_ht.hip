@@ -31,7 +31,8 @@
 // (Tried and rejected, twice: starting half of the CUs 4 - 24 us late to de-synchronise those bursts -- slower by the delay itself, in every
 // epilogue form: the epilogue is bound per CU, like the main loop, not by aggregate HBM bandwidth.  Also rejected: 16 residual loads in flight per
 // lane instead of 4 in the fp32+residual epilogue -- same span per tile (tools/ht_trace.py), 23 - 60 spilled VGPRs; and the bias vector parked in
-// LDS instead of fetched per tile -- 0.2 us of a 32 us tile: "pass 1" is bound by the issue of the next tile's 128 KiB prologue DMA.)
+// LDS instead of fetched per tile -- 0.2 us of a 32 us tile: "pass 1" is bound by the issue of the next tile's 128 KiB prologue DMA; and, for
+// GELU tiles, the second wave group doing its arithmetic first and issuing its share of that DMA afterwards -- 1 % slower.)
 #include <algorithm>
 #include <cstdlib>
 
