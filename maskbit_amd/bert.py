@@ -125,14 +125,16 @@ class LFQBert(BaseModel):
         return h
 
     def resolved_precision(self):
-        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch of the headline configuration
-        the cheapest way": guided forwards in differential form where the shape allows it, plain forwards with hi + lo activation pairs."""
+        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch the cheapest way": guided
+        forwards in differential form where the shape allows it -- with the weight-correction pass (cfg_pair 2) from 7 bits per group on, where the
+        fp16 rounding of the weights alone exceeds the bound (measured against the reference's own runs: 14-bit / 256 steps 1.42e-3 without it,
+        6.5e-4 with it; 12-bit / 64 steps 8.4e-4 without it) -- and plain forwards with hi + lo activation pairs."""
         capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm)
         pair, act = int(self.cfg_pair), int(self.act_split)
         if act < 0:
             act = 0 if self.weight_split else resolve_act_split(act, self.hidden_dim, self.mlp_dim)   # fp16x2 weights are not combined with act_split
         if pair < 0:
-            pair = 1
+            pair = 2 if self.bits // self.splits >= 7 else 1
         if not capable:
             pair = 0
         if pair == 2 and (act == 4 or self.weight_split):
