@@ -10,7 +10,9 @@
 // from the stats pass), nearest-2x upsampling is an index shift (>>1) of the source pixel, bias /
 // residual add live in the epilogue, and the last conv writes fp32 NCHW and/or clamp*255 uint8 NHWC.
 // GroupNorm statistics (32 groups, eps 1e-6, autoencoder.py:39-43) are a deterministic two-level
-// reduction (no float atomics), so outputs are bit-stable run to run.
+// reduction (no float atomics), so outputs are bit-stable run to run.  Level one lives in the epilogue of the conv that PRODUCES the tensor
+// (one (sum, sumsq) pair per 8x16-pixel tile and group, written next to the tile), level two in gn_finalize_kernel before the consuming conv;
+// only tensors that no conv of this file produced (the encoder's average-pooled ones) still take the separate sweep (gn_partial_kernel).
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -35,6 +37,8 @@ struct ConvArgs {
   uint8_t* img_u8;       // final conv only
   int B, H, W, Cin, Cout, Cout_pad;
   unsigned* sat;         // counts output groups of 4 whose value left the fp16 range and was clamped (mb_dec_saturation_count)
+  float* gn_part;        // or null: GroupNorm partial statistics of the OUTPUT, [B][pixel tiles per image][32 groups][sum, sumsq] -- the consumer's
+                         // GroupNorm then needs no sweep over the tensor (its fp16-stored values are what is summed, as that sweep did)
 };
 
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -153,6 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: lane holds out[pixel (y = wm*MJ+j, x = l15)][cout = ..+g*4 .. +3]
+  float gs[NI], gq[NI];                     // GroupNorm partials of this lane's 4 channels of n-tile i over its MJ pixels
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const int Y = y0 + wm * MJ + j, X = x0 + l15;
@@ -180,7 +187,44 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
         // activations are stored as fp16: values beyond +-65504 are clamped by to_h -- counted, so that a checkpoint whose decoder needs a
         // wider residual stream is noticed instead of silently clipped (random-init weights stay far inside the range)
         if (fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > MB_H16_MAX) atomicAdd(a.sat, 1u);
-        *(h16x4*)(a.out + pix * a.Cout + n) = h16x4{to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
+        const h16x4 hv = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
+        *(h16x4*)(a.out + pix * a.Cout + n) = hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float f = (float)hv[r]; gs[i] += f; gq[i] = fmaf(f, f, gq[i]); }
+      }
+    }
+  }
+  if constexpr (!FINAL) {
+    if (a.gn_part) {                        // uniform; requires Cout % 128 == 0 and 4 | 8 | 16 channels per group (launch_conv)
+      // 16 pixel columns (lanes of a lane group), then the lane groups that share a GroupNorm group, then the WM wave rows through LDS
+      const int cpg = a.Cout >> 5;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { gs[i] += __shfl_xor(gs[i], o); gq[i] += __shfl_xor(gq[i], o); }
+        if (cpg >= 8) { gs[i] += __shfl_xor(gs[i], 16); gq[i] += __shfl_xor(gq[i], 16); }
+        if (cpg >= 16) { gs[i] += __shfl_xor(gs[i], 32); gq[i] += __shfl_xor(gq[i], 32); }
+      }
+      __syncthreads();                      // everyone is done with the halo / weight tiles: smem is free
+      float* red = (float*)smem;            // [wave][i][g][2]
+      if (l15 == 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { red[((wave * NI + i) * 4 + g) * 2] = gs[i]; red[((wave * NI + i) * 4 + g) * 2 + 1] = gq[i]; }
+      }
+      __syncthreads();
+      // one thread per GroupNorm group of this workgroup's BN channels: channel c0 = first channel of the group inside the tile
+      const int ngrp = BN / cpg;
+      if (tid < ngrp) {
+        const int c0 = tid * cpg, wn_ = c0 / (NI * 16), i_ = (c0 % (NI * 16)) / 16, g_ = (c0 % 16) / 4;
+        float ts = 0.f, tq = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {      // fixed order over the wave rows
+          const int w = m * WN + wn_;
+          ts += red[((w * NI + i_) * 4 + g_) * 2]; tq += red[((w * NI + i_) * 4 + g_) * 2 + 1];
+        }
+        const int ntile = nty * ntx, tile = ty * ntx + tx;
+        float* o = a.gn_part + (((size_t)b * ntile + tile) * 32 + (n0 / cpg + tid)) * 2;
+        o[0] = ts; o[1] = tq;
       }
     }
   }
@@ -221,23 +265,34 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const h16* __restrict__
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float2* __restrict__ out, int HW, int C, int nchunk) {
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float2* __restrict__ out, int HW, int C, int nchunk) {
+  // 256 threads = 32 groups x 8 chunk lanes: lane l sums chunks l, l+8, ... in order, then the 8 lanes are summed in order (fixed association:
+  // bit-stable run to run whatever produced the partials)
+  __shared__ float red[2][8][32];
+  __shared__ float2 ms[32];
+  const int b = blockIdx.x, grp = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int cpg = C / 32;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int grp = c / cpg;
-    float ts = 0.f, tq = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* o = part + (((size_t)b * nchunk + k) * 32 + grp) * 2;
-      ts += o[0]; tq += o[1];
-    }
+  float ts = 0.f, tq = 0.f;
+  for (int k = l; k < nchunk; k += 8) {
+    const float* o = part + (((size_t)b * nchunk + k) * 32 + grp) * 2;
+    ts += o[0]; tq += o[1];
+  }
+  red[0][l][grp] = ts; red[1][l][grp] = tq;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    ts = 0.f; tq = 0.f;
+    for (int k = 0; k < 8; ++k) { ts += red[0][k][grp]; tq += red[1][k][grp]; }
     const float n = (float)HW * (float)cpg;
     const float mean = ts / n;
     const float var = fmaxf(tq / n - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + 1e-6f);
-    const float sc = rstd * gamma[c];
-    out[(size_t)b * C + c] = make_float2(sc, beta[c] - mean * sc);
+    ms[grp] = make_float2(mean, rsqrtf(var + 1e-6f));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float2 m = ms[c / cpg];
+    const float sc = m.y * gamma[c];
+    out[(size_t)b * C + c] = make_float2(sc, beta[c] - m.x * sc);
   }
 }
 
@@ -369,6 +424,8 @@ struct mb_dec {
   unsigned* sat = nullptr;  // device counter: fp16 clamps in the conv epilogues since the last read
   float* gn_part = nullptr;
   float2* gn_ss = nullptr;
+  const void* gn_of = nullptr;   // the tensor whose per-tile GroupNorm partials the last conv left in gn_part (null: none) ...
+  int gn_ntile = 0;              // ... and the number of pixel tiles per image they cover
   std::vector<void*> owned;
 };
 
@@ -409,9 +466,14 @@ bool init_block(mb_dec* d, ResBlock& rb, const std::string& p, int cin, int cout
   return ok;
 }
 
-void launch_conv(hipStream_t s, const Conv& c, const h16* in, const float2* gn, const h16* residual, h16* out,
-                 float* img, uint8_t* u8, int B, int H, int W, bool final_) {
-  ConvArgs a{in, gn, c.w, c.has_bias ? c.b : nullptr, residual, out, img, u8, B, H, W, c.cin_pad, c.cout, c.cout_pad, c.sat};
+void launch_conv(hipStream_t s, mb_dec* d, const Conv& c, const h16* in, const float2* gn, const h16* residual, h16* out,
+                 float* img, uint8_t* u8, int B, int H, int W, bool final_, bool stats = true) {
+  // GroupNorm partials of the output ride in the epilogue when a GroupNorm will read it (stats) and its groups are whole lane groups of a tile
+  const int cpg = c.cout / 32;
+  const bool part = !final_ && stats && c.cout % 128 == 0 && (cpg == 4 || cpg == 8 || cpg == 16);
+  ConvArgs a{in, gn, c.w, c.has_bias ? c.b : nullptr, residual, out, img, u8, B, H, W, c.cin_pad, c.cout, c.cout_pad, c.sat, part ? d->gn_part : nullptr};
+  d->gn_of = part ? (const void*)out : nullptr;
+  d->gn_ntile = (H / TH) * (W / TW);
   const int bn = final_ ? 16 : 128;
   dim3 grid((unsigned)((size_t)B * (H / TH) * (W / TW) * (c.cout_pad / bn))), block(256);
   if (final_) hipLaunchKernelGGL((conv_kernel<1, 1, 3, false, true>), grid, block, 0, s, a);
@@ -422,8 +484,12 @@ void launch_conv(hipStream_t s, const Conv& c, const h16* in, const float2* gn, 
 }
 
 void launch_gn(hipStream_t s, mb_dec* d, const Norm& n, const h16* x, int B, int HW) {
-  int nchunk = HW / 256; if (nchunk < 1) nchunk = 1; if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, d->gn_part, HW, n.c, nchunk);
+  int nchunk = d->gn_ntile;
+  if (d->gn_of != (const void*)x) {                   // not the tensor the last conv summed (average-pooled tensors of the encoder): sweep it
+    nchunk = HW / 256; if (nchunk < 1) nchunk = 1; if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, d->gn_part, HW, n.c, nchunk);
+  }
+  d->gn_of = nullptr;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, d->gn_part, n.g, n.b, d->gn_ss, HW, n.c, nchunk);
 }
 
@@ -431,15 +497,15 @@ void launch_gn(hipStream_t s, mb_dec* d, const Norm& n, const h16* x, int B, int
 int run_block(hipStream_t s, mb_dec* d, const ResBlock& rb, int xi, int B, int H, int W) {
   const int t1 = (xi + 1) % 3, t2 = (xi + 2) % 3;
   launch_gn(s, d, rb.n1, d->buf[xi], B, H * W);
-  launch_conv(s, rb.c1, d->buf[xi], d->gn_ss, nullptr, d->buf[t1], nullptr, nullptr, B, H, W, false);
+  launch_conv(s, d, rb.c1, d->buf[xi], d->gn_ss, nullptr, d->buf[t1], nullptr, nullptr, B, H, W, false);
   launch_gn(s, d, rb.n2, d->buf[t1], B, H * W);
   if (!rb.has_sc) {
-    launch_conv(s, rb.c2, d->buf[t1], d->gn_ss, d->buf[xi], d->buf[t2], nullptr, nullptr, B, H, W, false);
+    launch_conv(s, d, rb.c2, d->buf[t1], d->gn_ss, d->buf[xi], d->buf[t2], nullptr, nullptr, B, H, W, false);
     return t2;
   }
   // shortcut quirk (autoencoder.py:72-73,93-96): out = h + nin_shortcut(h); the block input is dropped
-  launch_conv(s, rb.c2, d->buf[t1], d->gn_ss, nullptr, d->buf[t2], nullptr, nullptr, B, H, W, false);
-  launch_conv(s, rb.sc, d->buf[t2], nullptr, d->buf[t2], d->buf[t1], nullptr, nullptr, B, H, W, false);
+  launch_conv(s, d, rb.c2, d->buf[t1], d->gn_ss, nullptr, d->buf[t2], nullptr, nullptr, B, H, W, false, false);   // read by the shortcut conv, not by a GroupNorm
+  launch_conv(s, d, rb.sc, d->buf[t2], nullptr, d->buf[t2], d->buf[t1], nullptr, nullptr, B, H, W, false);
   return t1;
 }
 
@@ -537,7 +603,8 @@ mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
   }
   for (int i = 0; ok && i < 3; ++i) ok = dalloc(d, &d->buf[i], (size_t)max_batch * max_elems, err);
   ok = ok && dalloc(d, &d->z, (size_t)max_batch * cfg.latent_size * cfg.latent_size * CK, err) &&
-       dalloc(d, &d->gn_part, (size_t)max_batch * GN_MAXCHUNK * 64, err) && dalloc(d, &d->gn_ss, (size_t)max_batch * 4096, err);
+       dalloc(d, &d->gn_part, (size_t)max_batch * std::max(GN_MAXCHUNK, (d->out_res / TH) * (d->out_res / TW)) * 64, err) &&
+       dalloc(d, &d->gn_ss, (size_t)max_batch * 4096, err);
   if (!ok) { dec_destroy(d); return nullptr; }
   return d;
 }
@@ -600,7 +667,7 @@ int dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_n
   const size_t npix = (size_t)B * res * res;
   hipLaunchKernelGGL(latent_kernel, dim3((unsigned)std::min<size_t>(2048, (npix * CK + 255) / 256)), dim3(256), 0, s,
                      tokens, d->z, npix, c.token_size);
-  launch_conv(s, d->conv_in, d->z, nullptr, nullptr, d->buf[0], nullptr, nullptr, B, res, res, false);
+  launch_conv(s, d, d->conv_in, d->z, nullptr, nullptr, d->buf[0], nullptr, nullptr, B, res, res, false);
   int xi = 0;
   for (auto& rb : d->mid) xi = run_block(s, d, rb, xi, B, res, res);
   for (auto& st : d->up) {
@@ -608,12 +675,12 @@ int dec_decode(mb_dec* d, const int64_t* tokens, float* img_nchw, uint8_t* img_n
     if (st.has_up) {
       res *= 2;
       const int t = (xi + 1) % 3;
-      launch_conv(s, st.up, d->buf[xi], nullptr, nullptr, d->buf[t], nullptr, nullptr, B, res, res, false);
+      launch_conv(s, d, st.up, d->buf[xi], nullptr, nullptr, d->buf[t], nullptr, nullptr, B, res, res, false);
       xi = t;
     }
   }
   launch_gn(s, d, d->norm_out, d->buf[xi], B, res * res);
-  launch_conv(s, d->conv_out, d->buf[xi], d->gn_ss, nullptr, nullptr, img_nchw, img_nhwc_u8, B, res, res, true);
+  launch_conv(s, d, d->conv_out, d->buf[xi], d->gn_ss, nullptr, nullptr, img_nchw, img_nhwc_u8, B, res, res, true);
   return 0;
 }
 
@@ -632,7 +699,7 @@ int enc_encode(mb_dec* d, const float* img, int64_t* indices, float* zq, float* 
   const size_t npix = (size_t)B * res * res;
   hipLaunchKernelGGL(pack_image_kernel, dim3((unsigned)std::min<size_t>(4096, (npix * 8 + 255) / 256)), dim3(256), 0, s,
                      img, d->buf[2], B, c.num_channels, res, res);
-  launch_conv(s, d->e_conv_in, d->buf[2], nullptr, nullptr, d->buf[0], nullptr, nullptr, B, res, res, false);
+  launch_conv(s, d, d->e_conv_in, d->buf[2], nullptr, nullptr, d->buf[0], nullptr, nullptr, B, res, res, false);
   int xi = 0;
   for (auto& st : d->e_down) {
     for (auto& rb : st.blocks) xi = run_block(s, d, rb, xi, B, res, res);
@@ -642,6 +709,7 @@ int enc_encode(mb_dec* d, const float* img, int64_t* indices, float* zq, float* 
       if (!c.sample_with_conv) {                           // F.avg_pool2d(2, 2) (autoencoder.py:182)
         hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)std::min<size_t>(4096, (n8 / 4 + 255) / 256)), dim3(256), 0, s, d->buf[xi], d->buf[t], B, res,
                            res, st.up.cin);
+        d->gn_of = nullptr;                             // (no conv wrote this tensor: its GroupNorm takes the separate sweep)
         res /= 2;
         xi = t;
         continue;
@@ -649,14 +717,14 @@ int enc_encode(mb_dec* d, const float* img, int64_t* indices, float* zq, float* 
       hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)std::min<size_t>(4096, (n8 + 255) / 256)), dim3(256), 0, s, d->buf[xi], d->buf[t], B, res, res,
                          st.up.cin);
       res /= 2;
-      launch_conv(s, st.up, d->buf[t], nullptr, nullptr, d->buf[t2], nullptr, nullptr, B, res, res, false);
+      launch_conv(s, d, st.up, d->buf[t], nullptr, nullptr, d->buf[t2], nullptr, nullptr, B, res, res, false);
       xi = t2;
     }
   }
   for (auto& rb : d->e_mid) xi = run_block(s, d, rb, xi, B, res, res);
   launch_gn(s, d, d->e_norm_out, d->buf[xi], B, res * res);
   const int t = (xi + 1) % 3;
-  launch_conv(s, d->e_conv_out, d->buf[xi], d->gn_ss, nullptr, d->buf[t], nullptr, nullptr, B, res, res, false);
+  launch_conv(s, d, d->e_conv_out, d->buf[xi], d->gn_ss, nullptr, d->buf[t], nullptr, nullptr, B, res, res, false);
   const size_t np = (size_t)B * res * res;
   hipLaunchKernelGGL(lfq_kernel, dim3((unsigned)std::min<size_t>(1024, (np + 255) / 256)), dim3(256), 0, s, d->buf[t], indices, zq, zraw, B, res * res,
                      c.token_size, d->e_conv_out.cout);
