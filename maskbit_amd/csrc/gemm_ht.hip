@@ -32,7 +32,11 @@
 // epilogue form: the epilogue is bound per CU, like the main loop, not by aggregate HBM bandwidth.  Also rejected: 16 residual loads in flight per
 // lane instead of 4 in the fp32+residual epilogue -- same span per tile (tools/ht_trace.py), 23 - 60 spilled VGPRs; and the bias vector parked in
 // LDS instead of fetched per tile -- 0.2 us of a 32 us tile: "pass 1" is bound by the issue of the next tile's 128 KiB prologue DMA; and, for
-// GELU tiles, the second wave group doing its arithmetic first and issuing its share of that DMA afterwards -- 1 % slower.)
+// GELU tiles, the second wave group doing its arithmetic first and issuing its share of that DMA afterwards -- 1 % slower.
+// The fp32 + residual output pass is bound per CU AND chip-wide at once: with 256 / 128 / 64 workgroups running it takes 22.5 / 20.4 / 16.8 us per
+// tile (512 KiB read-modify-written in 64-byte row segments), and 256 x 512 KiB in 22.5 us is 5.9 TB/s, the HBM rate.  Landing the residual rows in
+// the free LDS by LDS-DMA instead of registers -- 16 KiB in flight per wave, the next tile's prologue deferred -- left a tile at 18.6 us on 64
+// workgroups and 108 us per launch on 256: not a latency problem.)
 #include <algorithm>
 #include <cstdlib>
 
@@ -707,6 +711,9 @@ static int num_cu_cached() {
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (num_cu <= 0) num_cu = 256;
+#ifdef MB_HT_TRACE
+    if (getenv("MASKBIT_AMD_HT_GRID")) num_cu = atoi(getenv("MASKBIT_AMD_HT_GRID"));   // trace builds: fewer persistent workgroups than CUs
+#endif
   }
   return num_cu;
 }

@@ -48,13 +48,14 @@ def run(mode):
         o32 = torch.empty(M, N, device=dev) if epi == 2 else None
         o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
         fn = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K, None, None, None, None, st()))
+        G = int(os.environ.get("MASKBIT_AMD_HT_GRID", 256))
         trace = torch.zeros(256, 8, 8, dtype=torch.int64, device=dev)
         for _ in range(3): fn()
         torch.cuda.synchronize()
         assert lib.mb_debug_ht_trace(trace.data_ptr()) == 0
         fn(); torch.cuda.synchronize()
         assert lib.mb_debug_ht_trace(None) == 0
-        t = trace.cpu().numpy().astype(np.float64) * 0.01             # us
+        t = trace.cpu().numpy().astype(np.float64)[:G] * 0.01         # us
         ntile = int((t[0, :, 0] > 0).sum())
         t0 = t[:, 0, 0].min()
         print(f"== {name}: N={N} K={K}, {ntile} tiles per workgroup; kernel span {t[:, :ntile, 5 if mode == 2 else 4].max() - t0:.1f} us", flush=True)
