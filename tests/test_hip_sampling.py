@@ -192,6 +192,36 @@ def test_sharded_noise_slices_reproduce_the_single_device_run():
     assert torch.equal(torch.cat([p[0] for p in parts], 0), u8_full)
 
 
+def test_sample_sharded_single_process_equals_the_single_device_run():
+    """parallel.sample_sharded without a process group (world 1) draws and feeds the noise chunk by chunk through mb_sample's step ranges, like
+    sample(): same images as run_chunked under the same seed, in both noise modes (at world 1 "batch" and "rank" noise are the same draws), and a
+    two-rank shard of the same batch (its slice of the batch-level noise, fed chunk by chunk) reproduces its block of the images."""
+    from maskbit_amd import parallel
+    from maskbit_amd.parallel import sample_sharded, shard_range, slice_noise
+    from maskbit_amd.sampling import build_plan, draw_noise, run_chunked, run_loop, step_chunks
+    _, _, gm, tm = tiny_models()
+    y = torch.tensor([3, 1, 4, 1, 5], device=DEV)
+    kw = dict(num_steps=9, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2, mask_schedule_strategy="arccos")
+    plan = build_plan(9, 512, 7.1, "cosine", 3.0, 1.0, False, "arccos")
+    torch.manual_seed(11)
+    _, want, _, _ = run_chunked(gm, tm, y, plan, 8.2, want_steps=False, want_image=False, want_u8=True)
+    for mode in ("batch", "rank"):
+        torch.manual_seed(11)
+        got = sample_sharded(gm, tm, y, noise=mode, **kw)
+        assert torch.equal(got, want), mode
+    # what rank 1 of 2 would compute: its rows of the batch-level noise, chunk by chunk
+    lo, hi = shard_range(1, 2, 5)
+    torch.manual_seed(11)
+    u8 = None
+    chunks = step_chunks(5, 256, 2, 64, 9)
+    assert len(chunks) > 2
+    for (b0, b1) in chunks:
+        e, c = draw_noise(5, 256, 2, 64, 9, 8.2, torch.device(DEV), b0, b1)
+        e, c = slice_noise(e, c, lo, hi, 512)
+        _, u8, _, _ = run_loop(gm, tm, y[lo:hi], plan, e, c, want_steps=False, want_image=False, want_u8=True, step_range=(b0, b1))
+    assert torch.equal(u8, want[lo:hi])
+
+
 @pytest.mark.parametrize("scale", [7.1, 0.0])
 def test_step_chunked_run_equals_the_whole_run(scale, monkeypatch):
     """mb_sample over step ranges (mb_sample_plan.step_begin / step_end) with the noise drawn chunk by chunk is bit-identical to one
