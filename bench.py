@@ -129,11 +129,48 @@ def build_models(dev):
 def measured_parity(gen):
     """Teacher-forced token mismatch of the engine's CURRENT precision mode against the real reference's full-size 64-step run
     (tests/golden/sample_full12_64.npz, made by oracle/make_golden.py full64 with these same weights): 84 284 sampled positions."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     bad, tot, _, _ = R.teacher_forced(gen)
     return {"token_mismatch": bad / tot, "mismatches": bad, "positions": tot,
             "against": "the reference's own sample() run, CPU fp32 (tests/golden/sample_full12_64.npz), teacher-forced per step"}
+
+
+def other_configs(dev):
+    """One batch each of the other BASELINE configurations through the same sample() path (outside the timed region, N = 1): configs[1] =
+    10-bit generator, 16 steps, no guidance, batch 16 (as named) and 64; configs[4]'s per-GPU shard = 14-bit, 256 steps, CFG 5.8 cosine, batch 32.
+    Generators and sampler settings are those of the reference's own recorded runs (tests/golden/sample_full10_16_nocfg / sample_full14_256);
+    decode to uint8 included.  -> {name: {images_per_s, ms_per_batch, batch, precision}}"""
+    from maskbit_amd import ConvVQModel, synth
+    from maskbit_amd import parity_replay as R
+    from maskbit_amd.sampling import build_plan, run_chunked
+    out = {}
+    for tag, run, batches in (("configs[1] 10-bit/16 steps/no CFG", R.RUN_CFG1, (16, 64)), ("configs[4] shard 14-bit/256 steps/CFG 5.8", R.RUN_CFG5, (32,))):
+        g = R.load_run(run)
+        gen, _ = R.build_models(dev, with_tokenizer=False, name=run)
+        bits = int(g["bits"])
+        cfg = tok_config(); cfg["codebook_size"], cfg["token_size"] = 2 ** bits, bits
+        tok = ConvVQModel(cfg)
+        tok.load_state_dict(synth.make_tokenizer_weights(synth.TokCfg(token_size=bits), seed=7), strict=False)
+        tok = tok.eval().requires_grad_(False).to(dev)
+        kw = g["kw"]
+        plan = build_plan(int(kw["num_steps"]), 512, float(kw["guidance_scale"]), kw["guidance_annealing"], float(kw["scale_pow"]), 1.0, False,
+                          kw["mask_schedule_strategy"])
+        rt = float(kw["randomize_temperature"])
+        for B in batches:
+            labels = (torch.arange(B) * 37 % 1000).to(dev)
+            torch.manual_seed(0)
+            reps = 3 if int(kw["num_steps"]) < 100 else 1
+            for timed in (False, True):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps if timed else 1):
+                    run_chunked(gen, tok, labels, plan, rt, want_steps=False, want_image=False, want_u8=True)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            out[f"{tag}, batch {B}"] = {"images_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B,
+                                        "precision": "LFQBert (act_split, cfg_pair) = %s" % (gen.resolved_precision(),)}
+        del gen, tok
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -188,7 +225,7 @@ def main():
         labels = ((torch.arange(B) + (rank * B + i * world * B)) * 37 % 1000).to(dev)
         # the product's own path (sample() / generate_uint8()): noise drawn chunk by chunk in the reference's generator order, overlapped with the loop
         _, u8, _, _ = run_chunked(gen, tok, labels, plan, SAMPLER["randomize_temperature"], want_steps=False, want_image=False, want_u8=True)
-        return gather_images(u8) if world > 1 else u8
+        return gather_images(u8, equal=True) if world > 1 else u8      # every rank holds B images: one collective per batch, no size exchange
 
     def fence():
         torch.cuda.synchronize()
@@ -227,6 +264,12 @@ def main():
         one_batch(10_001); torch.cuda.synchronize()
         modes[other] = {"images_per_s": B / (time.perf_counter() - ts), "timed": False, "parity": measured_parity(gen)}
         gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
+    others = None
+    if world == 1 and not args.no_modes and B == B_PER_GPU:
+        try:
+            others = other_configs(dev)
+        except Exception as e:                              # noqa: BLE001  (context only: never costs the headline line)
+            others = {"error": repr(e)}
 
     if rank == 0:
         total_images = B * world * args.steps
@@ -244,7 +287,7 @@ def main():
             fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
             traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.*), if present
             traffic_src = None
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if B == B_PER_GPU and args.mode in pmc.get("_mode", "fp16"):
@@ -256,10 +299,14 @@ def main():
             roofline = {"bound": "mfma", "kernel": f"gemm_ht_kernel ({dom}: M={M}, N={4096 if dom == 'gemm_ffn_up' else (3072 if dom == 'gemm_qkv' else 1024)}, "
                                                    f"K={4096 if dom == 'gemm_ffn_down' else 1024})",
                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                        "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src})",
+                        "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE+WRITE_SIZE) from a committed rocprofv3 --pmc pass of this kernel, profiles/{traffic_src}: "
+                                        "NOT measured in this run",
                         "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
                         "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
-                        "end_to_end_frac": value / world * (2 * NUM_STEPS * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
+                        # executed sequence-forwards per image: two per guided step, one where the annealed scale is exactly 0 (the loop skips the
+                        # unconditional forward there: c + 0 (c - u) == c)
+                        "seq_forwards_per_image": sum(2 if a != 0.0 else 1 for a in plan[0]),
+                        "end_to_end_frac": value / world * (sum(2 if a != 0.0 else 1 for a in plan[0]) * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
             # the two other rooflines the north star names: attention core on MFMA, decoder on HBM
             if "attention" in prof:
                 c_, ms_ = prof["attention"]
@@ -289,6 +336,8 @@ def main():
                                     "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u)",
                           "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
             "precision_modes": modes,
+            "other_configs": others,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
             "kernels_note": f"HIP events on the launch stream inside the timed region; generator kernels sampled on every {PROF_EVERY}th forward",
         }
         print(json.dumps(line), flush=True)

@@ -94,7 +94,10 @@ typedef struct {
   const int* mask_len;         /* [num_steps] floor(mask_ratio * n*m) (sampling.py:120-123)       */
   /* Step chunk of this call: step_end = 0 -> the whole run; otherwise steps [step_begin, step_end) -- the first chunk (step_begin 0) starts from the
    * all-masked state, later chunks continue from the state the engine kept, the last one (step_end = num_steps) combines and decodes.  The noise and
-   * step_tokens pointers of a call hold the steps of ITS chunk (chunk-relative), the arrays above the whole run. */
+   * step_tokens pointers of a call hold the steps of ITS chunk (chunk-relative), the arrays above the whole run.  A chunk is accepted only as the
+   * exact continuation of the run in progress on that handle (same B, num_steps, use_guidance; step_begin = the previous chunk's step_end): a
+   * generator handle is NOT re-entrant while a chunked run is in progress -- two interleaved runs need two handles.
+   * Steps whose scale[i] is exactly 0 run the conditional forward alone (c + 0 (c - u) == c: the unconditional forward cannot change the result). */
   int step_begin, step_end;
 } mb_sample_plan;
 
@@ -114,8 +117,8 @@ int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, cons
                    float* logits, int nb, mb_stream stream);
 /* The guided forward of sample() (sampling.py:83-88): tokens int64 [B,seq,m], labels int64 [B] -> logits fp32 [2B,seq,m,C], rows [0,B) the
  * conditional and [B,2B) the label-dropped forward of the same tokens.  With cfg.cfg_pair the two streams run in differential form
- * (see mb_gen_cfg.cfg_pair); `scale` is the step's guidance scale (a hint for the precision plan: pass the value the logits will be
- * combined with, or a negative number when unknown). */
+ * (see mb_gen_cfg.cfg_pair).  `scale` is reserved (ignored: the precision of the forward does not depend on the guidance scale); pass the
+ * step's scale or any number. */
 int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, mb_stream stream);
 /* The same forward with `return_attn=True` (bert.py:461, 505-508; nn.MultiheadAttention need_weights with head averaging,
  * bert.py:119,137): additionally attn fp32 [depth, nb, seq+1, seq+1], layer l's softmax weights averaged over the heads
@@ -207,6 +210,9 @@ int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W
                       float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
             void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
+/* Persistent kernels launch one workgroup per CU.  On a stream created with a CU mask (hipExtStreamCreateWithCUMask) fewer CUs serve the launch:
+ * n = the CUs the following launches should size their grids for, 0 = the device's count (default).  Process-wide, not thread-safe. */
+int mb_set_cu_count(int n);
 int mb_prof_enable(int on); /* 0 off; n >= 1: HIP-event timing of every kernel of every n-th generator forward (and of all other calls) */
 int mb_prof_read(char* buf, int buflen); /* host buffer; writes "name calls total_ms\n" lines */
 

@@ -68,6 +68,7 @@ SIGNATURES = {
                                     C.c_int, C.c_void_p]),
     "mb_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_void_p]),
+    "mb_set_cu_count": (C.c_int, [C.c_int]),
     "mb_prof_enable": (C.c_int, [C.c_int]),
     "mb_prof_read": (C.c_int, [C.c_char_p, C.c_int]),
 }

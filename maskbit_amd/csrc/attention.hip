@@ -579,8 +579,8 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
   if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   dim3 grid(P * heads), block(64 * ATT_NW);
-  const char* pm = getenv("MASKBIT_AMD_ATT_PAIR");                 // A/B switch, read per call (tools/forward_ab.py flips it inside one process):
-  const int pair_mode = pm ? atoi(pm) : 4;                         // 4 (default) / 2 (two launches through aux)
+  // A/B switch, read once per process: 4 (default) = one launch / 2 = two launches through the fp32 aux rows
+  static const int pair_mode = getenv("MASKBIT_AMD_ATT_PAIR") ? atoi(getenv("MASKBIT_AMD_ATT_PAIR")) : 4;
   if (out4 && dh != 64) return -1;         // the fp4 output exists for head dimension 64
   if (pair_mode == 4) {                    // one workgroup per (pair, head): conditional pass, then the twin; conditional outputs parked in registers
     // 88 us against 119 us for the two launches (B = 64 pairs): a third of the traffic was the fp32 aux round trip

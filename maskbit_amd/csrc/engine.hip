@@ -131,7 +131,10 @@ struct mb_gen {
   uint8_t *att4 = nullptr, *att4s = nullptr, *h4 = nullptr, *h4s = nullptr;              // e2m1 of the conditional attention outputs / FFN hiddens + block scales
   int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
   // loop state for mb_sample
-  int loop_B = 0;                                       // samples of the run mb_sample is in the middle of (step chunks)
+  // the run mb_sample is in the middle of (step chunks): samples, total steps, guidance flag, the step the next chunk must begin with (-1: no run)
+  int loop_B = 0, loop_steps = 0, loop_guided = 0, loop_next = -1;
+  const int64_t* cfg_labels_ready = nullptr;            // gen_forward_cfg: lab_cfg / drop_cfg already hold [labels | labels] / [0 | 1] for this many pairs
+  int cfg_ready_B = 0;
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
   uint8_t* drop_cfg = nullptr;
   float* logits = nullptr;
@@ -171,6 +174,9 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   // cfg_pair == 2 outside a guided forward (plain forward(), sampling without guidance): weight rounding is the dominant logit error there, so the
   // QKV / FFN-up GEMMs always carry the MX-fp4 weight-correction pass (x4 = e2m1 of the LayerNorm VALUES against e2m1(W - fp16(W)))
   const bool wm = g->pair_ok && c.cfg_pair == 2 && !c.act_split && !c.weight_split;   // (with act_split the plain forward runs its hi + lo pairs instead)
+  // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
+  uint8_t* const x4p = (x4m || wm) ? g->x4 : nullptr;
+  uint8_t* const x4sp = (x4m || wm) ? g->x4s : nullptr;
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
@@ -195,7 +201,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
     e.x_lo = c.depth ? xlo_trunk : g->x_lo;
-    e.x8 = x8p; e.x4 = g->x4; e.x4_scale = g->x4s; e.x4_values = wm;
+    e.x8 = x8p; e.x4 = x4p; e.x4_scale = x4sp; e.x4_values = wm;
     embed_ln(s, e);
   }
   if (c.prenorm) {
@@ -203,7 +209,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
     for (int l = 0; l < c.depth; ++l) {
       const mb_gen::Layer& L = g->layers[l];
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s, wm); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, x4p, x4sp, wm); }
       { ProfScope p("gemm_qkv", s, true);
         xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
       if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
@@ -213,7 +219,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
         GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
         split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
         gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, g->x4, g->x4s, wm); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, x4p, x4sp, wm); }
       { ProfScope p("gemm_ffn_up", s, true);
         xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
       { ProfScope p("gemm_ffn_down", s, true);
@@ -238,7 +244,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
       gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, g->x4, g->x4s, wm); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, x4p, x4sp, wm); }
     { ProfScope p("gemm_ffn_up", s, true);
       xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
     { ProfScope p("gemm_ffn_down", s, true);
@@ -246,7 +252,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
       gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p, g->x4, g->x4s, wm); }   // the last one feeds the head
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p, x4p, x4sp, wm); }   // the last one feeds the head
   }
   }
   { ProfScope p("gemm_head", s, true);
@@ -282,7 +288,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   int rc = 0;
   // measured (tests/diag/weight_subset_study.py): the weight rounding of the SECOND half of the trunk is what costs token parity (exact weights in
   // layers 0..11 alone: no gain; in layers 12..23: most of the gain) -> the correction pass runs in layers >= depth / 2 only
-  const int wfrom = getenv("MASKBIT_AMD_WFROM") ? atoi(getenv("MASKBIT_AMD_WFROM")) : 0;   // first layer with the correction pass (experiments)
+  static const int wfrom = getenv("MASKBIT_AMD_WFROM") ? atoi(getenv("MASKBIT_AMD_WFROM")) : 0;   // first layer with the correction pass (experiments; read once)
   auto x4_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4 : nullptr; };
   auto x4s_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4s : nullptr; };
   auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo,
@@ -370,10 +376,12 @@ int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, flo
     const int nc = B - b0 < chunk ? B - b0 : chunk;
     HIP_TRY(hipMemcpyAsync(g->tok_cfg, tokens + (size_t)b0 * P, nc * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(g->tok_cfg + nc * P, tokens + (size_t)b0 * P, nc * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(g->lab_cfg, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(g->lab_cfg + nc, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(g->drop_cfg, 0, nc, s));
-    HIP_TRY(hipMemsetAsync(g->drop_cfg + nc, 1, nc, s));
+    if (!(nc == B && g->cfg_labels_ready == labels && g->cfg_ready_B == B)) {   // (mb_sample marks them ready for the steps of one call)
+      HIP_TRY(hipMemcpyAsync(g->lab_cfg, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(g->lab_cfg + nc, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemsetAsync(g->drop_cfg, 0, nc, s));
+      HIP_TRY(hipMemsetAsync(g->drop_cfg + nc, 1, nc, s));
+    }
     float* out = (nc == B) ? logits : g->logits_tmp;    // chunked: through a buffer of the engine's own, then to the two halves of the caller's
     int rc = pair ? gen_forward_pair_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, out, nc, wmode, s)
                   : gen_forward_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, out, 2 * nc, s);
@@ -393,6 +401,7 @@ extern "C" {
 int mb_abi_version(void) { return MB_ABI_VERSION; }
 const char* mb_last_error(void) { return g_err.c_str(); }
 
+int mb_set_cu_count(int n) { mb::set_cu_count(n); return 0; }
 int mb_prof_enable(int on) {
   if (!on) g_prof.drain();
   g_prof.on = on != 0;
@@ -841,33 +850,45 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
   // the all-masked state, later chunks continue from the token state the engine kept; exp_noise / conf_noise / step_tokens hold THIS chunk's steps.
   const int s0 = plan->step_end > 0 ? plan->step_begin : 0, s1 = plan->step_end > 0 ? plan->step_end : plan->num_steps;
   if (s0 < 0 || s1 > plan->num_steps || s0 >= s1) return fail(-1, "mb_sample: step chunk [%d, %d) outside [0, %d)", s0, s1, plan->num_steps);
-  if (s0 == 0) { mb::fill_i64(s, g->tok_a, (int64_t)C, (size_t)B * P); g->loop_B = B; }
-  else if (g->loop_B != B) return fail(-1, "mb_sample: step chunk [%d, %d) continues a run of %d samples with B = %d", s0, s1, g->loop_B, B);
+  // A run fed in chunks keeps its token state in the engine: a chunk is accepted only as the exact continuation of the run in progress (same batch,
+  // plan length and guidance flag, beginning where the previous chunk ended).  The handle is not re-entrant while a run is in progress.
+  if (s0 == 0) { mb::fill_i64(s, g->tok_a, (int64_t)C, (size_t)B * P); g->loop_B = B; g->loop_steps = plan->num_steps; g->loop_guided = plan->use_guidance != 0; }
+  else if (g->loop_next != s0 || g->loop_B != B || g->loop_steps != plan->num_steps || g->loop_guided != (plan->use_guidance != 0))
+    return fail(-1, "mb_sample: step chunk [%d, %d) of a %d-step run with B = %d does not continue the run in progress (next step %d of %d, B = %d)",
+                s0, s1, plan->num_steps, B, g->loop_next, g->loop_steps, g->loop_B);
+  g->loop_next = -1;                                   // (set again below when this chunk has been enqueued and more follow)
   int64_t* cur = (s0 & 1) ? g->tok_b : g->tok_a;
   int64_t* nxt = (s0 & 1) ? g->tok_a : g->tok_b;
   int64_t* last_pred = g->pred;
+  g->cfg_labels_ready = nullptr;
   for (int i = s0; i < s1; ++i) {
     const float* lc = g->logits;
     const float* lu = nullptr;
     int rc;
-    if (plan->use_guidance) {
+    // sampling.py:98-99 combines c + s_i (c - u).  Where the annealed scale s_i is exactly 0 -- the first steps of the cosine schedule: (i / N)^p pi
+    // is below float32's cos() resolution -- the unconditional logits do not enter the result (c + 0 (c - u) == c for finite logits), so that
+    // forward is not run: the step is the plain conditional forward, bit for bit what the guided expression evaluates to.
+    if (plan->use_guidance && plan->scale[i] != 0.0f) {
       rc = gen_forward_cfg(g, cur, labels, g->logits, B, plan->scale[i], s);
       lu = g->logits + (size_t)B * P * C;
+      if (B <= g->chunk_seqs / 2) { g->cfg_labels_ready = labels; g->cfg_ready_B = B; }   // lab_cfg / drop_cfg stay valid for the rest of this call
     } else {
       rc = gen_forward(g, cur, labels, nullptr, g->logits, B, s);
     }
-    if (rc) return rc;
+    if (rc) { g->cfg_labels_ready = nullptr; return rc; }
     const size_t k = (size_t)(i - s0);                 // the noise / step_tokens buffers hold this chunk's steps
     int64_t* pred = step_tokens ? step_tokens + k * B * P : g->pred;
     rc = mb_sample_step(lc, lu, plan->scale[i], plan->temperature[i], exp_noise + k * B * P * C,
                         conf_noise + k * B * P, plan->mask_len[i], cur, nxt, pred, B, n, m, C, stream);
-    if (rc) return rc;
+    if (rc) { g->cfg_labels_ready = nullptr; return rc; }
     last_pred = pred;
     int64_t* t = cur; cur = nxt; nxt = t;
   }
+  g->cfg_labels_ready = nullptr;
   if (s1 < plan->num_steps) {                          // more chunks follow: keep the last predictions only if they are the engine's own buffer
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+    g->loop_next = s1;
     return 0;
   }
   // combine_factorized_tokens (factorization.py:7-24) on the LAST step's predictions, kept as integers

@@ -704,8 +704,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #undef MB_F4_ONE
 }
 
+static int g_cu_override = 0;   // mb_set_cu_count: the CUs a persistent grid is sized for (a stream created with a CU mask sees fewer than the device has)
+void set_cu_count(int n) { g_cu_override = n > 0 ? n : 0; }
 static int num_cu_cached() {
   static int num_cu = 0;
+  if (g_cu_override) return g_cu_override;
   if (!num_cu) {
     int dev = 0;
     (void)hipGetDevice(&dev);

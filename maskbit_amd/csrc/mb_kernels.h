@@ -76,6 +76,7 @@ struct GemmArgs {
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   // 0, or -1: lo-pass request outside the half-tile kernel's shapes
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
+void set_cu_count(int n);   // persistent grids are sized for n CUs (0 = the device's count): for launches on CU-masked streams
 // e4m3 copy of a weight (row stride 2K bytes, first K used) for the fp8 correction pass; *exp_out = the power of two it was scaled by
 void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp);
 

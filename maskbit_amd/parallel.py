@@ -8,8 +8,14 @@ single-device, eval_maskbit.py:65).
 
 For bit-parity with a single-device run of the same global batch, a rank must consume *its slice of
 the batch-level noise* (noise tensors are row-major in the batch, so slices are contiguous) rather
-than re-seeding per rank: ``sample_sharded(..., noise="batch")`` does that.  ``noise="rank"`` draws
-only the local shard's noise (independent streams per rank; cheaper host-side RNG at large N).
+than re-seeding per rank: ``sample_sharded(..., noise="batch")`` does that -- every rank then draws the
+WHOLE batch's noise and keeps its rows (torch's generators cannot skip ahead, and the reference's CPU Gumbel
+draw is ~12 ms per step at a global batch of 512), so it is the mode for REPRODUCING a single-device run, not
+the throughput mode.  ``noise="rank"`` (the default) draws only the local shard's noise: the cost per rank does
+not grow with the world size; the caller seeds each rank differently (``torch.manual_seed(seed + rank)``, as
+bench.py does), otherwise all ranks would sample the same images.
+When the batch divides evenly over the ranks a batch costs exactly ONE collective (``all_gather_into_tensor``
+of the uint8 block) and no host synchronisation; only ragged batches exchange block sizes first.
 """
 from __future__ import annotations
 
@@ -33,19 +39,25 @@ def slice_noise(exp_noise: torch.Tensor, conf_noise: torch.Tensor, lo: int, hi: 
     return (exp_noise[:, lo * rows_per_sample:hi * rows_per_sample].contiguous(), conf_noise[:, lo:hi].contiguous())
 
 
-def gather_images(local: torch.Tensor, group=None) -> torch.Tensor:
-    """all_gather of per-rank image blocks [b_r, ...] -> [sum b_r, ...] in rank order.  Equal block sizes use a
-    single all_gather_into_tensor (one RCCL collective); ragged blocks fall back to all_gather of padded blocks."""
+def gather_images(local: torch.Tensor, group=None, equal: Optional[bool] = None) -> torch.Tensor:
+    """all_gather of per-rank image blocks [b_r, ...] -> [sum b_r, ...] in rank order.
+    ``equal=True``: the caller knows every rank holds the same number of rows (the batch divides evenly over the ranks): ONE
+    all_gather_into_tensor, no size exchange, no host synchronisation.  ``equal=None``: the block sizes are exchanged first (one small
+    all_gather + a host sync) and equal blocks still take the single-collective path; ragged blocks are padded and gathered."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo" and local.is_cuda:          # test-only path: gloo collectives on host copies
-        return gather_images(local.cpu(), group).to(local.device)
+        return gather_images(local.cpu(), group, equal).to(local.device)
+    local = local.contiguous()
+    if equal:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
     sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
     sizes = [int(s.item()) for s in sizes]
-    local = local.contiguous()
     if len(set(sizes)) == 1:
         out = torch.empty((world * sizes[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local, group=group)
@@ -59,14 +71,14 @@ def gather_images(local: torch.Tensor, group=None) -> torch.Tensor:
 
 
 @torch.no_grad()
-def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: str = "batch", group=None,
+def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: str = "rank", group=None,
                    num_steps: int = 64, guidance_scale: float = 7.1, guidance_annealing: str = "cosine", scale_pow: float = 3.0,
                    softmax_temperature: float = 1.0, use_sampling_annealing: bool = False, randomize_temperature: float = 8.2,
                    mask_schedule_strategy: str = "arccos") -> torch.Tensor:
     """Sample ``len(global_labels)`` images across the process group; every rank returns all images,
-    uint8 NHWC, identical on every rank (and, with ``noise="batch"``, identical to a 1-GPU run)."""
+    uint8 NHWC, identical on every rank (and, with ``noise="batch"``, identical to a 1-GPU run of the same seed; see the module docstring)."""
     import torch.distributed as dist
-    from .sampling import _ForcedPlan, build_plan, draw_noise, run_loop, step_chunks
+    from .sampling import _ForcedPlan, build_plan, draw_noise, plan_arrays, run_loop, step_chunks
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     B = int(global_labels.numel())
@@ -88,11 +100,12 @@ def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: st
         return gather_images(torch.empty((0, side, side, vqgan_model.num_channels), dtype=torch.uint8, device=dev), group)
     chunks = step_chunks(nb, n, m, C_, num_steps)
     labels = global_labels[lo:hi].to(dev)
+    cplan = plan_arrays(plan)
     u8 = None
     for (b0, b1) in chunks:
         e, c = draw_noise(nb, n, m, C_, num_steps, randomize_temperature, dev, b0, b1)
         if noise == "batch":
             e, c = slice_noise(e, c, lo, hi, n * m)
         _, u8, _, _ = run_loop(model, vqgan_model, labels, plan, e, c, want_steps=False, want_image=False, want_u8=True,
-                               step_range=(b0, b1) if len(chunks) > 1 else None)
-    return gather_images(u8, group)
+                               step_range=(b0, b1) if len(chunks) > 1 else None, _cplan=cplan)
+    return gather_images(u8, group, equal=(B % world == 0) or None)

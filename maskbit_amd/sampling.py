@@ -92,6 +92,7 @@ def run_chunked(model: "LFQBert", vqgan_model, labels: torch.Tensor, plan, rando
         return run_loop(model, vqgan_model, labels, plan, e, c, **kw)
     want_steps = kw.get("want_steps", True)
     parts, out = [], None
+    kw = dict(kw, _cplan=plan_arrays(plan))              # the ctypes arrays of the plan are built once per run, not once per chunk
     for (b0, b1) in chunks:
         e, c = draw_noise(B, n, m, model.effective_codebook_size, steps, randomize_temperature, model.device, b0, b1)
         out = run_loop(model, vqgan_model, labels, plan, e, c, step_range=(b0, b1), **kw)
@@ -101,9 +102,17 @@ def run_chunked(model: "LFQBert", vqgan_model, labels: torch.Tensor, plan, rando
     return img, u8, (torch.cat(parts) if want_steps else None), codes
 
 
+def plan_arrays(plan):
+    """The plan as the ctypes arrays ``mb_sample`` reads (+ whether any step is guided)."""
+    scale, temp, mask_len = plan
+    nsteps = len(scale)
+    use_cfg = any(s != 0.0 for s in scale) or getattr(plan, "force_guidance", False)
+    return (C.c_float * nsteps)(*scale), (C.c_float * nsteps)(*temp), (C.c_int * nsteps)(*mask_len), use_cfg
+
+
 def run_loop(model: LFQBert, vqgan_model: Optional[ConvVQModel], labels: torch.Tensor, plan, exp_noise: torch.Tensor,
              conf_noise: torch.Tensor, want_steps: bool = True, want_image: bool = True, want_u8: bool = False,
-             step_range: Optional[Tuple[int, int]] = None):
+             step_range: Optional[Tuple[int, int]] = None, _cplan=None):
     """One ``mb_sample`` call.  -> (image or None, uint8 NHWC or None, step tokens [steps,B,n,m] or None, codes [B,n]).
     ``step_range`` = (begin, end): only those steps of the plan, with ``exp_noise`` / ``conf_noise`` holding that chunk's noise; chunk (0, e)
     starts the run, later chunks continue from the engine's token state, the chunk ending at the last step combines and decodes (image / codes
@@ -117,13 +126,14 @@ def run_loop(model: LFQBert, vqgan_model: Optional[ConvVQModel], labels: torch.T
         raise ValueError(f"noise holds {exp_noise.shape[0]} steps, the step range {steps}")
     B = labels.shape[0]
     n, m = model.seq_len, model.splits
-    use_cfg = any(s != 0.0 for s in scale) or getattr(plan, "force_guidance", False)
+    c_scale, c_temp, c_len, use_cfg = _cplan if _cplan is not None else plan_arrays(plan)
     labels = labels.to(device=dev, dtype=torch.int64).contiguous()
     step_tokens = torch.empty((steps, B, n, m), dtype=torch.int64, device=dev) if want_steps else None
-    codes = torch.empty((B, n), dtype=torch.int64, device=dev)
+    last = se == nsteps                                  # only the chunk that ends the run combines and decodes: earlier chunks need no outputs
+    codes = torch.empty((B, n), dtype=torch.int64, device=dev) if last else None
     img = u8 = None
     hdec = None
-    if vqgan_model is not None and (want_image or want_u8):
+    if last and vqgan_model is not None and (want_image or want_u8):
         side = int(round(n ** 0.5))
         res = side << (vqgan_model.num_resolutions - 1)
         if want_image:
@@ -132,14 +142,11 @@ def run_loop(model: LFQBert, vqgan_model: Optional[ConvVQModel], labels: torch.T
             u8 = torch.empty((B, res, res, vqgan_model.num_channels), dtype=torch.uint8, device=dev)
         hdec = vqgan_model.engine(B, side)
     hgen = model.engine(2 * B if use_cfg else B)
-    c_scale = (C.c_float * nsteps)(*scale)
-    c_temp = (C.c_float * nsteps)(*temp)
-    c_len = (C.c_int * nsteps)(*mask_len)
     cplan = _lib.SamplePlan(nsteps, 1 if use_cfg else 0, c_scale, c_temp, c_len, sb if step_range is not None else 0, se if step_range is not None else 0)
     ptr = lambda t: t.data_ptr() if t is not None else None
     with torch.cuda.device(dev):
         _lib.check(_lib.load().mb_sample(hgen, hdec, C.byref(cplan), labels.data_ptr(), B, exp_noise.data_ptr(),
-                                         conf_noise.data_ptr(), ptr(step_tokens), codes.data_ptr(), ptr(img), ptr(u8),
+                                         conf_noise.data_ptr(), ptr(step_tokens), ptr(codes), ptr(img), ptr(u8),
                                          torch.cuda.current_stream().cuda_stream), "mb_sample")
     return img, u8, step_tokens, codes
 

@@ -107,10 +107,13 @@ FULL64 = dict(num_steps=64, guidance_scale=7.1, guidance_annealing="cosine", sca
 # guidance off as BASELINE.json names it); configs[4]: 14-bit generator, configs/generator/maskbit_generator_14bit_256steps.yaml:38-44
 CFG1_16 = dict(num_steps=16, guidance_scale=0.0, guidance_annealing="none", scale_pow=4.0, randomize_temperature=10.5, mask_schedule_strategy="arccos")
 CFG5_256 = dict(num_steps=256, guidance_scale=5.8, guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=10.3, mask_schedule_strategy="arccos")
-RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs, with decode)
+RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs, with decode[, noise seed, first label index])
     "sample_full12_64": (12, 100, 12.0, 4, FULL64, True),
     "sample_full10_16_nocfg": (10, 101, 12.0, 16, CFG1_16, False),
     "sample_full14_256": (14, 102, 12.0, 2, CFG5_256, False),
+    # a second full-size 12-bit run of the real reference: other generator weights (seed, head gain), other noise seed, other labels -- the parity
+    # figure of configs[2] is then not a single-draw result (round-2 review, item 3)
+    "sample_full12_64_s2": (12, 177, 16.0, 4, FULL64, False, 4321, 8),
 }
 
 
@@ -120,7 +123,11 @@ def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
     state the model saw (bit-packed mask: what a teacher-forced replay needs); for the 12-bit run also the final codes, pixel crops, a
     4x-subsampled uint8 image and hashes.  Weights are regenerated from seeds (sha-guarded), noise from the seed (torch CPU generator,
     draw order of the reference on a CPU model)."""
-    bits, gseed, gain, B, kw, decode = RUNS[name]
+    bits, gseed, gain, B, kw, decode = RUNS[name][:6]
+    if len(RUNS[name]) > 6:
+        seed, lab0 = RUNS[name][6:8]
+    else:
+        lab0 = 0
     gcfg = O.GenCfg(bits=bits, splits=2)
     C_ = gcfg.group_codes
     gsd = O.make_generator_weights(gcfg, seed=gseed, head_gain=gain)
@@ -128,7 +135,7 @@ def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
     tcfg = O.TokCfg(token_size=bits)
     tsd = O.make_tokenizer_weights(tcfg, seed=200)
     tok = build_ref_tok(ConvVQModel, tcfg, O.make_tokenizer_weights(tcfg, seed=200, with_encoder=True))
-    labels = torch.tensor([7, 282, 604, 980, 1, 404, 850, 33, 512, 111, 927, 65, 340, 771, 208, 999][:B])
+    labels = torch.tensor([7, 282, 604, 980, 1, 404, 850, 33, 512, 111, 927, 65, 340, 771, 208, 999][lab0:lab0 + B])
     seen = []
     inner = gen.forward
 

@@ -1,159 +1,3 @@
-"""Replay of the REAL reference's full-size 64-step run (tests/golden/sample_full12_64.npz) through the HIP engine.
-
-The fixture was written by ``oracle/make_golden.py full64``: the reference's own ``sample()`` (sampling.py:55-136) on the
-12-bit generator, 64 steps, CFG 7.1 cosine, arccos schedule, CPU fp32, seed 1234, with the seeded synthetic weights of
-``maskbit_amd/synth.py``.  Nothing here imports ``oracle/``: the weights come from the seeds, the noise from the seed (the
-reference's draw order on a CPU model: per step one ``exponential_`` [B*n*m, C], then one Gumbel [B, n, m]), the expected
-tokens and pixels from the fixture.  Used by ``tests/test_hip_full64.py`` and by ``bench.py`` (which reports the measured
-token mismatch of the mode it times).
-
-  teacher_forced(): every step restarts from the reference's masked-token state; mismatches are counted over the positions
-                    sampled at that step (84 284 in the run) -- the north star's "bit-token mismatch vs reference".
-  free_running():   one ``mb_sample`` call over all 64 steps with the same noise; reports how far the trajectories drift.
-"""
-from __future__ import annotations
-
-import os
-from typing import Dict, Tuple
-
-import numpy as np
-import torch
-
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN = os.path.join(GOLDEN_DIR, "sample_full12_64.npz")
-# the other full-size runs of the reference (oracle/make_golden.py RUNS): BASELINE configs[1] and configs[4] with their own sampler settings
-RUN_CFG1 = "sample_full10_16_nocfg"
-RUN_CFG5 = "sample_full14_256"
-
-
-def load_run(name: str = "sample_full12_64") -> Dict[str, object]:
-    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    steps = torch.from_numpy(z["steps"].astype(np.int64))                      # [S, B, 256, 2] predicted tokens per step
-    S, B = steps.shape[0], steps.shape[1]
-    masks = torch.from_numpy(np.unpackbits(z["masks"], axis=1)[:, : B * 512].reshape(S, B, 256, 2).astype(bool))
-    kw = {str(k): str(v) for k, v in zip(z["kw_keys"], z["kw_vals"])}
-    bits = int(z["bits"]) if "bits" in z.files else 12
-    g = {"z": z, "name": name, "steps": steps, "masks": masks, "labels": torch.from_numpy(z["labels"].astype(np.int64)), "kw": kw,
-         "seed": int(z["seed"]), "bits": bits, "C": 1 << (bits // 2)}
-    if "codes" in z.files:
-        g["codes"] = torch.from_numpy(z["codes"].astype(np.int64))
-    return g
-
-
-def load_full64() -> Dict[str, object]:
-    return load_run("sample_full12_64")
-
-
-def tokens_in(g, i: int) -> torch.Tensor:
-    """The masked-token state the reference's model saw at step i."""
-    if i == 0:
-        return torch.full_like(g["steps"][0], g["C"])
-    return torch.where(g["masks"][i], torch.full_like(g["steps"][0], g["C"]), g["steps"][i - 1])
-
-
-def reference_noise(g, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(exp_noise [S, B*512, 64], conf_noise [S, B, 256, 2]) exactly as the reference drew them (CPU default generator)."""
-    S, B = g["steps"].shape[0], g["steps"].shape[1]
-    rt = float(g["kw"]["randomize_temperature"])
-    torch.manual_seed(g["seed"])
-    gum = torch.distributions.Gumbel(0.0, 1.0)
-    qs, cs = [], []
-    for i in range(S):
-        qs.append(torch.empty(B * 512, g["C"]).exponential_(1))
-        cs.append(gum.sample((B, 256, 2)) * rt * (1 - (i + 1) / S))
-    return torch.stack(qs).to(device), torch.stack(cs).to(device)
-
-
-def plan_of(g):
-    from maskbit_amd.sampling import build_plan
-    kw = g["kw"]
-    return build_plan(int(kw["num_steps"]), 512, float(kw["guidance_scale"]), kw["guidance_annealing"], float(kw["scale_pow"]), 1.0, False,
-                      kw["mask_schedule_strategy"])
-
-
-def build_models(device, with_tokenizer: bool = True, name: str = "sample_full12_64"):
-    """The fixture's generator / tokenizer on the HIP engine (weights regenerated from the seeds, sha-checked)."""
-    import hashlib
-    from maskbit_amd import ConvVQModel, LFQBert, synth
-    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    bits = int(z["bits"]) if "bits" in z.files else 12
-    gsd = synth.make_generator_weights(synth.GenCfg(bits=bits, splits=2), seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]))
-    sha = lambda t: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
-    assert sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]) == str(z["w_sha_in_proj0"]), "synthetic generator weights changed"
-    gen = LFQBert(img_size=256, hidden_dim=1024, codebook_size=2 ** bits, codebook_splits=2, depth=24, heads=16, mlp_dim=4096, dropout=0.1,
-                  nclass=1000, input_stride=16)
-    gen.load_state_dict(gsd, strict=True)
-    gen = gen.eval().requires_grad_(False).to(device)
-    tok = None
-    if with_tokenizer:
-        tcfg = synth.TokCfg(token_size=12)
-        tsd = synth.make_tokenizer_weights(tcfg, seed=int(z["tok_seed"]))
-        assert sha(tsd["decoder.conv_in.weight"]) == str(z["w_sha_conv_in"]), "synthetic tokenizer weights changed"
-
-        class Cfg(dict):
-            __getattr__ = dict.__getitem__
-        tok = ConvVQModel(Cfg(quantizer_type="lookup-free", codebook_size=4096, token_size=12, num_channels=3, hidden_channels=128,
-                              channel_mult=[1, 1, 2, 2, 4], num_resolutions=5, num_res_blocks=2, sample_with_conv=True))
-        tok.load_state_dict(tsd, strict=False)
-        tok = tok.eval().requires_grad_(False).to(device)
-    return gen, tok
-
-
-@torch.no_grad()
-def teacher_forced(gen, g=None, noise=None):
-    """-> (mismatches, sampled positions, per-step mismatch counts, re-mask differences)."""
-    from maskbit_amd import _lib
-    lib = _lib.load()
-    g = g or load_full64()
-    dev = gen.device
-    q, c = noise if noise is not None else reference_noise(g, dev)
-    scale, temp, mask_len = plan_of(g)
-    S, B = g["steps"].shape[0], g["steps"].shape[1]
-    y = g["labels"].to(dev)
-    per_step, remask = [], 0
-    total = 0
-    for i in range(S):
-        tin_cpu = tokens_in(g, i)
-        tin = tin_cpu.to(dev).contiguous()
-        if float(g["kw"]["guidance_scale"]) != 0.0:
-            lg = gen.forward_cfg(tin, y, scale[i])                   # the guided forward of the loop (cond | label-dropped)
-            lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
-        else:
-            lc, lu = gen(tin, y, torch.zeros(B, dtype=torch.bool, device=dev)), None
-        tout, pred = torch.empty_like(tin), torch.empty_like(tin)
-        _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr() if lu is not None else None, scale[i], temp[i], q[i].data_ptr(), c[i].data_ptr(),
-                                      mask_len[i], tin.data_ptr(), tout.data_ptr(), pred.data_ptr(), B, 256, 2, g["C"],
-                                      torch.cuda.current_stream().cuda_stream), "mb_sample_step")
-        msk = g["masks"][i]
-        per_step.append(int((pred.cpu() != g["steps"][i])[msk].sum()))
-        total += int(msk.sum())
-        if i + 1 < S:
-            remask += int((tout.cpu() != tokens_in(g, i + 1)).sum())
-    return sum(per_step), total, per_step, remask
-
-
-@torch.no_grad()
-def free_running(gen, tok, g=None, noise=None):
-    """One mb_sample call with the reference's noise.  -> dict(step_mismatch=[per step fraction], codes_mismatch, pixel_max_err,
-    u8_mean_abs_diff): how far the free-running trajectory drifts from the reference's (a flipped token changes every later step)."""
-    from maskbit_amd.sampling import run_loop
-    g = g or load_full64()
-    dev = gen.device
-    q, c = noise if noise is not None else reference_noise(g, dev)
-    img, u8, steps, codes = run_loop(gen, tok, g["labels"], plan_of(g), q, c, want_u8=True)
-    torch.cuda.synchronize()
-    steps = steps.cpu()
-    z = g["z"]
-    out = {"step_mismatch": [float((steps[i] != g["steps"][i]).float().mean()) for i in range(steps.shape[0])],
-           "codes_mismatch": float((codes.cpu() != g["codes"]).float().mean())}
-    img = img.cpu()
-    same = (codes.cpu() == g["codes"]).all(dim=1)                       # images whose final codes equal the reference's: pixels comparable
-    errs = []
-    for (yy, xx) in ((0, 0), (120, 120), (240, 240), (37, 201)):
-        ref = torch.from_numpy(z[f"crop_{yy}_{xx}"])
-        if bool(same.any()):
-            errs.append(float((img[same][:, :, yy:yy + 16, xx:xx + 16] - ref[same]).abs().max()))
-    out["images_with_identical_codes"] = int(same.sum())
-    out["pixel_max_err_identical_codes"] = max(errs) if errs else None
-    out["u8_mean_abs_diff"] = float((u8.cpu()[:, ::4, ::4].float() - torch.from_numpy(z["image_u8_q"]).float()).abs().mean())
-    return out
+"""The replay of the reference's recorded runs lives in the package (maskbit_amd/parity_replay.py: bench.py and the tools use it too)."""
+from maskbit_amd.parity_replay import *  # noqa: F401,F403
+from maskbit_amd.parity_replay import GOLDEN, GOLDEN_DIR, RUN_C3_S2, RUN_CFG1, RUN_CFG5  # noqa: F401

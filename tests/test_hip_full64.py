@@ -73,5 +73,8 @@ def test_free_running_64_steps_vs_reference_run(setup):
     assert sm[0] <= 2e-3
     if r["pixel_max_err_identical_codes"] is not None:
         assert r["pixel_max_err_identical_codes"] < 0.03
-    # the trajectories stay statistically close: the final 12-bit codes of a 64-step chaotic sampler agree for most positions
-    assert r["codes_mismatch"] < 0.5
+    # the trajectories stay statistically close.  Measured over the builds of rounds 2-3: final codes 0.9-1.0 % different, mean |uint8 difference| of
+    # the 4x-subsampled images 7.8-8.4 (a flipped code repaints its receptive field of the random-weight decoder); bounds at 3x / 2x of that
+    assert r["codes_mismatch"] <= 0.03
+    assert r["u8_mean_abs_diff"] <= 16.0
+    assert max(sm) <= 0.03                                  # no step drifts further than the final codes do

@@ -39,7 +39,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ragged, q):
+def _worker(rank, world, port, ragged, q, equal=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,18 +47,23 @@ def _worker(rank, world, port, ragged, q):
         B = 5 if ragged else 6
         lo, hi = shard_range(rank, world, B)
         full = (torch.arange(B * 4 * 4 * 3) % 251).to(torch.uint8).reshape(B, 4, 4, 3)
-        got = gather_images(full[lo:hi].clone())
-        q.put((rank, bool(torch.equal(got, full)), tuple(got.shape)))
+        import unittest.mock as um
+        calls = []
+        real = dist.all_gather
+        with um.patch.object(dist, "all_gather", lambda *a, **k: (calls.append(1), real(*a, **k))[1]):
+            got = gather_images(full[lo:hi].clone(), equal=equal)
+        # equal=True: exactly one collective (all_gather_into_tensor), no size exchange
+        q.put((rank, bool(torch.equal(got, full)) and (len(calls) == 0 if equal else len(calls) >= 1), tuple(got.shape)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ragged", [False, True])
-def test_gather_images_gloo_world2(ragged):
+@pytest.mark.parametrize("ragged,equal", [(False, None), (True, None), (False, True)])
+def test_gather_images_gloo_world2(ragged, equal):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ragged, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ragged, q, equal)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
