@@ -180,6 +180,8 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
     }
 #endif
     if (AUX == 4 && i + 1 < ATT_MAXQT) q_fetch(i + 1);
+    // (round 3, measured and removed: pulling the twin sequence's K / V rows towards the L2 during the first pass -- one dword per row as LDS-DMA into the
+    // padding key tile -- made the launch SLOWER, 90-91 us against 85-88: the second pass's staging is not waiting for HBM.)
     MB_ATRACE(3 + 4 * i);
     // ---- softmax over keys (fp32); only the last two key tiles can hold keys >= N
     float mx = -INFINITY;

@@ -14,6 +14,7 @@
 // (one (sum, sumsq) pair per 8x16-pixel tile and group, written next to the tile), level two in gn_finalize_kernel before the consuming conv;
 // only tensors that no conv of this file produced (the encoder's average-pooled ones) still take the separate sweep (gn_partial_kernel).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,7 +24,7 @@
 
 namespace mb {
 
-constexpr int TH = 8, TW = 16;           // output pixel tile
+constexpr int TH8 = 8, TW = 16;          // output pixel tile: TH x 16 pixels, TH = 8 (4 waves) or 16 (8 waves: twice the pixels per weight tile, four waves per SIMD)
 constexpr int CK = 64;                   // input-channel chunk = one 128-byte LDS row
 
 struct ConvArgs {
@@ -43,9 +44,14 @@ struct ConvArgs {
 
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-template <int NI, int WN, int KS, bool UP, bool FINAL>
-__global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
-  constexpr int WM = 4 / WN, MJ = TH / WM, BN = WN * NI * 16;
+// TH = 16 (round 3): the 8 x 16 tile ran two 4-wave workgroups per CU (LDS-bound) = two waves per SIMD, each tap step (32 MFMAs per wave) behind
+// a barrier and the LDS-DMA of its weight tile: per step 3 500 clocks for 512 clocks of matrix work.  A 16 x 16 tile on 8 waves keeps two
+// workgroups per CU (74 KiB each) but FOUR waves per SIMD at the same 125 VGPRs, stages each weight tile for twice the pixels and shrinks the
+// halo overhead from 1.41 to 1.27 pixels read per pixel written.
+template <int NI, int WN, int KS, bool UP, bool FINAL, int TH = 8>
+__global__ __launch_bounds__(32 * TH, TH / 4) void conv_kernel(ConvArgs a) {
+  constexpr int NTHR = 32 * TH, NWAVE = NTHR / 64;
+  constexpr int WM = NWAVE / WN, MJ = TH / WM, BN = WN * NI * 16;
   // KS = 3: symmetric pad 1.  KS = 2 (the stride-2 Conv2dSame of the encoder, run on a space-to-depth input): no pad before,
   // one zero row/column after (autoencoder.py:18,31-36: TF "SAME" puts the odd pixel at the bottom/right).
   constexpr int PAD = (KS - 1) / 2, HW_ = TW + KS - 1, HALO = (TH + KS - 1) * HW_, NTAP = KS * KS;
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
   const int Hin = UP ? a.H / 2 : a.H, Win = UP ? a.W / 2 : a.W;
 
   // ---- weight-tile DMA: BN rows of 128 B; a wave instruction covers 8 rows
-  constexpr int WROWS_PER_WAVE = BN / 4;            // 32 or 4
-  constexpr int WINST = (WROWS_PER_WAVE + 7) / 8;   // 4 or 1
+  constexpr int WROWS_PER_WAVE = BN / NWAVE;        // 32 / 16 (BN = 128 on 4 / 8 waves) or 4 (BN = 16)
+  constexpr int WINST = (WROWS_PER_WAVE + 7) / 8;   // 4 / 2 or 1
   const h16* wsrc[WINST];
 #pragma unroll
   for (int j = 0; j < WINST; ++j) {
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float2 v = a.gn[(size_t)b * Cin + c0 + e]; sc[e] = v.x; sh[e] = v.y; }
     }
-    for (int hp = tid >> 3; hp < HALO; hp += 32) {
+    for (int hp = tid >> 3; hp < HALO; hp += NTHR / 8) {
       const int hy = hp / HW_, hx = hp - hy * HW_;
       const int Y = y0 - PAD + hy, X = x0 - PAD + hx;
       h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -473,13 +479,21 @@ void launch_conv(hipStream_t s, mb_dec* d, const Conv& c, const h16* in, const f
   const bool part = !final_ && stats && c.cout % 128 == 0 && (cpg == 4 || cpg == 8 || cpg == 16);
   ConvArgs a{in, gn, c.w, c.has_bias ? c.b : nullptr, residual, out, img, u8, B, H, W, c.cin_pad, c.cout, c.cout_pad, c.sat, part ? d->gn_part : nullptr};
   d->gn_of = part ? (const void*)out : nullptr;
-  d->gn_ntile = (H / TH) * (W / TW);
   const int bn = final_ ? 16 : 128;
-  dim3 grid((unsigned)((size_t)B * (H / TH) * (W / TW) * (c.cout_pad / bn))), block(256);
+  // 16-row tiles (8 waves) for the 3x3 convolutions from 32 x 32 maps on; 8-row tiles below (a 16 x 16 map would be one tile per image).  The choice
+  // must not depend on the batch: the GroupNorm partial sums are per tile, and results are bit-identical across batch sizes.
+  static const int th_force = getenv("MASKBIT_AMD_CONV_TH") ? atoi(getenv("MASKBIT_AMD_CONV_TH")) : 0;   // A/B switch (experiments; read once)
+  bool th16 = !final_ && c.ks == 3 && H % 16 == 0 && H >= 32;
+  if (th_force == 8) th16 = false;
+  const int th = th16 ? 16 : TH8;
+  d->gn_ntile = (H / th) * (W / TW);
+  dim3 grid((unsigned)((size_t)B * (H / th) * (W / TW) * (c.cout_pad / bn))), block(32 * th);
   if (final_) hipLaunchKernelGGL((conv_kernel<1, 1, 3, false, true>), grid, block, 0, s, a);
   else if (c.ks == 1) hipLaunchKernelGGL((conv_kernel<4, 2, 1, false, false>), grid, block, 0, s, a);
   else if (c.ks == 2) hipLaunchKernelGGL((conv_kernel<4, 2, 2, false, false>), grid, block, 0, s, a);
+  else if (c.up && th16) hipLaunchKernelGGL((conv_kernel<4, 2, 3, true, false, 16>), grid, block, 0, s, a);
   else if (c.up) hipLaunchKernelGGL((conv_kernel<4, 2, 3, true, false>), grid, block, 0, s, a);
+  else if (th16) hipLaunchKernelGGL((conv_kernel<4, 2, 3, false, false, 16>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((conv_kernel<4, 2, 3, false, false>), grid, block, 0, s, a);
 }
 
@@ -603,7 +617,7 @@ mb_dec* dec_create(const mb_dec_cfg& cfg, int max_batch, std::string& err) {
   }
   for (int i = 0; ok && i < 3; ++i) ok = dalloc(d, &d->buf[i], (size_t)max_batch * max_elems, err);
   ok = ok && dalloc(d, &d->z, (size_t)max_batch * cfg.latent_size * cfg.latent_size * CK, err) &&
-       dalloc(d, &d->gn_part, (size_t)max_batch * std::max(GN_MAXCHUNK, (d->out_res / TH) * (d->out_res / TW)) * 64, err) &&
+       dalloc(d, &d->gn_part, (size_t)max_batch * std::max(GN_MAXCHUNK, (d->out_res / TH8) * (d->out_res / TW)) * 64, err) &&
        dalloc(d, &d->gn_ss, (size_t)max_batch * 4096, err);
   if (!ok) { dec_destroy(d); return nullptr; }
   return d;

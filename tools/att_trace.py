@@ -23,7 +23,7 @@ def build():
     print("built", os.path.join(AB, "libatt_trace.so"))
 
 
-VARIANTS = {"base": [], "nospipe": ["-DMB_ATT_NOSPIPE=1"], "gk2": ["-DMB_ATT_SDEPTH=2"], "gk6": ["-DMB_ATT_SDEPTH=6"], "gk9": ["-DMB_ATT_SDEPTH=9"]}
+VARIANTS = {"base": []}      # (round 2: nospipe / gk2 / gk6 / gk9 = -DMB_ATT_NOSPIPE=1 / -DMB_ATT_SDEPTH=2, 6, 9)
 
 
 def build_variants():
