@@ -331,6 +331,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   };
   // BS: request the 4 block scales of lo K-tile kt for this lane's rows (inline asm: counted by the K loop's own vmcnt waits, which the registers are tied through)
   auto bs_issue = [&](int kt) {
+#ifdef MB_BS_NOLOAD                                      // experiment (timing only): no block-scale loads in the lo K-tiles
+    return;
+#endif
     const uint8_t* base = a.a_scale + 4 * kt;
 #pragma unroll
     for (int i = 0; i < 5; ++i) asm volatile("global_load_dword %0, %1, %2" : "=v"(xs_nxt[i]) : "v"(bs_off[i]), "s"(base) : "memory");

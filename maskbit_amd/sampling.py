@@ -49,6 +49,25 @@ NOISE_CHUNK_BYTES = 1 << 30       # sample() / generate_uint8() draw and feed th
 OVERLAP_CHUNKS = 8                # ... and in at least this many chunks (+ a one-step head): the host draws chunk k+1 while the device runs chunk k
 
 
+class _FewCpuThreads:
+    """The host-side draws are a few small CPU tensor ops per step.  With the default intra-op pool of a many-core host (128 OpenMP threads on the
+    256-CPU MI355X boxes) every such op wakes the pool, whose workers then spin -- and the HIP runtime's own host threads starve: measured on
+    BASELINE configs[1] (16 steps, batch 16) 345 ms per run against 136 ms of device time, stalls of 70-180 ms landing on whatever host call came
+    next.  Inside this context the pool is held at one thread (the draws are far below any parallel grain that pays; torch's CPU generators
+    produce the same stream for any thread count) and restored afterwards."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n > 1:
+            torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.n > 1:
+            torch.set_num_threads(self.n)
+        return False
+
+
 def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, randomize_temperature: float,
                device: torch.device, step_begin: int = 0, step_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Noise for steps [step_begin, step_end) of a run (default: the whole run), drawn in the reference's per-generator order: consecutive
@@ -61,10 +80,12 @@ def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, random
         exp_noise[i].exponential_(1)
     gumbel = torch.distributions.Gumbel(loc=0.0, scale=1.0)                     # python-float params => CPU draws
     conf = []
-    for i in range(step_begin, step_end):
-        progress = (i + 1) / num_steps
-        conf.append(gumbel.sample((num_samples, n, m)) * randomize_temperature * (1 - progress))
-    return exp_noise, torch.stack(conf).to(device, non_blocking=False)
+    with _FewCpuThreads():
+        for i in range(step_begin, step_end):
+            progress = (i + 1) / num_steps
+            conf.append(gumbel.sample((num_samples, n, m)) * randomize_temperature * (1 - progress))
+        conf = torch.stack(conf)
+    return exp_noise, conf.to(device, non_blocking=False)
 
 
 def step_chunks(num_samples: int, n: int, m: int, C_: int, num_steps: int):

@@ -14,12 +14,12 @@ AB = os.path.join(ROOT, "tools", "_ab")
 def build():
     from maskbit_amd import build as B
     os.makedirs(AB, exist_ok=True)
-    for mode in (1, 2, 3, 4):
+    for mode in ([int(a) for a in sys.argv[2:]] or (1, 2, 3, 4)):
         objs, procs = [], []
         for src in B.SOURCES:
             obj = os.path.join(AB, f"trace{mode}_{src.replace('.hip', '.o')}")
             objs.append(obj)
-            procs.append(subprocess.Popen([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f"-DMB_HT_TRACE={mode}",
+            procs.append(subprocess.Popen([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f"-DMB_HT_TRACE={mode % 10}", *(["-DMB_BS_NOLOAD=1"] if mode >= 10 else []),
                                            "-c", os.path.join(B.CSRC, src), "-o", obj]))
         assert all(p.wait() == 0 for p in procs)
         subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", os.path.join(AB, f"libtrace{mode}.so")])
@@ -47,7 +47,15 @@ def run(mode):
         res = torch.randn(M, N, device=dev) if epi == 2 else None
         o32 = torch.empty(M, N, device=dev) if epi == 2 else None
         o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
-        fn = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K, None, None, None, None, st()))
+        if os.environ.get("HT_F4"):                      # with the MX-fp4 weight-correction pass (precise mode): K/256 extra lo K-tiles on the conditional half
+            x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8)
+            xsb = torch.full((P * (K // 64) + 256,), 100, device=dev, dtype=torch.uint8)
+            w4 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); ws = torch.zeros(N, device=dev, dtype=torch.uint8)
+            _lib.check(lib.mb_w4_from_f32(W.float().data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), st()))
+            fn = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K,
+                                                     x4.data_ptr(), xsb.data_ptr(), w4.data_ptr(), ws.data_ptr(), st()))
+        else:
+            fn = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K, None, None, None, None, st()))
         G = int(os.environ.get("MASKBIT_AMD_HT_GRID", 256))
         trace = torch.zeros(256, 8, 8, dtype=torch.int64, device=dev)
         for _ in range(3): fn()
