@@ -27,8 +27,9 @@ DEFAULT_ACT_SPLIT = -1
 STRICT_LEVEL = int(os.environ.get("MASKBIT_AMD_STRICT_LEVEL", "3"))   # lo-pass format behind "strict": 3 = e4m3, 4 = MX-fp4 for the LayerNorm outputs
 # Differential classifier-free guidance (mb_gen_cfg.cfg_pair) for the GUIDED forward (forward_cfg / sample() with guidance): -1 = auto (1 where
 # the shape allows it), 0 = off, 1 = differential operands -- the hi + lo pairs' parity class at the cost of the plain fp16 forward --,
-# 2 = "precise": + an MX-fp4 correction pass for the fp16 rounding of every trunk weight (+17 % time; token mismatch 5.8e-4 instead of 9.0e-4
-# on the 12-bit / 64-step configuration, 7.1e-4 instead of 1.44e-3 on the 14-bit / 256-step one).  act_split keeps governing the plain (unguided) forward.
+# 2 = "precise": + an MX-fp4 correction pass for the fp16 rounding of every trunk weight (+19 % time; token mismatch against the reference's own
+# runs 5.0e-4 / 5.5e-4 instead of 8.4e-4 / 9.9e-4 on the two 12-bit / 64-step runs, 6.5e-4 instead of 1.42e-3 on the 14-bit / 256-step one:
+# profiles/r03_parity.md).  act_split keeps governing the plain (unguided) forward.
 DEFAULT_CFG_PAIR = -1
 
 
