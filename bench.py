@@ -179,9 +179,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU per step (default: the C3 batch, 64)")
-    ap.add_argument("--mode", choices=("strict", "fp16", "wcorr", "max"), default="strict",
+    ap.add_argument("--mode", choices=("strict", "fp16", "wcorr", "precise", "max"), default="strict",
                     help="precision mode of the TIMED region: strict (default; the product default, meets <= 1e-3 token mismatch), single fp16, "
-                         "wcorr (strict + MX-fp4 weight-rounding correction in the second half of the trunk) or max (strict + fp16x2 weights)")
+                         "precise (strict + MX-fp4 weight-rounding correction pass on every trunk GEMM), wcorr (that pass in the second half of the "
+                         "trunk only) or max (strict + fp16x2 weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurements: parity replay and the other precision mode")
@@ -215,8 +216,9 @@ def main():
 
     B = args.batch
     gen, tok = build_models(dev)
-    MODES = {"strict": (0, -1, -1), "fp16": (0, 0, 0), "wcorr": (0, -1, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
+    MODES = {"strict": (0, -1, -1), "fp16": (0, 0, 0), "wcorr": (0, -1, 2), "precise": (0, -1, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
     gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
+    gen.wcorr_from = gen.depth // 2 if args.mode == "wcorr" else 0
     torch.manual_seed(1234 + rank)
     plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
                       SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])

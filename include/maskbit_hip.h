@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MB_ABI_VERSION 4
+#define MB_ABI_VERSION 5
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
 typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
@@ -111,6 +111,10 @@ void mb_gen_destroy(mb_gen* g);
  * modeling/modules/base_model.py:87-141).  `data` is a device fp32 tensor in the checkpoint's
  * own layout; GEMM weights are repacked to fp16 here (plus the 8- / 4-bit lo-pass copies of the strict mode).  Unknown names return -2. */
 int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream);
+/* cfg_pair == 2 only: the weight-correction pass of the guided forward runs in trunk layers >= `layer` (default 0 = every layer; depth = none).  The
+ * second half of the trunk alone (layer = depth / 2) costs half as much and measured 6.3e-4 instead of 5.0e-4 / 8.4e-4 (all / no layers) on the
+ * 12-bit 64-step run of the reference, but 1.26e-3 instead of 6.5e-4 on the 14-bit 256-step one (profiles/r03_parity.md). */
+int mb_gen_set_wcorr_from(mb_gen* g, int layer);
 /* tokens int64 [nb,seq,m] (value C = masked), labels int64 [nb], drop uint8 [nb] (1 => label
  * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */
 int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop,

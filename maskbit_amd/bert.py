@@ -105,6 +105,9 @@ class LFQBert(BaseModel):
         # the shape allows, else 2.  Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
         self.act_split = int(os.environ.get("MASKBIT_AMD_ACT_SPLIT", str(DEFAULT_ACT_SPLIT)))
         self.cfg_pair = int(os.environ.get("MASKBIT_AMD_CFG_PAIR", str(DEFAULT_CFG_PAIR)))
+        # cfg_pair 2 only: first trunk layer that carries the weight-correction pass (0 = all; depth // 2 = the second half of the trunk: half the
+        # cost, 6.3e-4 instead of 5.0e-4 on the 12-bit / 64-step run, no use on the 14-bit one -- profiles/r03_parity.md)
+        self.wcorr_from = int(os.environ.get("MASKBIT_AMD_WFROM", "0"))
         self._engine_split = None
         if not self.embed_tables:
             self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
@@ -123,6 +126,7 @@ class LFQBert(BaseModel):
         self._engine_split = (int(self.weight_split), int(self.act_split), int(self.cfg_pair))
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
+        self._engine_wfrom = None
         return h
 
     def resolved_precision(self):
@@ -154,7 +158,12 @@ class LFQBert(BaseModel):
         if self._engine is not None and self._engine_split != (int(self.weight_split), int(self.act_split), int(self.cfg_pair)):
             self._drop_engine()                                    # precision mode changed: rebuild and repack
         have = self._engine_key[1] if self._engine_key else 0
-        return self._ensure_engine(max(min_seqs, have, 16))
+        h = self._ensure_engine(max(min_seqs, have, 16))
+        wf = max(0, min(int(self.wcorr_from), self.depth))
+        if getattr(self, "_engine_wfrom", None) != wf:
+            _lib.check(_lib.load().mb_gen_set_wcorr_from(h, wf), "mb_gen_set_wcorr_from")
+            self._engine_wfrom = wf
+        return h
 
     def _check_labels(self, labels: torch.Tensor) -> None:
         """Host-resident labels are range-checked here (an out-of-range class would index past class_emb, where the

@@ -133,6 +133,7 @@ struct mb_gen {
   // loop state for mb_sample
   // the run mb_sample is in the middle of (step chunks): samples, total steps, guidance flag, the step the next chunk must begin with (-1: no run)
   int loop_B = 0, loop_steps = 0, loop_guided = 0, loop_next = -1;
+  int wcorr_from = 0;                                   // cfg_pair 2: first trunk layer that carries the weight-correction pass (mb_gen_set_wcorr_from)
   const int64_t* cfg_labels_ready = nullptr;            // gen_forward_cfg: lab_cfg / drop_cfg already hold [labels | labels] / [0 | 1] for this many pairs
   int cfg_ready_B = 0;
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
@@ -288,7 +289,9 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   int rc = 0;
   // measured (tests/diag/weight_subset_study.py): the weight rounding of the SECOND half of the trunk is what costs token parity (exact weights in
   // layers 0..11 alone: no gain; in layers 12..23: most of the gain) -> the correction pass runs in layers >= depth / 2 only
-  static const int wfrom = getenv("MASKBIT_AMD_WFROM") ? atoi(getenv("MASKBIT_AMD_WFROM")) : 0;   // first layer with the correction pass (experiments; read once)
+  // measured (tests/diag/weight_subset_study.py, profiles/r03_parity.md): the correction pass in layers >= depth / 2 alone buys 62 % of the gain on the
+  // 12-bit run for half of the cost, and next to nothing on the 14-bit one -- an option (mb_gen_set_wcorr_from), not the default
+  const int wfrom = g->wcorr_from;
   auto x4_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4 : nullptr; };
   auto x4s_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4s : nullptr; };
   auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo,
@@ -742,6 +745,12 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   }
   else HIP_TRY(hipMemcpyAsync(dst_f, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   g->loaded++;
+  return 0;
+}
+
+int mb_gen_set_wcorr_from(mb_gen* g, int layer) {
+  if (!g || layer < 0 || layer > g->c.depth) return fail(-1, "mb_gen_set_wcorr_from: layer outside [0, depth]");
+  g->wcorr_from = layer;
   return 0;
 }
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mb_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.mb_abi_version() == _lib.ABI_VERSION == 5
     assert isinstance(lib.mb_last_error(), bytes)
 
 
