@@ -1,5 +1,5 @@
-// Fused MaskBit sampling step: everything sample() does between the transformer forward and the
-// next forward (modeling/modules/sampling.py:90-131), one workgroup per image:
+// MaskBit sampling step: everything sample() does between the transformer forward and the
+// next forward (modeling/modules/sampling.py:90-131):
 //   CFG combine -> softmax -> categorical draw as argmax(p / Exp(1)) (= torch.multinomial(n=1)) ->
 //   keep already-decoded tokens -> confidence log p[pred] + scaled Gumbel noise (+inf for decoded
 //   positions) -> k-th smallest confidence per image -> re-mask everything <= threshold.
@@ -11,27 +11,21 @@
 
 namespace mb {
 
+// Two launches (round 3; one workgroup per image did both parts, i.e. 64 of 256 CUs ran 32 latency-bound rows per wave: 100 us per step):
+//   sample_rows_kernel   -- one wave per (image, position, group) row, 16 rows per 4-wave workgroup over the whole chip: guidance, softmax, draw,
+//                           confidence.  Result packed into the int64 slot of tokens_out: low dword = the confidence's float bits, high dword = pred.
+//   sample_thresh_kernel -- one workgroup per image: unpack into LDS, k-th smallest confidence by rank counting, re-mask, write tokens (+ pred).
+// The arithmetic per row and the order statistic are unchanged (bit-exact with the oracle: tests/test_hip_parity.py).
 template <int CPL>   // logits per lane: C <= 64*CPL
-__global__ __launch_bounds__(1024) void sample_step_kernel(StepArgs a, const int64_t* __restrict__ tokens_in) {
-  extern __shared__ float sm[];
-  const int P = a.P, C = a.C;
-  float* conf_s = sm;                    // [P]
-  int* pred_s = (int*)(sm + P);          // [P]
-  int* cnt_s = pred_s + P;               // [16]: per-wave partial counts, [15] = result slot
-  float* thr_s = (float*)(cnt_s + 16);   // [1]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void sample_rows_kernel(StepArgs a, const int64_t* __restrict__ tokens_in) {
+  const int C = a.C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t mask_tok = (int64_t)C;
-
-  // num_masked of SAMPLE 0 (sampling.py:109 reads index [0] for the whole batch)
-  int mycnt = 0;
-  for (int p = tid; p < P; p += blockDim.x) mycnt += tokens_in[p] == mask_tok;
-  mycnt = (int)wave_sum((float)mycnt);
-  if (lane == 0) cnt_s[wave] = mycnt;
-  if (tid == 0) *thr_s = -INFINITY;
-
-  for (int r = wave; r < P; r += nw) {
-    const size_t row = (size_t)b * P + r;
+  const size_t nrows = (size_t)a.B * a.P;
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const size_t row = (size_t)blockIdx.x * 16 + wave * 4 + it;
+    if (row >= nrows) return;
     const float* lc = a.logits_c + row * C;
     const float* lu = a.logits_u ? a.logits_u + row * C : nullptr;
     const float* qn = a.exp_noise + row * C;
@@ -81,9 +75,32 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(StepArgs a, const int
     for (int i = 0; i < CPL; ++i) if (pred == lane + 64 * i) pv = l[i];
     pv = __shfl(pv, pred & 63);
     if (lane == 0) {
-      conf_s[r] = (masked ? logf(pv) : INFINITY) + a.conf_noise[row];    // :113-118
-      pred_s[r] = pred;
+      const float conf = (masked ? logf(pv) : INFINITY) + a.conf_noise[row];    // :113-118
+      a.tokens[row] = (int64_t)(((uint64_t)(uint32_t)pred << 32) | (uint64_t)__float_as_uint(conf));
     }
+  }
+}
+
+__global__ __launch_bounds__(1024) void sample_thresh_kernel(StepArgs a, const int64_t* __restrict__ tokens_in) {
+  extern __shared__ float sm[];
+  const int P = a.P;
+  float* conf_s = sm;                    // [P]
+  int* pred_s = (int*)(sm + P);          // [P]
+  int* cnt_s = pred_s + P;               // [16]: per-wave partial counts
+  float* thr_s = (float*)(cnt_s + 16);   // [1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int b = blockIdx.x;
+  const int64_t mask_tok = (int64_t)a.C;
+  // num_masked of SAMPLE 0 (sampling.py:109 reads index [0] for the whole batch)
+  int mycnt = 0;
+  for (int p = tid; p < P; p += blockDim.x) mycnt += tokens_in[p] == mask_tok;
+  mycnt = (int)wave_sum((float)mycnt);
+  if (lane == 0) cnt_s[wave] = mycnt;
+  if (tid == 0) *thr_s = -INFINITY;
+  for (int p = tid; p < P; p += blockDim.x) {        // everything of this image is in LDS before any of its slots is overwritten
+    const uint64_t v = (uint64_t)a.tokens[(size_t)b * P + p];
+    conf_s[p] = __uint_as_float((uint32_t)v);
+    pred_s[p] = (int)(uint32_t)(v >> 32);
   }
   __syncthreads();
   int nm = 0;
@@ -110,15 +127,17 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(StepArgs a, const int
 
 int sample_step(hipStream_t s, const StepArgs& a, const int64_t* tokens_in) {
   if (a.C > 4096 || a.P > 8192) return -1;
+  const size_t nrows = (size_t)a.B * a.P;
+  dim3 grid((unsigned)((nrows + 15) / 16)), block(256);
+  if (a.C <= 64) hipLaunchKernelGGL(sample_rows_kernel<1>, grid, block, 0, s, a, tokens_in);
+  else if (a.C <= 128) hipLaunchKernelGGL(sample_rows_kernel<2>, grid, block, 0, s, a, tokens_in);
+  else if (a.C <= 256) hipLaunchKernelGGL(sample_rows_kernel<4>, grid, block, 0, s, a, tokens_in);
+  else if (a.C <= 512) hipLaunchKernelGGL(sample_rows_kernel<8>, grid, block, 0, s, a, tokens_in);
+  else if (a.C <= 1024) hipLaunchKernelGGL(sample_rows_kernel<16>, grid, block, 0, s, a, tokens_in);   // single-group codebooks (codebook_splits = 1)
+  else if (a.C <= 2048) hipLaunchKernelGGL(sample_rows_kernel<32>, grid, block, 0, s, a, tokens_in);
+  else hipLaunchKernelGGL(sample_rows_kernel<64>, grid, block, 0, s, a, tokens_in);
   const size_t shm = (size_t)a.P * 8 + 16 * 4 + 16;
-  dim3 grid(a.B), block(1024);          // 16 waves: the per-row chain (load -> 4 wave reductions) is latency-bound, more rows in flight
-  if (a.C <= 64) hipLaunchKernelGGL(sample_step_kernel<1>, grid, block, shm, s, a, tokens_in);
-  else if (a.C <= 128) hipLaunchKernelGGL(sample_step_kernel<2>, grid, block, shm, s, a, tokens_in);
-  else if (a.C <= 256) hipLaunchKernelGGL(sample_step_kernel<4>, grid, block, shm, s, a, tokens_in);
-  else if (a.C <= 512) hipLaunchKernelGGL(sample_step_kernel<8>, grid, block, shm, s, a, tokens_in);
-  else if (a.C <= 1024) hipLaunchKernelGGL(sample_step_kernel<16>, grid, block, shm, s, a, tokens_in);   // single-group codebooks (codebook_splits = 1)
-  else if (a.C <= 2048) hipLaunchKernelGGL(sample_step_kernel<32>, grid, block, shm, s, a, tokens_in);
-  else hipLaunchKernelGGL(sample_step_kernel<64>, grid, block, shm, s, a, tokens_in);
+  hipLaunchKernelGGL(sample_thresh_kernel, dim3(a.B), dim3(a.P >= 1024 ? 1024 : 512), shm, s, a, tokens_in);
   return 0;
 }
 

@@ -8,8 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from maskbit_amd import _lib
 
+if os.environ.get("CLOCK_PROBE_LIB"):                 # e.g. tools/_ab/libbf16.so: the library built with -DMB_HALF_BF16=1
+    _lib.LIB_PATH = os.path.abspath(os.environ["CLOCK_PROBE_LIB"])
 lib = _lib.load()
 dev = torch.device("cuda")
+HALF = torch.bfloat16 if "bf16" in os.environ.get("CLOCK_PROBE_LIB", "") else torch.float16
 
 
 def smi_sample():
@@ -30,15 +33,15 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     shapes = {"ffn_up": (1, 4096, 1024), "qkv": (0, 3072, 1024)}
     for name, (epi, N, K) in shapes.items():
-        A = torch.randn(M, K, device=dev).half(); A[P:] *= 0.02
-        W = (torch.randn(N, K, device=dev) * 0.03).half()
+        A = torch.randn(M, K, device=dev).to(HALF); A[P:] *= 0.02
+        W = (torch.randn(N, K, device=dev) * 0.03).to(HALF)
         bias = torch.randn(N, device=dev) * 0.1
-        o16 = torch.empty(M, N, device=dev, dtype=torch.float16)
+        o16 = torch.empty(M, N, device=dev, dtype=HALF)
         fn = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, None, o16.data_ptr(), P, N, K, None, None, None, None, st))
         for data in ("random", "zeros"):
             if data == "zeros":
                 A.zero_(); W.zero_()
-            for G in (256, 192, 128, 64):
+            for G in ((256, 128) if os.environ.get("CLOCK_PROBE_LIB") else (256, 192, 128, 64)):
                 lib.mb_set_cu_count(G if G != 256 else 0)
                 for _ in range(5): fn()
                 torch.cuda.synchronize()
