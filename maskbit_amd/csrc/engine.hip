@@ -303,10 +303,14 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   };
   {
     ProfScope p("embed_ln", s, true);
-    EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
-                g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
-    embed_ln(s, e);
-    rc |= pairify_rows(s, g->y_f32, g->x_h16, P, d, x4_for(0), x4s_for(0));          // y_f32 holds the embedding LayerNorm's fp32 rows here
+    // (tokens / labels / drop are laid out [B conditional | B twins]; the twins repeat the conditional tokens and labels with the drop flag set)
+    EmbedArgs e{tokens, labels, nullptr, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
+                g->y_f32, g->x_h16, B, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
+    if (embed_pair(s, e, x4_for(0), x4s_for(0))) {         // shapes the fused kernel does not serve: the two-kernel path
+      e.drop = drop; e.nb = nb;
+      embed_ln(s, e);
+      rc |= pairify_rows(s, g->y_f32, g->x_h16, P, d, x4_for(0), x4s_for(0));        // y_f32 holds the embedding LayerNorm's fp32 rows here
+    }
   }
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];

@@ -119,6 +119,10 @@ struct EmbedArgs {
   bool x4_values = false;  // x4 = e2m1 of the values instead of the lo halves
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
+// guided forward: a.nb = B conditional sequences (tokens [B, seq, m], labels [B]); rows of the label-dropped twins are written B * (seq + 1) rows further
+// down; x_h16 receives the pair operands (fp16(x_c) | fp16(x_u - x_c)), x4 / x4s (optional) the e2m1 conditional values + block scales.  -1: shape not
+// served (embedding tables, widths other than 768 / 1024) -> embed_ln over [cond | twins] + pairify_rows
+int embed_pair(hipStream_t s, const EmbedArgs& a, uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------

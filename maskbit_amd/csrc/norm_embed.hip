@@ -289,6 +289,80 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
                  a.x4 ? a.x4 + (size_t)row * 2 * d : nullptr, a.x4_scale ? a.x4_scale + row : nullptr, a.x4_values);
 }
 
+// The same for the guided (CFG pair) forward: sequences [0, nb) conditional, their label-dropped twins nb sequences further down.  A twin has the
+// same tokens as its conditional sequence, so every image-token row is embedded and normalised ONCE and written twice (difference operand 0); only the
+// class-token row differs (class_emb[nclass] instead of class_emb[label]).  Writes what embed_ln over [cond | twins] + pairify_rows wrote, bit for
+// bit: x_f32 (both rows), x_h16 = fp16(x_c) | fp16(x_u - x_c), and optionally the e2m1 values + block scales of the conditional rows.
+template <int NV>
+__global__ __launch_bounds__(256) void embed_pair_kernel(EmbedArgs a, uint8_t* x4, uint8_t* x4s) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int N = a.seq + 1, P = a.nb * N;
+  if (row >= P) return;
+  const int sq = row / N, t = row - sq * N;
+  const int d = a.d, K = a.m * a.gbits;
+  uint32_t plus = 0, live = 0;
+  const float* cls = nullptr;
+  if (t < a.seq) {
+    for (int g = 0; g < a.m; ++g) {
+      const int64_t idx = a.tokens[((size_t)sq * a.seq + t) * a.m + g];
+      const uint32_t gm = (1u << a.gbits) - 1u;
+      if (idx != ((int64_t)1 << a.gbits)) { live |= gm << (g * a.gbits); plus |= ((uint32_t)idx & gm) << (g * a.gbits); }
+    }
+  } else {
+    int64_t lab = a.labels[sq];
+    lab = lab < 0 ? 0 : (lab > a.nclass ? a.nclass : lab);
+    cls = a.class_emb + (size_t)lab * d;
+  }
+  const float* pos = a.pos + (size_t)t * d;
+  float4 vc[NV], vu[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = q * 256 + lane * 4;
+    float4 e = cls ? *(const float4*)(cls + c) : *(const float4*)(a.b_in + c);
+    if (!cls) {
+#pragma unroll
+      for (int j = 0; j < MAXBITS; ++j) {
+        if (j < K) {
+          const float4 w = *(const float4*)(a.w_in + (size_t)j * d + c);
+          const float sj = ((live >> j) & 1u) ? (((plus >> j) & 1u) ? 1.f : -1.f) : 0.f;
+          e.x = fmaf(sj, w.x, e.x); e.y = fmaf(sj, w.y, e.y); e.z = fmaf(sj, w.z, e.z); e.w = fmaf(sj, w.w, e.w);
+        }
+      }
+    }
+    const float4 p = *(const float4*)(pos + c);
+    vc[q] = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    if (cls) {                                            // the twin's class token: the "dropped label" embedding (bert.py:482-484)
+      const float4 eu = *(const float4*)(a.class_emb + (size_t)a.nclass * d + c);
+      vu[q] = make_float4(eu.x + p.x, eu.y + p.y, eu.z + p.z, eu.w + p.w);
+    }
+  }
+  ln_normalize<NV>(vc, d, a.gamma, a.beta, 1e-12f, lane);
+  if (cls) ln_normalize<NV>(vu, d, a.gamma, a.beta, 1e-12f, lane);
+  else {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) vu[q] = vc[q];
+  }
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = q * 256 + lane * 4;
+    *(float4*)(a.x_f32 + (size_t)row * d + c) = vc[q];
+    *(float4*)(a.x_f32 + (size_t)(row + P) * d + c) = vu[q];
+  }
+  pair_store<NV>(vc, vu, lane, a.x_h16 + (size_t)row * d, a.x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
+                 x4s ? x4s + (size_t)row * (d / 64) : nullptr, nullptr);
+}
+
+int embed_pair(hipStream_t s, const EmbedArgs& a, uint8_t* x4, uint8_t* x4s) {
+  if (a.tables || a.m * a.gbits > MAXBITS) return -1;     // (the embedding-table Bert takes the two-kernel path)
+  const int rows = a.nb * (a.seq + 1);
+  dim3 grid((rows + 3) / 4), block(256);
+  if (a.d == 1024) hipLaunchKernelGGL(embed_pair_kernel<4>, grid, block, 0, s, a, x4, x4s);
+  else if (a.d == 768) hipLaunchKernelGGL(embed_pair_kernel<3>, grid, block, 0, s, a, x4, x4s);
+  else return -1;
+  return 0;
+}
+
 void embed_ln(hipStream_t s, const EmbedArgs& a) {
   const int rows = a.nb * (a.seq + 1);
   dim3 grid((rows + 3) / 4), block(256);
