@@ -599,39 +599,72 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       // buffer holds the pre-LayerNorm rows and the normalised residual is re-derived here (GemmArgs); in place is fine:
       // every element is read and written by the same lane.
       const bool lnres = a.ln_stats != nullptr;
-      auto finish = [&](f32x4 c, const float4& rr, const float2& st, const f32x4& gm, const f32x4& bt, int r, int nt) {
+      // Order of the memory operations (round 3).  Loads and stores share the in-order vmcnt counter, so the old "fetch row r + 1, store row r" rhythm
+      // made every wait for a residual row also wait for the ACKNOWLEDGEMENT of the store two rows back (tools/micro/store_path.hip: 19 us per tile
+      // interleaved, 15 / 12 / 9 us with 4 / 8 / 16 loads batched ahead of their stores).  Now: batches of two rows, the next batch's loads issued
+      // BEFORE the current batch's stores: 22.8 -> 19.5 us per tile.
+      constexpr int RB = (PAIR && F4) ? 1 : 2;        // rows per batch: 4 float4 per lane -- what fits next to 136 accumulator registers without spilling (2 in the fp4 pair kernel)
+      // (Measured with larger / growing batches -- 4 rows, or 2 + 2 + 4 rows then a whole sweep into the registers the first sweep vacated: 16-42 spilled
+      // VGPRs in the pair kernels and no gain in the kernels that did not spill: with every CU in its epilogue at once the pass runs at the chip's
+      // ~6.5-6.9 TB/s of mixed read + write traffic, profiles/r03_power_and_streams.md section 6.)
+      constexpr int NB = MT / RB;                       // batches per sweep
+      static_assert(MT % RB == 0, "whole batches");
+      float4 rv[RB][2];
+      float2 sv[RB] = {};
+      auto fetch = [&](int k) {                         // batch k: sweep p = k / NB (n-tiles 2p, 2p + 1: one 128-byte line per row), rows (k % NB) * RB ..
+        const int p = k / NB, r0 = (k % NB) * RB;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const uint32_t rowc = (uint32_t)min(row_of(r0 + j), a.M - 1);                // clamped: always a legal address
+#pragma unroll
+          for (int q = 0; q < 2; ++q) rv[j][q] = *(const float4*)((const char*)resp + (size_t)((rowc * (uint32_t)a.N + (uint32_t)col_of(r0 + j, 2 * p + q)) * 4u));
+          if (lnres) sv[j] = *(const float2*)(a.ln_stats + 2 * (size_t)rowc);
+        }
+      };
+      auto add_one = [&](f32x4& c, const float4& rr, const float2& st, const f32x4& gm, const f32x4& bt) {
         if (lnres) {
           c[0] += ln_affine(rr.x, st.x, st.y, gm[0], bt[0]); c[1] += ln_affine(rr.y, st.x, st.y, gm[1], bt[1]);
           c[2] += ln_affine(rr.z, st.x, st.y, gm[2], bt[2]); c[3] += ln_affine(rr.w, st.x, st.y, gm[3], bt[3]);
         } else { c[0] += rr.x; c[1] += rr.y; c[2] += rr.z; c[3] += rr.w; }
-        *(float4*)((char*)out32 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)col_of(r, nt)) * 4u)) = make_float4(c[0], c[1], c[2], c[3]);
       };
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        f32x4 gm[2] = {}, bt[2] = {};
+      f32x4 gm[2] = {}, bt[2] = {};
+      auto affine = [&](int p) {
         if (lnres) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) { gm[q] = *(const f32x4*)(a.ln_g + col_of(0, 2 * p + q)); bt[q] = *(const f32x4*)(a.ln_b + col_of(0, 2 * p + q)); }
         }
-        float4 rv[2][2]; float2 sv[2] = {};
-        auto fetch = [&](int r, float4 (&dst)[2], float2& st) {
-          const uint32_t rowc = (uint32_t)min(row_of(r), a.M - 1);                    // clamped: always a legal address
+      };
+      auto add = [&](int k) {
+        const int p = k / NB, r0 = (k % NB) * RB;
 #pragma unroll
-          for (int q = 0; q < 2; ++q) dst[q] = *(const float4*)((const char*)resp + (size_t)((rowc * (uint32_t)a.N + (uint32_t)col_of(r, 2 * p + q)) * 4u));
-          if (lnres) st = *(const float2*)(a.ln_stats + 2 * (size_t)rowc);
-        };
-        fetch(0, rv[0], sv[0]);
+        for (int j = 0; j < RB; ++j)
 #pragma unroll
-        for (int r = 0; r < MT; ++r) {
-          if (r + 1 < MT) fetch(r + 1, rv[(r + 1) & 1], sv[(r + 1) & 1]);
-          if (row_ok(r)) {
+          for (int q = 0; q < 2; ++q) add_one(acc[2 * p + q][r0 + j], rv[j][q], sv[j], gm[q], bt[q]);
+      };
+      auto store_one = [&](const f32x4& c, int r, int nt) {
+        *(float4*)((char*)out32 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)col_of(r, nt)) * 4u)) = make_float4(c[0], c[1], c[2], c[3]);
+      };
+      auto store = [&](int k) {
+        const int p = k / NB, r0 = (k % NB) * RB;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) finish(acc[2 * p + q][r], rv[r & 1][q], sv[r & 1], gm[q], bt[q], r, 2 * p + q);
+        for (int j = 0; j < RB; ++j)
+          if (row_ok(r0 + j)) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) store_one(acc[2 * p + q][r0 + j], r0 + j, 2 * p + q);
           }
-        }
+      };
+      // L(0) | add(0) L(1) | S(0) add(1) L(2) | S(1) add(2) L(3) | ... : the wait for L(k + 1) leaves S(k) in flight
+      affine(0);
+      fetch(0);
+#pragma unroll
+      for (int k = 0; k < 2 * NB; ++k) {
+        asm volatile("" ::: "memory");
+        add(k);                                           // (waits for L(k); in place on the accumulators: the load registers are free again)
+        if (k + 1 < 2 * NB) { if ((k + 1) % NB == 0) affine((k + 1) / NB); fetch(k + 1); }
+        asm volatile("" ::: "memory");
+        store(k);
       }
-      if (SEQ) {                       // class-token row: this wave row's two n-tiles, lanes l15 == 0
-        f32x4 gm[2] = {}, bt[2] = {};
+      if (SEQ) {                       // class-token row: this wave row's two n-tiles, lanes l15 == 0 (pair tiles: l15 == 1 = the twin's)
         float4 rr[2]; float2 st = {};
         const uint32_t rowc = (uint32_t)min(row_of(MT), a.M - 1);
 #pragma unroll
@@ -640,9 +673,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           if (lnres) { gm[q] = *(const f32x4*)(a.ln_g + col_of(MT, q)); bt[q] = *(const f32x4*)(a.ln_b + col_of(MT, q)); }
         }
         if (lnres) st = *(const float2*)(a.ln_stats + 2 * (size_t)rowc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) add_one(acce[q], rr[q], st, gm[q], bt[q]);
         if (row_ok(MT)) {
 #pragma unroll
-          for (int q = 0; q < 2; ++q) finish(acce[q], rr[q], st, gm[q], bt[q], MT, q);
+          for (int q = 0; q < 2; ++q) store_one(acce[q], MT, q);
         }
       }
     } else {

@@ -12,6 +12,39 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // SHAPE: rows per instruction = 16 / 8 / 4 (segment = 64 / 128 / 256 B).  RMW: load + add + store (fp32 residual pass) instead of store only.
+// RMW with the loads of NB instructions issued before the first store (the in-order vmcnt counter makes "load next, store previous" wait for the
+// PREVIOUS STORE'S acknowledgement at every step)
+template <int RPI, int NB>
+__global__ __launch_bounds__(512) void rmw_batched_kernel(char* __restrict__ out, size_t row_stride, int tile_bytes_per_row, int iters, long long* wall) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int SEG = 1024 / RPI;
+  const int r_in = lane / (SEG / 16), c_in = (lane % (SEG / 16)) * 16;
+  char* base = out + (size_t)blockIdx.x * 256 * row_stride + (size_t)(wave * 32) * row_stride;
+  const int nrow_steps = 32 / RPI, ncol_steps = tile_bytes_per_row / SEG;
+  const int total = nrow_steps * ncol_steps;
+  f32x4 v = {1.f, 2.f, 3.f, (float)lane};
+  const long long w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+    for (int s0 = 0; s0 < total; s0 += NB) {
+      f32x4 buf[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int st = s0 + j, cs = st / nrow_steps, rs = st - cs * nrow_steps;
+        buf[j] = *(const f32x4*)(base + (size_t)(rs * RPI + r_in) * row_stride + (size_t)it * tile_bytes_per_row + cs * SEG + c_in);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int st = s0 + j, cs = st / nrow_steps, rs = st - cs * nrow_steps;
+        *(f32x4*)(base + (size_t)(rs * RPI + r_in) * row_stride + (size_t)it * tile_bytes_per_row + cs * SEG + c_in) = buf[j] + v;
+      }
+    }
+    v[0] += 1.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const long long w1 = wall_clock64();
+  if (tid == 0) wall[blockIdx.x] = w1 - w0;
+}
+
 template <int RPI, bool RMW>
 __global__ __launch_bounds__(512) void store_kernel(char* __restrict__ out, size_t row_stride, int tile_bytes_per_row, int iters, long long* wall) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,6 +95,28 @@ static void run(const char* tag, char* buf, size_t row_stride, int tile_bytes_pe
          bytes / (mean * 1e-6) / 1e9, bytes * ncu / (ms * 1e-3) / 1e12);
 }
 
+template <int RPI, int NB>
+static void run_b(const char* tag, char* buf, size_t row_stride, int tile_bytes_per_row, int iters, long long* dwall, int ncu) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((rmw_batched_kernel<RPI, NB>), dim3(ncu), dim3(512), 0, 0, buf, row_stride, tile_bytes_per_row, iters, dwall);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((rmw_batched_kernel<RPI, NB>), dim3(ncu), dim3(512), 0, 0, buf, row_stride, tile_bytes_per_row, iters, dwall);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<long long> w(ncu);
+  hipMemcpy(w.data(), dwall, ncu * sizeof(long long), hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (auto x : w) mean += (double)x;
+  mean = mean / ncu * 0.01;
+  const double bytes = 256.0 * tile_bytes_per_row * iters * 2;
+  printf("%-34s: %8.1f us per launch, %6.2f us per tile pass, %6.1f GB/s per CU, %6.2f TB/s chip (R+W)\n", tag, ms * 1e3, mean / iters,
+         bytes / (mean * 1e-6) / 1e9, bytes * ncu / (ms * 1e-3) / 1e12);
+}
+
 int main() {
   int ncu = 256;
   hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
@@ -86,6 +141,11 @@ int main() {
         run<16, true>("RMW   16 rows x  64 B / instr", buf, stride, tb, it, dwall, ncu);
         run<8, true>("RMW    8 rows x 128 B / instr", buf, stride, tb, it, dwall, ncu);
         run<4, true>("RMW    4 rows x 256 B / instr", buf, stride, tb, it, dwall, ncu);
+        run_b<16, 4>("RMW 16x64B, 4 loads then 4 stores", buf, stride, tb, it, dwall, ncu);
+        run_b<16, 8>("RMW 16x64B, 8 loads then 8 stores", buf, stride, tb, it, dwall, ncu);
+        run_b<16, 16>("RMW 16x64B, 16 loads then 16 stores", buf, stride, tb, it, dwall, ncu);
+        run_b<16, 32>("RMW 16x64B, 32 loads then 32 stores", buf, stride, tb, it, dwall, ncu);
+        run_b<8, 16>("RMW 8x128B, 16 loads then 16 stores", buf, stride, tb, it, dwall, ncu);
       }
     }
     hipFree(buf);
