@@ -564,11 +564,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       }
     }
     MB_TRACE(2);
-    // the next tile's first K-tiles must be in LDS before anyone reads them; nothing of THIS tile is stored yet
-    if (has_next) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    // The next tile's first K-tiles must be in LDS before anyone reads them.  Every wave waits for ITS share of that DMA here, while nothing of this
+    // tile is stored yet (so the wait does not cover store acknowledgements), then issues its stores, and the workgroup barrier comes AFTER the stores
+    // (round 3; it used to stand here): with the GELU epilogue the two waves of a SIMD finish their arithmetic 3.8 us apart, and the leading
+    // group's stores now go out under the trailing group's arithmetic instead of after it.
+    if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MB_TRACE(3);
     if constexpr (PAIR && EPI == EPI_GELU_H16) {
       if (a.out4) {
@@ -721,6 +721,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         }
       }
     }
+    if (has_next) __builtin_amdgcn_s_barrier();        // everyone's share of the next tile's K-tiles 0 and 1 has landed (each wave waited above)
     MB_TRACE(4);
 #ifdef MB_HT_TRACE
 #if MB_HT_TRACE >= 2
