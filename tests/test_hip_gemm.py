@@ -426,3 +426,27 @@ def test_f4_weight_correction_pass(M, N, K):
     e_corr, e_plain = float((out.double() - true).pow(2).mean().sqrt()), float((plain - true).pow(2).mean().sqrt())
     print(f"rms error vs fp32 weights: fp16 weights {e_plain:.3e}, with the fp4 correction pass {e_corr:.3e}")
     assert e_corr < e_plain / 3
+
+
+def test_persistent_grids_sized_for_fewer_cus_give_the_same_bits():
+    """mb_set_cu_count (persistent grids on a CU-masked stream): 128 workgroups walk the tile list instead of 256 -- same tiles, same bits."""
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    P, N, K = 4 * 257, 1024, 1024
+    M = 2 * P
+    A = torch.randn(M, K, device=DEV).half(); A[P:] *= 0.02
+    W = (torch.randn(N, K, device=DEV) * 0.03).half()
+    bias = torch.randn(N, device=DEV) * 0.1
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        for n in (0, 128, 8):
+            assert lib.mb_set_cu_count(n) == 0
+            o = torch.empty(M, N, device=DEV, dtype=torch.float16)
+            _lib.check(lib.mb_gemm_pair(0, A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, None, o.data_ptr(), P, N, K, None, None, None, None, st))
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        lib.mb_set_cu_count(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -252,6 +252,48 @@ def test_step_chunked_run_equals_the_whole_run(scale, monkeypatch):
         run_loop(gm, tm, y, plan, e, c, step_range=(0, 3))                      # noise does not match the range
     with pytest.raises(RuntimeError):
         run_loop(gm, tm, y[:2], plan, e[3:4, :2 * 512].contiguous(), c[3:4, :2].contiguous(), step_range=(3, 4))   # continuation with another batch
+    # a chunk is accepted only as the exact continuation of the run in progress (round 3: the handle keeps the token state between chunks)
+    run_loop(gm, tm, y, plan, e[0:3], c[0:3], want_image=False, step_range=(0, 3))
+    with pytest.raises(RuntimeError):
+        run_loop(gm, tm, y, plan, e[4:7], c[4:7], want_image=False, step_range=(4, 7))          # skips step 3
+    run_loop(gm, tm, y, plan, e[0:3], c[0:3], want_image=False, step_range=(0, 3))               # (a rejected chunk ends the run: start again)
+    plan5 = build_plan(5, 512, scale, "cosine", 3.0, 1.0, False, "arccos")
+    with pytest.raises(RuntimeError):
+        run_loop(gm, tm, y, plan5, e[3:5], c[3:5], want_image=False, step_range=(3, 5))         # another plan length
+    run_loop(gm, tm, y, plan, e[0:3], c[0:3], want_image=False, step_range=(0, 3))
+    _, _, st34, _ = run_loop(gm, tm, y, plan, e[3:4], c[3:4], want_image=False, step_range=(3, 4))   # the right continuation still works
+    assert torch.equal(st34, steps_full[3:4])
+
+
+def test_guidance_scale_zero_steps_run_the_conditional_forward_alone():
+    """Where the annealed guidance scale is exactly 0 (the first steps of the cosine schedule in float32) the loop runs the plain conditional forward
+    and hands the step kernel no unconditional logits: the tokens equal those of forward + step composed that way, bit for bit."""
+    from maskbit_amd import _lib
+    from maskbit_amd.sampling import build_plan, run_loop
+    lib = _lib.load()
+    _, _, gm, tm = tiny_models()
+    B, N = 3, 24
+    y = torch.tensor([1, 4, 8], device=DEV)
+    plan = build_plan(N, 512, 7.1, "cosine", 3.0, 1.0, False, "arccos")
+    zero = [i for i, a in enumerate(plan[0]) if a == 0.0]
+    assert zero and zero[0] == 0 and len(zero) < N                                                 # a few leading steps, not all
+    q, c = cpu_noise(13, B, N, 8.2)
+    q, c = q.to(DEV), c.to(DEV)
+    _, _, steps, _ = run_loop(gm, None, y, plan, q, c, want_image=False)
+    tok = torch.full((B, 256, 2), 64, dtype=torch.int64, device=DEV)
+    drop = torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(DEV)
+    for i in range(len(zero) + 2):
+        if plan[0][i] == 0.0:
+            lc, lu = gm(tok, y, torch.zeros(B, dtype=torch.bool, device=DEV)), None
+        else:
+            lg = gm(torch.cat([tok, tok]), torch.cat([y, y]), drop)
+            lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
+        nxt, pred = torch.empty_like(tok), torch.empty_like(tok)
+        _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr() if lu is not None else None, plan[0][i], plan[1][i], q[i].data_ptr(), c[i].data_ptr(),
+                                      plan[2][i], tok.data_ptr(), nxt.data_ptr(), pred.data_ptr(), B, 256, 2, 64, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(pred, steps[i]), i
+        tok = nxt
 
 
 @pytest.mark.parametrize("num_steps,B,scale", [(1, 1, 7.1), (2, 2, 0.0), (3, 5, 3.0)])

@@ -166,3 +166,23 @@ def test_eval_harness_host_pieces():
     ref = torch.randperm(1000, dtype=torch.int).repeat(50)
     assert lab.dtype == torch.int32 and lab.shape == (50000,) and torch.equal(lab, ref)
     assert torch.equal(lab[:1000].sort().values, torch.arange(1000, dtype=torch.int32))
+
+
+def test_host_noise_draws_restore_the_thread_pool_and_keep_the_stream():
+    """draw_noise holds torch's intra-op pool at one thread while it draws (profiles/r03_parity.md section 4) and restores it; the CPU stream is the
+    one the reference consumes (one Gumbel draw of [B, n, m] per step from the default generator)."""
+    import torch
+    from maskbit_amd.sampling import _FewCpuThreads, draw_noise
+    before = torch.get_num_threads()
+    with _FewCpuThreads():
+        assert torch.get_num_threads() == 1
+    assert torch.get_num_threads() == before
+    torch.manual_seed(11)
+    _, conf = draw_noise(2, 256, 2, 64, 3, 4.5, torch.device("cpu"))
+    assert torch.get_num_threads() == before
+    torch.manual_seed(11)
+    for i in range(3):
+        torch.empty(2 * 512, 64).exponential_(1)
+    g = torch.distributions.Gumbel(0.0, 1.0)
+    want = torch.stack([g.sample((2, 256, 2)) * 4.5 * (1 - (i + 1) / 3) for i in range(3)])
+    assert torch.equal(conf, want)
