@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "mb_decoder.h"
@@ -40,7 +41,19 @@ struct ConvArgs {
   unsigned* sat;         // counts output groups of 4 whose value left the fp16 range and was clamped (mb_dec_saturation_count)
   float* gn_part;        // or null: GroupNorm partial statistics of the OUTPUT, [B][pixel tiles per image][32 groups][sum, sumsq] -- the consumer's
                          // GroupNorm then needs no sweep over the tensor (its fp16-stored values are what is summed, as that sweep did)
+#ifdef MB_CONV_TRACE
+  long long* trace;      // tools/dec_trace.py: [workgroup][16] wall-clock stamps of one selected launch
+#endif
 };
+
+// Timeline instrumentation (tools/dec_trace.py builds its own copy with -DMB_CONV_TRACE; never in the product library): thread 0 of every workgroup
+// stamps the 100 MHz wall clock: 0 start; per input-channel chunk c < 3: 1+4c halo free (barrier passed), 2+4c halo staged by this wave, 3+4c weights +
+// halo visible (barrier passed), 4+4c the chunk's last tap done; 15 end of the epilogue.
+#ifdef MB_CONV_TRACE
+#define MB_CTRACE(k) do { if (a.trace && tid == 0 && (k) < 16) a.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define MB_CTRACE(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
@@ -56,9 +69,10 @@ __global__ __launch_bounds__(32 * TH, TH / 4) void conv_kernel(ConvArgs a) {
   // one zero row/column after (autoencoder.py:18,31-36: TF "SAME" puts the odd pixel at the bottom/right).
   constexpr int PAD = (KS - 1) / 2, HW_ = TW + KS - 1, HALO = (TH + KS - 1) * HW_, NTAP = KS * KS;
   constexpr int WT_BYTES = BN * 128;
-  __shared__ __attribute__((aligned(16))) char smem[HALO * 128 + 2 * WT_BYTES];
+  constexpr int HALO_BYTES = (HALO + 7) / 8 * 1024;   // whole 8-pixel DMA groups
+  __shared__ __attribute__((aligned(16))) char smem[HALO_BYTES + 2 * WT_BYTES];
   char* halo = smem;
-  char* wt = smem + HALO * 128;
+  char* wt = smem + HALO_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
@@ -96,28 +110,53 @@ __global__ __launch_bounds__(32 * TH, TH / 4) void conv_kernel(ConvArgs a) {
     }
   };
 
-  // ---- halo staging through registers (GN-apply + SiLU + zero padding)
-  const int myslot = tid & 7;
+  // ---- halo staging (GN-apply + SiLU + zero padding).  The raw rows come in by LDS-DMA, 8 pixels x 128 B per wave instruction, from clamped
+  // coordinates; every lane then normalises the 16 bytes IT brought in, in place (no barrier in between: a lane re-reads only its own slot after
+  // its own vmcnt wait).  All of a wave's 5-6 instructions are in flight together and hold no registers.  (Round 3, before: a
+  // load -> SiLU -> ds_write loop through registers, which the compiler left rolled -- six trips to memory per thread one after the other,
+  // ~1.5 us each under load, twice per tile of a 128-channel conv whose workgroup lived 47 us; unrolled with the loads batched it spilled.)
+  // Wave w takes pixel groups j = w, w + NWAVE, ..: j keeps its parity, so the 16-byte slot swizzle ((pixel >> 1) & 7 = (4j + lane/16) & 7)
+  // maps a lane to ONE logical channel slot for all its groups and the GroupNorm scale / shift of its 8 channels stay in registers.
+  constexpr int NGRP = (HALO + 7) / 8, NGW = (NGRP + NWAVE - 1) / NWAVE;
+  const int myslot = (lane & 7) ^ (lane >> 4) ^ ((wave & 1) << 2);
   auto stage_halo = [&](int chunk) {
     const int c0 = chunk * CK + myslot * 8;
+#pragma unroll
+    for (int jj = 0; jj < NGW; ++jj) {
+      const int j = wave + jj * NWAVE;
+      if (j < NGRP) {
+        const int hp = min(j * 8 + (lane >> 3), HALO - 1);
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int Y = min(max(y0 - PAD + hy, 0), a.H - 1), X = min(max(x0 - PAD + hx, 0), a.W - 1);
+        const int sy = UP ? (Y >> 1) : Y, sx = UP ? (X >> 1) : X;
+        MB_GLDS16(a.in + (((size_t)b * Hin + sy) * Win + sx) * Cin + c0, halo + j * 1024);
+      }
+    }
     float sc[8], sh[8];
     if (a.gn) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float2 v = a.gn[(size_t)b * Cin + c0 + e]; sc[e] = v.x; sh[e] = v.y; }
     }
-    for (int hp = tid >> 3; hp < HALO; hp += NTHR / 8) {
-      const int hy = hp / HW_, hx = hp - hy * HW_;
-      const int Y = y0 - PAD + hy, X = x0 - PAD + hx;
-      h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
-        const int sy = UP ? (Y >> 1) : Y, sx = UP ? (X >> 1) : X;
-        v = *(const h16x8*)(a.in + (((size_t)b * Hin + sy) * Win + sx) * Cin + c0);
-        if (a.gn) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = to_h(silu(fmaf((float)v[e], sc[e], sh[e])));
+    for (int jj = 0; jj < NGW; ++jj) {
+      const int j = wave + jj * NWAVE;
+      const int hp = j * 8 + (lane >> 3);
+      if (j < NGRP && hp < HALO) {
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int Y = y0 - PAD + hy, X = x0 - PAD + hx;
+        h16x8* slot = (h16x8*)(halo + j * 1024 + lane * 16);
+        if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
+          if (a.gn) {
+            h16x8 v = *slot;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = to_h(silu(fmaf((float)v[e], sc[e], sh[e])));
+            *slot = v;
+          }
+        } else {
+          *slot = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
       }
-      *(h16x8*)(halo + hp * 128 + ((myslot ^ ((hp >> 1) & 7)) * 16)) = v;
     }
   };
 
@@ -132,15 +171,19 @@ __global__ __launch_bounds__(32 * TH, TH / 4) void conv_kernel(ConvArgs a) {
     for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int T = (Cin / CK) * NTAP;
+  MB_CTRACE(0);
   stage_w(0, 0);
   for (int t = 0; t < T; ++t) {
     const int chunk = t / NTAP, tap = t - chunk * NTAP;
     if (tap == 0) {
       __syncthreads();                      // all waves are done with the previous chunk's halo
+      MB_CTRACE(1 + 4 * chunk);
       stage_halo(chunk);
+      MB_CTRACE(2 + 4 * chunk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                        // weight tile t landed, halo visible
+    if (tap == 0) MB_CTRACE(3 + 4 * chunk);
     if (t + 1 < T) stage_w(t + 1, (t + 1) & 1);
     const int dy = tap / KS, dx = tap - dy * KS;
     const char* wb = wt + (t & 1) * WT_BYTES + wn * NI * 16 * 128;
@@ -160,45 +203,79 @@ __global__ __launch_bounds__(32 * TH, TH / 4) void conv_kernel(ConvArgs a) {
         for (int j = 0; j < MJ; ++j)
           acc[i][j] = MB_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
     }
+    if (tap == NTAP - 1) MB_CTRACE(4 + 4 * chunk);
   }
 
   // ---- epilogue: lane holds out[pixel (y = wm*MJ+j, x = l15)][cout = ..+g*4 .. +3]
+  // The bias of a lane's channels is fetched once; the residual values of pixel row j + 1 are requested before row j is stored, and the
+  // saturation count is one atomic per lane at the end.  (Round 3, before: bias and residual loaded inside the (row, channel tile) loop behind
+  // run-time branches -- the compiler waited vmcnt(0) after each of the 32 loads, i.e. also for the previous store: 14.5 us of a 50 us workgroup.)
   float gs[NI], gq[NI];                     // GroupNorm partials of this lane's 4 channels of n-tile i over its MJ pixels
+  float4 bv[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+  for (int i = 0; i < NI; ++i) {
+    gs[i] = 0.f; gq[i] = 0.f;
+    bv[i] = a.bias ? *(const float4*)(a.bias + n0 + wn * NI * 16 + i * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if constexpr (FINAL) {
 #pragma unroll
-  for (int j = 0; j < MJ; ++j) {
-    const int Y = y0 + wm * MJ + j, X = x0 + l15;
-    const size_t pix = ((size_t)b * a.H + Y) * a.W + X;
+    for (int j = 0; j < MJ; ++j) {
+      const int Y = y0 + wm * MJ + j, X = x0 + l15;
+      const size_t pix = ((size_t)b * a.H + Y) * a.W + X;
+      const float v[4] = {acc[0][j][0] + bv[0].x, acc[0][j][1] + bv[0].y, acc[0][j][2] + bv[0].z, acc[0][j][3] + bv[0].w};
+      if (g == 0) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int n = n0 + wn * NI * 16 + i * 16 + g * 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (a.bias) { const float4 bv = *(const float4*)(a.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-      if (FINAL) {
-        if (g == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (r < a.Cout) {
-              if (a.img_nchw) a.img_nchw[(((size_t)b * a.Cout + r) * a.H + Y) * a.W + X] = v[r];
-              if (a.img_u8) a.img_u8[pix * a.Cout + r] = (uint8_t)(fminf(fmaxf(v[r], 0.f), 1.f) * 255.0f);
-            }
+        for (int r = 0; r < 4; ++r) {
+          if (r < a.Cout) {
+            if (a.img_nchw) a.img_nchw[(((size_t)b * a.Cout + r) * a.H + Y) * a.W + X] = v[r];
+            if (a.img_u8) a.img_u8[pix * a.Cout + r] = (uint8_t)(fminf(fmaxf(v[r], 0.f), 1.f) * 255.0f);
           }
         }
-      } else if (n < a.Cout) {
-        if (a.residual) {
-          const h16x4 rv = *(const h16x4*)(a.residual + pix * a.Cout + n);
-          v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
-        }
-        // activations are stored as fp16: values beyond +-65504 are clamped by to_h -- counted, so that a checkpoint whose decoder needs a
-        // wider residual stream is noticed instead of silently clipped (random-init weights stay far inside the range)
-        if (fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > MB_H16_MAX) atomicAdd(a.sat, 1u);
-        const h16x4 hv = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
-        *(h16x4*)(a.out + pix * a.Cout + n) = hv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float f = (float)hv[r]; gs[i] += f; gq[i] = fmaf(f, f, gq[i]); }
       }
     }
+  } else {
+    const size_t pix0 = ((size_t)b * a.H + y0 + wm * MJ) * a.W + x0 + l15;        // pixel row j: + j * W
+    const int nl = n0 + wn * NI * 16 + g * 4;                                       // channel of n-tile i: + i * 16
+    unsigned nsat = 0;
+    // straight-line per variant (residual or not; every channel of the tile stored or not): with the run-time tests inside the loop the
+    // compiler's wait-count pass fell back to vmcnt(0) in front of every store
+    auto body = [&](auto res_c, auto full_c) {
+      constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
+      h16x4 rv[2][NI];
+      auto fetch = [&](int j, h16x4 (&r)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          r[i] = h16x4{0, 0, 0, 0};
+          if (RES && (FULL || nl + i * 16 < a.Cout)) r[i] = *(const h16x4*)(a.residual + (pix0 + (size_t)j * a.W) * a.Cout + nl + i * 16);
+        }
+      };
+      fetch(0, rv[0]);
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        if (j + 1 < MJ) fetch(j + 1, rv[(j + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          if (FULL || nl + i * 16 < a.Cout) {
+            float v[4] = {acc[i][j][0] + bv[i].x, acc[i][j][1] + bv[i].y, acc[i][j][2] + bv[i].z, acc[i][j][3] + bv[i].w};
+            if (RES) {
+              const h16x4 r = rv[j & 1][i];
+              v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+            }
+            // activations are stored as fp16: values beyond +-65504 are clamped by to_h -- counted, so that a checkpoint whose decoder needs a
+            // wider residual stream is noticed instead of silently clipped (random-init weights stay far inside the range)
+            nsat += fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > MB_H16_MAX ? 1u : 0u;
+            const h16x4 hv = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
+            *(h16x4*)(a.out + (pix0 + (size_t)j * a.W) * a.Cout + nl + i * 16) = hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float f = (float)hv[r]; gs[i] += f; gq[i] = fmaf(f, f, gq[i]); }
+          }
+        }
+      }
+    };
+    const bool full = n0 + BN <= a.Cout;
+    if (a.residual) { if (full) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+    else { if (full) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+    if (nsat) atomicAdd(a.sat, nsat);
   }
   if constexpr (!FINAL) {
     if (a.gn_part) {                        // uniform; requires Cout % 128 == 0 and 4 | 8 | 16 channels per group (launch_conv)
@@ -234,6 +311,7 @@ __global__ __launch_bounds__(32 * TH, TH / 4) void conv_kernel(ConvArgs a) {
       }
     }
   }
+  MB_CTRACE(15);
 }
 
 // ---- GroupNorm statistics: partial (sum, sumsq) per (image, pixel chunk, group) -----------------
@@ -472,12 +550,20 @@ bool init_block(mb_dec* d, ResBlock& rb, const std::string& p, int cin, int cout
   return ok;
 }
 
+#ifdef MB_CONV_TRACE
+static long long* g_conv_trace = nullptr;
+static int g_conv_trace_sel = -1, g_conv_trace_n = 0;
+#endif
 void launch_conv(hipStream_t s, mb_dec* d, const Conv& c, const h16* in, const float2* gn, const h16* residual, h16* out,
                  float* img, uint8_t* u8, int B, int H, int W, bool final_, bool stats = true) {
   // GroupNorm partials of the output ride in the epilogue when a GroupNorm will read it (stats) and its groups are whole lane groups of a tile
   const int cpg = c.cout / 32;
   const bool part = !final_ && stats && c.cout % 128 == 0 && (cpg == 4 || cpg == 8 || cpg == 16);
   ConvArgs a{in, gn, c.w, c.has_bias ? c.b : nullptr, residual, out, img, u8, B, H, W, c.cin_pad, c.cout, c.cout_pad, c.sat, part ? d->gn_part : nullptr};
+#ifdef MB_CONV_TRACE
+  a.trace = (g_conv_trace && g_conv_trace_n++ == g_conv_trace_sel) ? g_conv_trace : nullptr;
+  if (a.trace) printf("conv launch %d: %s  %dx%d  %d -> %d  ks %d%s\n", g_conv_trace_sel, c.name.c_str(), H, W, c.cin_pad, c.cout, c.ks, c.up ? " up" : "");
+#endif
   d->gn_of = part ? (const void*)out : nullptr;
   const int bn = final_ ? 16 : 128;
   // 16-row tiles (8 waves) for the 3x3 convolutions from 32 x 32 maps on; 8-row tiles below (a 16 x 16 map would be one tile per image).  The choice
@@ -746,3 +832,7 @@ int enc_encode(mb_dec* d, const float* img, int64_t* indices, float* zq, float* 
 }
 
 }  // namespace mb
+
+#ifdef MB_CONV_TRACE
+extern "C" int mb_debug_conv_trace(long long* p, int sel) { mb::g_conv_trace = p; mb::g_conv_trace_sel = sel; mb::g_conv_trace_n = 0; return 0; }
+#endif

@@ -1,9 +1,11 @@
 """Decode time of B images (uint8 path), mean of n calls.  MASKBIT_AMD_CONV_TH=8 / 16 forces the conv tile height (read once per process).
-usage: python tools/dec_time.py [B=64] [n=10]"""
+usage: [DEC_TIME_LIB=other.so] python tools/dec_time.py [B=64] [n=10]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from maskbit_amd import ConvVQModel, synth
+from maskbit_amd import ConvVQModel, synth, _lib
+if os.environ.get("DEC_TIME_LIB"):      # A/B against another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["DEC_TIME_LIB"])
 
 
 class Cfg(dict):
