@@ -126,13 +126,32 @@ def build_models(dev):
     return gen.eval().requires_grad_(False).to(dev), tok.eval().requires_grad_(False).to(dev)
 
 
-def measured_parity(gen):
-    """Teacher-forced token mismatch of the engine's CURRENT precision mode against the real reference's full-size 64-step run
-    (tests/golden/sample_full12_64.npz, made by oracle/make_golden.py full64 with these same weights): 84 284 sampled positions."""
+def measured_parity(gen, run=None):
+    """Teacher-forced token mismatch of the engine's CURRENT precision mode against a full-size 64-step run of the real reference: by default
+    tests/golden/sample_full12_64.npz (made by oracle/make_golden.py full64 with the bench's own weights; 84 284 sampled positions); `run` names
+    another recorded run (`gen` must then carry that run's weights)."""
     from maskbit_amd import parity_replay as R
-    bad, tot, _, _ = R.teacher_forced(gen)
+    if run is None:
+        bad, tot, _, _ = R.teacher_forced(gen)
+    else:
+        g = R.load_run(run)
+        bad, tot, _, _ = R.teacher_forced(gen, g, R.reference_noise(g, gen.device))
     return {"token_mismatch": bad / tot, "mismatches": bad, "positions": tot,
-            "against": "the reference's own sample() run, CPU fp32 (tests/golden/sample_full12_64.npz), teacher-forced per step"}
+            "against": f"the reference's own sample() run, CPU fp32 (tests/golden/{run or 'sample_full12_64'}.npz), teacher-forced per step"}
+
+
+def second_run_parity(dev, mode_settings):
+    """The same measurement on the SECOND full-size reference run (other generator weights, head gain, noise seed and labels:
+    tests/golden/sample_full12_64_s2.npz) for each (weight_split, act_split, cfg_pair) in `mode_settings` -> {mode: parity}."""
+    from maskbit_amd import parity_replay as R
+    gen, _ = R.build_models(dev, with_tokenizer=False, name=R.RUN_C3_S2)
+    out = {}
+    for name, (ws, asplit, pair) in mode_settings.items():
+        gen.weight_split, gen.act_split, gen.cfg_pair = ws, asplit, pair
+        out[name] = measured_parity(gen, R.RUN_C3_S2)
+    del gen
+    torch.cuda.empty_cache()
+    return out
 
 
 def other_configs(dev):
@@ -258,14 +277,24 @@ def main():
     # (2) the same workload and the same parity measurement in the other precision mode, one batch.
     modes = None
     if world == 1 and not args.no_modes:
-        other = "fp16" if args.mode != "fp16" else "strict"
         modes = {args.mode: {"images_per_s": B * world * args.steps / elapsed, "timed": True, "parity": measured_parity(gen)}}
-        gen.weight_split, gen.act_split, gen.cfg_pair = MODES[other]
-        one_batch(10_000); torch.cuda.synchronize()
-        ts = time.perf_counter()
-        one_batch(10_001); torch.cuda.synchronize()
-        modes[other] = {"images_per_s": B / (time.perf_counter() - ts), "timed": False, "parity": measured_parity(gen)}
+        # the mode below the default (single fp16, independent streams) and the one above it (the weight-correction pass on every trunk GEMM:
+        # the mode with real margin under the 1e-3 bound), one untimed-region batch each
+        for other in [m for m in ("fp16", "strict", "precise") if m != args.mode]:
+            gen.weight_split, gen.act_split, gen.cfg_pair = MODES[other]
+            gen.wcorr_from = 0
+            one_batch(10_000); torch.cuda.synchronize()
+            ts = time.perf_counter()
+            one_batch(10_001); torch.cuda.synchronize()
+            modes[other] = {"images_per_s": B / (time.perf_counter() - ts), "timed": False, "parity": measured_parity(gen)}
         gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
+        gen.wcorr_from = gen.depth // 2 if args.mode == "wcorr" else 0
+        if args.mode != "wcorr":
+            try:                                                # second reference run (context only: never costs the headline line)
+                for name, par in second_run_parity(dev, {m: MODES[m] for m in modes}).items():
+                    modes[name]["parity_second_run"] = par
+            except Exception as e:                              # noqa: BLE001
+                modes["parity_second_run_error"] = repr(e)
     others = None
     if world == 1 and not args.no_modes and B == B_PER_GPU:
         try:
@@ -336,7 +365,9 @@ def main():
             "precision": {"timed_mode": args.mode,
                           "strict": "the product default: fp16 MFMA, fp32 accumulate, classifier-free guidance in differential form (the unconditional "
                                     "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u)",
-                          "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
+                          "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)",
+                          "precise": "strict + an MX-fp4 correction pass for the fp16 rounding of the weights on the conditional half of every trunk "
+                                     "GEMM (LFQBert.cfg_pair = 2): the mode with margin under the 1e-3 bound, at ~0.84 of the default's speed"},
             "precision_modes": modes,
             "other_configs": others,
             "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,

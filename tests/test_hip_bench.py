@@ -36,6 +36,10 @@ def test_bench_single_gpu_contract():
     pm = d["precision_modes"]
     assert pm["strict"]["timed"] and pm["strict"]["parity"]["positions"] == 84284 and pm["strict"]["parity"]["token_mismatch"] <= 1e-3
     assert not pm["fp16"]["timed"] and pm["fp16"]["images_per_s"] > 0
+    # the mode with margin, and both modes on the second full-size reference run (other weights, noise, labels)
+    assert not pm["precise"]["timed"] and pm["precise"]["parity"]["token_mismatch"] <= 7e-4
+    assert pm["strict"]["parity_second_run"]["positions"] == 84284 and pm["strict"]["parity_second_run"]["token_mismatch"] <= 1e-3
+    assert pm["precise"]["parity_second_run"]["token_mismatch"] <= 7e-4
 
 
 def test_bench_two_ranks_on_one_gpu():
