@@ -287,10 +287,9 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   const int d = c.hidden, f = c.mlp, N = g->N, nb = 2 * B, M = nb * N, P = B * N;
   g_prof.next_forward();
   int rc = 0;
-  // measured (tests/diag/weight_subset_study.py): the weight rounding of the SECOND half of the trunk is what costs token parity (exact weights in
-  // layers 0..11 alone: no gain; in layers 12..23: most of the gain) -> the correction pass runs in layers >= depth / 2 only
-  // measured (tests/diag/weight_subset_study.py, profiles/r03_parity.md): the correction pass in layers >= depth / 2 alone buys 62 % of the gain on the
-  // 12-bit run for half of the cost, and next to nothing on the 14-bit one -- an option (mb_gen_set_wcorr_from), not the default
+  // measured (profiles/r03_parity.md): the correction pass in layers >= depth / 2 alone buys about 60 % of the gain on the 12-bit runs for half of
+  // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- an option
+  // (mb_gen_set_wcorr_from), not the default
   const int wfrom = g->wcorr_from;
   auto x4_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4 : nullptr; };
   auto x4s_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4s : nullptr; };
