@@ -42,7 +42,7 @@ F_SEQ = 162.33e9                        # algorithmic FLOPs per 257-token sequen
 F_DEC = 185.97e9                        # per decoded image
 DEC_BYTES_IDEAL = 426e6                  # per decoded image: 213.06 M elements x 2 B
 HBM_PEAK_GBS = 8000.0
-PROF_EVERY = 8                           # HIP-event timing of every 8th forward of the timed region (16 of 128 per batch)
+PROF_EVERY = 8                           # HIP-event timing of every 8th forward of the timed region (forwards 4, 12, .. 60 of a 64-step run: all guided)
 GEN_SEED, HEAD_GAIN, TOK_SEED = 100, 12.0, 200   # maskbit_amd/synth.py: the same synthetic checkpoints the golden fixtures were made with
 
 
@@ -140,17 +140,19 @@ def measured_parity(gen, run=None):
             "against": f"the reference's own sample() run, CPU fp32 (tests/golden/{run or 'sample_full12_64'}.npz), teacher-forced per step"}
 
 
-def second_run_parity(dev, mode_settings):
-    """The same measurement on the SECOND full-size reference run (other generator weights, head gain, noise seed and labels:
-    tests/golden/sample_full12_64_s2.npz) for each (weight_split, act_split, cfg_pair) in `mode_settings` -> {mode: parity}."""
+def other_runs_parity(dev, mode_settings):
+    """The same measurement on the OTHER full-size 12-bit runs of the reference (other generator weights, head gain, noise seed and labels:
+    tests/golden/sample_full12_64_s2.npz, 84 284 positions, and _s3.npz, batch 8, 168 568 positions) for each (weight_split, act_split, cfg_pair)
+    in `mode_settings` -> {mode: {run: parity, "pooled_with_first_run": ...}} (the first run's count is added by the caller's own measurement)."""
     from maskbit_amd import parity_replay as R
-    gen, _ = R.build_models(dev, with_tokenizer=False, name=R.RUN_C3_S2)
-    out = {}
-    for name, (ws, asplit, pair) in mode_settings.items():
-        gen.weight_split, gen.act_split, gen.cfg_pair = ws, asplit, pair
-        out[name] = measured_parity(gen, R.RUN_C3_S2)
-    del gen
-    torch.cuda.empty_cache()
+    out = {m: {} for m in mode_settings}
+    for run in (R.RUN_C3_S2, R.RUN_C3_S3):
+        gen, _ = R.build_models(dev, with_tokenizer=False, name=run)
+        for name, (ws, asplit, pair) in mode_settings.items():
+            gen.weight_split, gen.act_split, gen.cfg_pair = ws, asplit, pair
+            out[name][run] = measured_parity(gen, run)
+        del gen
+        torch.cuda.empty_cache()
     return out
 
 
@@ -198,10 +200,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU per step (default: the C3 batch, 64)")
-    ap.add_argument("--mode", choices=("strict", "fp16", "wcorr", "precise", "max"), default="strict",
-                    help="precision mode of the TIMED region: strict (default; the product default, meets <= 1e-3 token mismatch), single fp16, "
-                         "precise (strict + MX-fp4 weight-rounding correction pass on every trunk GEMM), wcorr (that pass in the second half of the "
-                         "trunk only) or max (strict + fp16x2 weights)")
+    ap.add_argument("--mode", choices=("strict", "diff", "fp16", "wcorr", "max"), default="strict",
+                    help="precision mode of the TIMED region: strict (default; the product default: differential guidance + an MX-fp4 correction pass "
+                         "for the weights' fp16 rounding on every trunk GEMM; meets <= 1e-3 token mismatch with margin), diff (differential guidance "
+                         "alone: faster, AT the bound), single fp16, wcorr (the correction pass in the second half of the trunk only) or max (fp16x2 weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurements: parity replay and the other precision mode")
@@ -235,7 +237,7 @@ def main():
 
     B = args.batch
     gen, tok = build_models(dev)
-    MODES = {"strict": (0, -1, -1), "fp16": (0, 0, 0), "wcorr": (0, -1, 2), "precise": (0, -1, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
+    MODES = {"strict": (0, -1, -1), "diff": (0, -1, 1), "fp16": (0, 0, 0), "wcorr": (0, -1, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
     gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
     gen.wcorr_from = gen.depth // 2 if args.mode == "wcorr" else 0
     torch.manual_seed(1234 + rank)
@@ -278,23 +280,34 @@ def main():
     modes = None
     if world == 1 and not args.no_modes:
         modes = {args.mode: {"images_per_s": B * world * args.steps / elapsed, "timed": True, "parity": measured_parity(gen)}}
-        # the mode below the default (single fp16, independent streams) and the one above it (the weight-correction pass on every trunk GEMM:
-        # the mode with real margin under the 1e-3 bound), one untimed-region batch each
-        for other in [m for m in ("fp16", "strict", "precise") if m != args.mode]:
+        # the two faster modes below the default (differential guidance without the weight-correction pass; single fp16 with independent streams),
+        # one untimed-region batch each -- the first with the kernel timers on, so that the line also carries the dominant GEMM without the pass
+        for other in [m for m in ("diff", "fp16", "strict") if m != args.mode][:2]:
             gen.weight_split, gen.act_split, gen.cfg_pair = MODES[other]
             gen.wcorr_from = 0
             one_batch(10_000); torch.cuda.synchronize()
+            if other == "diff" and not args.no_prof:
+                _lib.prof_enable(True, every=PROF_EVERY)
             ts = time.perf_counter()
             one_batch(10_001); torch.cuda.synchronize()
-            modes[other] = {"images_per_s": B / (time.perf_counter() - ts), "timed": False, "parity": measured_parity(gen)}
+            ips = B / (time.perf_counter() - ts)
+            pr = {}
+            if other == "diff" and not args.no_prof:
+                pr = _lib.prof_read()
+                _lib.prof_enable(False)
+            modes[other] = {"images_per_s": ips, "timed": False, "parity": measured_parity(gen)}
+            if "gemm_ffn_up" in pr:
+                c_, ms_ = pr["gemm_ffn_up"]
+                modes[other]["ffn_up_avg_launch_us"] = ms_ / c_ * 1e3
+                modes[other]["ffn_up_frac_of_peak"] = 2.0 * (2 * B * 257) * 4096 * 1024 / (ms_ / c_ * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
         gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
         gen.wcorr_from = gen.depth // 2 if args.mode == "wcorr" else 0
         if args.mode != "wcorr":
-            try:                                                # second reference run (context only: never costs the headline line)
-                for name, par in second_run_parity(dev, {m: MODES[m] for m in modes}).items():
-                    modes[name]["parity_second_run"] = par
+            try:                                                # the other full-size reference runs (context only: never costs the headline line)
+                for name, par in other_runs_parity(dev, {m: MODES[m] for m in modes}).items():
+                    modes[name]["parity_other_runs"] = par
             except Exception as e:                              # noqa: BLE001
-                modes["parity_second_run_error"] = repr(e)
+                modes["parity_other_runs_error"] = repr(e)
     others = None
     if world == 1 and not args.no_modes and B == B_PER_GPU:
         try:
@@ -318,10 +331,10 @@ def main():
             fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
             traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.*), if present
             traffic_src = None
-            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for name in ("r03c_pmc_traffic.json", "r03_pmc_traffic.json"):     # the counter passes of the dominant kernel as the timed mode runs it
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                    if B == B_PER_GPU and args.mode in pmc.get("_mode", "fp16"):
+                    if B == B_PER_GPU and pmc.get("_mode", "").split(" ")[0] == args.mode:
                         traffic = pmc[dom.replace("gemm_", "")]["hbm_bytes_corrected"]
                         traffic_src = name
                         break
@@ -364,10 +377,11 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "precision": {"timed_mode": args.mode,
                           "strict": "the product default: fp16 MFMA, fp32 accumulate, classifier-free guidance in differential form (the unconditional "
-                                    "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u)",
-                          "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)",
-                          "precise": "strict + an MX-fp4 correction pass for the fp16 rounding of the weights on the conditional half of every trunk "
-                                     "GEMM (LFQBert.cfg_pair = 2): the mode with margin under the 1e-3 bound, at ~0.84 of the default's speed"},
+                                    "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u) + an MX-fp4 "
+                                    "correction pass for the fp16 rounding of the weights on the conditional half of every trunk GEMM (LFQBert.cfg_pair = 2)",
+                          "diff": "the differential form without the correction pass (LFQBert.cfg_pair = 1): ~1.17x the default's speed; its token "
+                                  "mismatch over the three reference runs is 1.03e-3, AT the bound (round 2's default)",
+                          "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
             "precision_modes": modes,
             "other_configs": others,
             "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,

@@ -217,7 +217,7 @@ int mb_gemm(int epi, const void* A, const void* W, const float* bias, const floa
 /* Persistent kernels launch one workgroup per CU.  On a stream created with a CU mask (hipExtStreamCreateWithCUMask) fewer CUs serve the launch:
  * n = the CUs the following launches should size their grids for, 0 = the device's count (default).  Process-wide, not thread-safe. */
 int mb_set_cu_count(int n);
-int mb_prof_enable(int on); /* 0 off; n >= 1: HIP-event timing of every kernel of every n-th generator forward (and of all other calls) */
+int mb_prof_enable(int on); /* 0 off; n >= 1: HIP-event timing of every kernel of every n-th generator forward (forwards n/2, n/2 + n, ..) and of all other calls */
 int mb_prof_read(char* buf, int buflen); /* host buffer; writes "name calls total_ms\n" lines */
 
 #ifdef __cplusplus

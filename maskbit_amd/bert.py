@@ -25,11 +25,11 @@ DEFAULT_WEIGHT_SPLIT = 0
 # (act_split 3 where the lo-pass kernels take the shape, i.e. hidden and mlp multiples of 256; act_split 2 otherwise).
 DEFAULT_ACT_SPLIT = -1
 STRICT_LEVEL = int(os.environ.get("MASKBIT_AMD_STRICT_LEVEL", "3"))   # lo-pass format behind "strict": 3 = e4m3, 4 = MX-fp4 for the LayerNorm outputs
-# Differential classifier-free guidance (mb_gen_cfg.cfg_pair) for the GUIDED forward (forward_cfg / sample() with guidance): -1 = auto (1 where
-# the shape allows it), 0 = off, 1 = differential operands -- the hi + lo pairs' parity class at the cost of the plain fp16 forward --,
-# 2 = "precise": + an MX-fp4 correction pass for the fp16 rounding of every trunk weight (+19 % time; token mismatch against the reference's own
-# runs 5.0e-4 / 5.5e-4 instead of 8.4e-4 / 9.9e-4 on the two 12-bit / 64-step runs, 6.5e-4 instead of 1.42e-3 on the 14-bit / 256-step one:
-# profiles/r03_parity.md).  act_split keeps governing the plain (unguided) forward.
+# Differential classifier-free guidance (mb_gen_cfg.cfg_pair) for the GUIDED forward (forward_cfg / sample() with guidance): -1 = auto (2 where
+# the shape allows it), 0 = off, 1 = differential operands alone -- the fastest guided forward; its token mismatch against the reference's own
+# 12-bit / 64-step runs is 1.03e-3 over three runs (8.4e-4 / 9.9e-4 / 1.14e-3): AT the 1e-3 bound, not under it --, 2 = the default: + an MX-fp4
+# correction pass for the fp16 rounding of every trunk weight (0.85 of the speed of 1; 4.8e-4 over the three runs, 4.4-5.5e-4 per run; the 14-bit /
+# 256-step runs 9.1e-4 over two runs against 1.42e-3 without it: profiles/r03_parity.md).  act_split keeps governing the plain (unguided) forward.
 DEFAULT_CFG_PAIR = -1
 
 
@@ -105,8 +105,8 @@ class LFQBert(BaseModel):
         # the shape allows, else 2.  Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
         self.act_split = int(os.environ.get("MASKBIT_AMD_ACT_SPLIT", str(DEFAULT_ACT_SPLIT)))
         self.cfg_pair = int(os.environ.get("MASKBIT_AMD_CFG_PAIR", str(DEFAULT_CFG_PAIR)))
-        # cfg_pair 2 only: first trunk layer that carries the weight-correction pass (0 = all; depth // 2 = the second half of the trunk: half the
-        # cost, 6.3e-4 instead of 5.0e-4 on the 12-bit / 64-step run, no use on the 14-bit one -- profiles/r03_parity.md)
+        # cfg_pair 2 only: first trunk layer that carries the weight-correction pass (0 = all, the default; depth // 2 = the second half of the trunk:
+        # half the cost, 7.6e-4 instead of 4.8e-4 over the three 12-bit / 64-step runs, no use on the 14-bit ones -- profiles/r03_parity.md)
         self.wcorr_from = int(os.environ.get("MASKBIT_AMD_WFROM", "0"))
         self._engine_split = None
         if not self.embed_tables:
@@ -130,16 +130,16 @@ class LFQBert(BaseModel):
         return h
 
     def resolved_precision(self):
-        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch the cheapest way": guided
-        forwards in differential form where the shape allows it -- with the weight-correction pass (cfg_pair 2) from 7 bits per group on, where the
-        fp16 rounding of the weights alone exceeds the bound (measured against the reference's own runs: 14-bit / 256 steps 1.42e-3 without it,
-        6.5e-4 with it; 12-bit / 64 steps 8.4e-4 without it) -- and plain forwards with hi + lo activation pairs."""
+        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch with margin": guided forwards
+        in differential form WITH the weight-correction pass (cfg_pair 2) wherever the shape allows it, for every codebook -- the differential
+        form alone measures 1.03e-3 over three full-size 12-bit runs of the reference (one of them 1.14e-3) and 1.42e-3 on the 14-bit one, i.e. the
+        fp16 rounding of the weights alone reaches the bound -- and plain forwards with hi + lo activation pairs."""
         capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm)
         pair, act = int(self.cfg_pair), int(self.act_split)
         if act < 0:
             act = 0 if self.weight_split else resolve_act_split(act, self.hidden_dim, self.mlp_dim)   # fp16x2 weights are not combined with act_split
         if pair < 0:
-            pair = 2 if self.bits // self.splits >= 7 else 1
+            pair = 2
         if not capable:
             pair = 0
         if pair == 2 and (act == 4 or self.weight_split):

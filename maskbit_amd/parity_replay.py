@@ -27,6 +27,9 @@ GOLDEN = os.path.join(GOLDEN_DIR, "sample_full12_64.npz")
 RUN_CFG1 = "sample_full10_16_nocfg"
 RUN_CFG5 = "sample_full14_256"
 RUN_C3_S2 = "sample_full12_64_s2"        # configs[2] again: other generator weights (seed, head gain), noise seed and labels
+RUN_C3_S3 = "sample_full12_64_s3"        # ... and a third time at twice the batch (168 568 sampled positions)
+RUN_CFG1_S2 = "sample_full10_16_nocfg_s2"   # second runs of configs[1] and configs[4] (other weights, head gain, noise, labels)
+RUN_CFG5_S2 = "sample_full14_256_s2"
 
 
 def load_run(name: str = "sample_full12_64") -> Dict[str, object]:

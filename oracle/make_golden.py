@@ -114,6 +114,11 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # a second full-size 12-bit run of the real reference: other generator weights (seed, head gain), other noise seed, other labels -- the parity
     # figure of configs[2] is then not a single-draw result (round-2 review, item 3)
     "sample_full12_64_s2": (12, 177, 16.0, 4, FULL64, False, 4321, 8),
+    # round 3, end: more statistical power (a mismatch count of ~70 carries a Poisson sigma of ~8): a third 12-bit run at twice the batch, and
+    # second runs of the other two BASELINE configurations
+    "sample_full12_64_s3": (12, 180, 12.0, 8, FULL64, False, 4324, 0),
+    "sample_full10_16_nocfg_s2": (10, 178, 16.0, 16, CFG1_16, False, 4322, 0),
+    "sample_full14_256_s2": (14, 179, 16.0, 2, CFG5_256, False, 4323, 4),
 }
 
 

@@ -27,14 +27,15 @@ def test_fixture_is_the_documented_run(setup):
 
 @pytest.mark.timeout(900)
 def test_teacher_forced_mismatch_vs_reference_run(setup):
-    """<= 1e-3 in the product default precision (the mode bench.py times); the single-fp16 mode is measured beside it for context."""
+    """The product default precision (the mode bench.py times: differential guidance + weight-correction pass) measures 4.9e-4 on this run:
+    asserted <= 7e-4 (the north star's bound is 1e-3); the single-fp16 mode is measured beside it for context."""
     g, gen, tok, noise = setup
     gen.weight_split, gen.act_split, gen.cfg_pair = 0, -1, -1
     bad, tot, per_step, remask = R.teacher_forced(gen, g, noise)
     print(f"product default: teacher-forced mismatch vs the reference's run {bad}/{tot} = {bad / tot:.2e}; re-mask differences {remask}; "
           f"per 8 steps {[sum(per_step[i:i + 8]) for i in range(0, 64, 8)]}")
     assert tot == 84284
-    assert bad / tot <= 1e-3
+    assert bad / tot <= 7e-4
     gen.act_split, gen.cfg_pair = 0, 0
     bad0, _, per0, _ = R.teacher_forced(gen, g, noise)
     print(f"single fp16:     teacher-forced mismatch vs the reference's run {bad0}/{tot} = {bad0 / tot:.2e}; "

@@ -1,5 +1,6 @@
 """Run one trunk GEMM shape as the engine's guided forward runs it (CFG pair tiles, B = 64 pairs) a few times: target for rocprofv3 --pmc passes.
-usage: python tools/pair_one.py <qkv|attn_out|ffn_up|ffn_down> [iters]"""
+usage: [PAIR_ONE_F4=1] python tools/pair_one.py <qkv|attn_out|ffn_up|ffn_down> [iters]      (PAIR_ONE_F4: with the MX-fp4 weight-correction pass,
+                                                                                             as the product default runs it since the end of round 3)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +19,14 @@ bias = torch.randn(N, device=dev) * 0.1
 res = torch.randn(M, N, device=dev) if epi == 2 else None
 o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
 ptr = lambda t: t.data_ptr() if t is not None else None
+x4 = xs = w4 = ws = None
+if os.environ.get("PAIR_ONE_F4"):
+    x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8)
+    xs = torch.full((P * (K // 64) + 256,), 100, device=dev, dtype=torch.uint8)
+    w4 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); ws = torch.zeros(N, device=dev, dtype=torch.uint8)
+    _lib.check(lib.mb_w4_from_f32(W.float().data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
 for _ in range(iters):
-    _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(res), ptr(o16), P, N, K, None, None, None, None,
+    _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(res), ptr(o16), P, N, K, ptr(x4), ptr(xs), ptr(w4), ptr(ws),
                                 torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
 print("done")

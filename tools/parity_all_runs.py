@@ -1,0 +1,33 @@
+"""Teacher-forced token mismatch of the product default and of the precise mode on EVERY recorded full-size run of the reference
+(tests/golden/sample_full*.npz), with the pooled figure per BASELINE configuration.
+usage: python tools/parity_all_runs.py [run names ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from maskbit_amd import parity_replay as R
+
+GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C3_S2, R.RUN_C3_S3],
+          "configs[1] 10-bit / 16 steps / no CFG": [R.RUN_CFG1, R.RUN_CFG1_S2],
+          "configs[4] 14-bit / 256 steps / CFG 5.8": [R.RUN_CFG5, R.RUN_CFG5_S2]}
+MODES = (("default", -1, -1), ("precise (cfg_pair = 2)", -1, 2))
+only = set(sys.argv[1:])
+for grp, names in GROUPS.items():
+    pooled = {m[0]: [0, 0] for m in MODES}
+    for name in names:
+        if only and name not in only:
+            continue
+        if not os.path.exists(os.path.join(R.GOLDEN_DIR, name + ".npz")):
+            continue
+        g = R.load_run(name)
+        gen, _ = R.build_models("cuda", with_tokenizer=False, name=name)
+        noise = R.reference_noise(g, gen.device)
+        for tag, asplit, pair in MODES:
+            gen.act_split, gen.cfg_pair = asplit, pair
+            bad, tot, per, _ = R.teacher_forced(gen, g, noise)
+            pooled[tag][0] += bad; pooled[tag][1] += tot
+            S = len(per)
+            print(f"{name:28s} {tag:24s} resolves to {gen.resolved_precision()}: {bad:4d}/{tot} = {bad / tot:.2e}   per eighth {[sum(per[i * S // 8:(i + 1) * S // 8]) for i in range(8)]}", flush=True)
+        del gen, noise; torch.cuda.empty_cache()
+    for tag, (b, t) in pooled.items():
+        if t:
+            print(f"== {grp}: {tag}: {b}/{t} = {b / t:.2e} (Poisson sigma {b ** 0.5 / t:.1e})", flush=True)
