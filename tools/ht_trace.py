@@ -1,7 +1,7 @@
 """Phase timeline of the half-tile GEMM on the trunk shapes: a copy of the library built with -DMB_HT_TRACE stamps the 100 MHz wall clock at the
 phase boundaries of every workgroup's tiles (gemm_ht.hip: MB_TRACE).  Answers: how long is the K loop of a tile, what does a tile pay outside it,
 and do all CUs hit their epilogues at the same time?
-  python tools/ht_trace.py build      (here: compiles tools/_ab/libtrace{1,2,3,4}.so; mode 2 also waits for the stores at the end of every tile;
+  [HT_DEFS="-DX=1 .."] python tools/ht_trace.py build      (here: compiles tools/_ab/libtrace{1,2,3,4}.so with the extra defines; mode 2 also waits for the stores at the end of every tile;
                                        modes 3 / 4 (results are garbage, timing only): the K loop issues no DMA / re-reads K-tiles 0 and 1 = pure L2 hits)
   python tools/ht_trace.py run [mode] (on the GPU box)"""
 import ctypes as C
@@ -20,7 +20,7 @@ def build():
             obj = os.path.join(AB, f"trace{mode}_{src.replace('.hip', '.o')}")
             objs.append(obj)
             procs.append(subprocess.Popen([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f"-DMB_HT_TRACE={mode % 10}", *(["-DMB_BS_NOLOAD=1"] if mode >= 10 else []),
-                                           "-c", os.path.join(B.CSRC, src), "-o", obj]))
+                                           *os.environ.get("HT_DEFS", "").split(), "-c", os.path.join(B.CSRC, src), "-o", obj]))
         assert all(p.wait() == 0 for p in procs)
         subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", os.path.join(AB, f"libtrace{mode}.so")])
         print("built", os.path.join(AB, f"libtrace{mode}.so"))

@@ -35,6 +35,14 @@ __global__ __launch_bounds__(512, 2) void mfma_kernel(float* out, int iters, lon
     } else if (SHAPE == 128) {                          // e4m3 x e4m3, K = 128: 4x the flops of one 16x16x32 f16 MFMA
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc4[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc4[i], 0, 0, 0, 127, 0, 127);
+    } else if (SHAPE == 129) {                          // fp4 x fp4 (cbsz = blgp = 4), K = 128: the weight-correction pass's instruction
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc4[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc4[i], 4, 4, 0, 127, 0, 127);
+    } else if (SHAPE == 65) {                           // fp4 x fp4, 32x32x64
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc16[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc16[i], 4, 4, 0, 127, 0, 127);
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
@@ -60,11 +68,13 @@ int main() {
   // says zero-filled inputs clock ~20 % higher than random ones.  Random operands are what a GEMM sees.
   for (int zeros = 0; zeros < 2; ++zeros)
   for (int rep = 0; rep < 3; ++rep)
-    for (int shape : {16, 32, 128}) {
+    for (int shape : {16, 32, 128, 129, 65}) {
       const int iters = 20000;                        // x 16 (or 8) MFMAs: 262144 flop-units per wave either way
       auto launch = [&](int n) {
         if (shape == 16) hipLaunchKernelGGL(mfma_kernel<16>, dim3(ncu), dim3(512), 0, 0, out, n, clk, zeros);
         else if (shape == 128) hipLaunchKernelGGL(mfma_kernel<128>, dim3(ncu), dim3(512), 0, 0, out, n, clk, zeros);
+        else if (shape == 129) hipLaunchKernelGGL(mfma_kernel<129>, dim3(ncu), dim3(512), 0, 0, out, n, clk, zeros);
+        else if (shape == 65) hipLaunchKernelGGL(mfma_kernel<65>, dim3(ncu), dim3(512), 0, 0, out, n, clk, zeros);
         else hipLaunchKernelGGL(mfma_kernel<32>, dim3(ncu), dim3(512), 0, 0, out, n, clk, zeros);
       };
       launch(1000);
@@ -72,9 +82,9 @@ int main() {
       float ms; hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
       hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
       double mhz = 0; for (int i = 0; i < ncu; ++i) mhz += (double)h[2 * i] / ((double)h[2 * i + 1] / 100.0); mhz /= ncu;
-      const double flops = (double)ncu * 8 * iters * 16 * 2.0 * 16 * 16 * (shape == 128 ? 128 : 32);
+      const double flops = (double)ncu * 8 * iters * 16 * 2.0 * 16 * 16 * (shape >= 128 ? 128 : shape == 65 ? 128 : 32);   // (32x32x64 x 8 per iteration = 16x16x128 x 16)
       printf("%s %s: %8.3f ms  %7.1f TFLOP/s  shader clock %6.0f MHz  (peak at that clock %.0f TFLOP/s)\n",
-             zeros ? "[zero operands]  " : "[random operands]", shape == 16 ? "v_mfma_f32_16x16x32_f16" : shape == 128 ? "v_mfma_scale_f32_16x16x128 e4m3" : "v_mfma_f32_32x32x16_f16", ms, flops / ms / 1e9, mhz, ncu * 4 * 1024.0 * mhz * 1e6 / 1e12);
+             zeros ? "[zero operands]  " : "[random operands]", shape == 16 ? "v_mfma_f32_16x16x32_f16" : shape == 128 ? "v_mfma_scale_f32_16x16x128 e4m3" : shape == 129 ? "v_mfma_scale_f32_16x16x128 fp4" : shape == 65 ? "v_mfma_scale_f32_32x32x64 fp4" : "v_mfma_f32_32x32x16_f16", ms, flops / ms / 1e9, mhz, ncu * 4 * 1024.0 * mhz * 1e6 / 1e12);
     }
   return 0;
 }
