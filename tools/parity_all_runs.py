@@ -1,4 +1,4 @@
-"""Teacher-forced token mismatch of the product default and of the precise mode on EVERY recorded full-size run of the reference
+"""Teacher-forced token mismatch of the product default and of the differential form without the weight-correction pass on EVERY recorded full-size run of the reference
 (tests/golden/sample_full*.npz), with the pooled figure per BASELINE configuration.
 usage: python tools/parity_all_runs.py [run names ...]"""
 import os, sys
@@ -9,7 +9,7 @@ from maskbit_amd import parity_replay as R
 GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C3_S2, R.RUN_C3_S3],
           "configs[1] 10-bit / 16 steps / no CFG": [R.RUN_CFG1, R.RUN_CFG1_S2],
           "configs[4] 14-bit / 256 steps / CFG 5.8": [R.RUN_CFG5, R.RUN_CFG5_S2]}
-MODES = (("default", -1, -1), ("precise (cfg_pair = 2)", -1, 2))
+MODES = (("default", -1, -1), ("differential only (cfg_pair = 1)", -1, 1))
 only = set(sys.argv[1:])
 for grp, names in GROUPS.items():
     pooled = {m[0]: [0, 0] for m in MODES}
@@ -26,7 +26,7 @@ for grp, names in GROUPS.items():
             bad, tot, per, _ = R.teacher_forced(gen, g, noise)
             pooled[tag][0] += bad; pooled[tag][1] += tot
             S = len(per)
-            print(f"{name:28s} {tag:24s} resolves to {gen.resolved_precision()}: {bad:4d}/{tot} = {bad / tot:.2e}   per eighth {[sum(per[i * S // 8:(i + 1) * S // 8]) for i in range(8)]}", flush=True)
+            print(f"{name:28s} {tag:34s} resolves to {gen.resolved_precision()}: {bad:4d}/{tot} = {bad / tot:.2e}   per eighth {[sum(per[i * S // 8:(i + 1) * S // 8]) for i in range(8)]}", flush=True)
         del gen, noise; torch.cuda.empty_cache()
     for tag, (b, t) in pooled.items():
         if t:
