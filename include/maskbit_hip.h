@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MB_ABI_VERSION 5
+#define MB_ABI_VERSION 6
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
 typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
@@ -47,26 +47,26 @@ typedef struct {
    * Checkpoint keys then are tok_emb_list.{g}.weight and bias.{g} instead of input_proj.* / prediction_layer.*. */
   int prenorm;
   int embed_tables;
-  /* Activation precision of the GEMMs that consume a LayerNorm output (QKV projection and FFN up-projection): 0 = one fp16
-   * value per element; 1 = fp16 hi + lo pairs (x = hi + lo, |x - hi - lo| <= 2^-22 |x|): the LayerNorm kernels store both
-   * halves and those two GEMMs sweep the weight twice (hi.W + lo.W in the same fp32 accumulator; twice their work).  With
-   * classifier-free guidance this rounding point decides the token parity: see DESIGN.md, "Precision".  2 = additionally the
-   * attention output and the FFN hidden are hi + lo pairs (written by the attention kernel and the FFN-up epilogue), so all four
-   * trunk GEMMs of a layer do twice their work.  3 = as 2, but the lo halves are stored as e4m3(lo * 2^12) and multiplied with an e4m3
-   * copy of the weights on v_mfma_scale_f32_16x16x128_f8f6f4 (whose E8M0 scales undo the powers of two): the correction pass costs half
-   * a sweep; needs hidden and mlp to be multiples of 256.  4 = as 3, but the lo halves of the LayerNorm outputs are MX-fp4 (e2m1, one
-   * power-of-two scale per row) against an e2m1 copy of the QKV / FFN-up weights (per-row scales): that correction pass costs a quarter
-   * sweep (hidden 768 / 1024).  2, 3 and 4 meet the <= 1e-3 token mismatch against the fp32 reference.  Not combined with weight_split. */
+  /* Activation precision of the trunk GEMMs in the PLAIN forward when the weight-correction mode below does not serve it (explicit modes; the
+   * default resolves to 0 with cfg_pair >= 2): 0 = one fp16 value per element; 1 = fp16 hi + lo pairs for the LayerNorm outputs (QKV and FFN-up
+   * sweep their weight twice: hi.W + lo.W in the same fp32 accumulator); 2 = additionally for the attention output and the FFN hidden (all four
+   * trunk GEMMs do twice their work); 3 = as 2 with the lo halves stored as e4m3(lo * 2^12) and multiplied with an e4m3 copy of the weights on
+   * v_mfma_scale_f32_16x16x128_f8f6f4 (half a sweep; hidden and mlp multiples of 256).  Not combined with weight_split.  (4, the MX-fp4 lo K-tiles of
+   * rounds 2-3, is retired: cfg_pair 2 / 3.) */
   int act_split;
-  /* Classifier-free guidance in differential form (mb_gen_forward_cfg / mb_sample; DESIGN.md "Precision"): 0 = off (the guided forward is
-   * the plain forward over [cond | uncond]); 1 = the unconditional stream's GEMM operands are carried as fp16(x_u - x_c) next to fp16(x_c),
-   * so the operand rounding of x_c is common to both streams and cancels in (c - u), the term the guidance scale multiplies -- at no
-   * extra GEMM work (act_split then only concerns the plain forward; weight_split = 1 composes: the pair GEMMs sweep twice); 2 = additionally an
-   * MX-fp4 correction pass for the fp16 rounding of the WEIGHTS of all four trunk GEMMs in the guided forward (e2m1 of the conditional operand
-   * values with per-(row, 64 columns) scales against e2m1(W - fp16(W)) with per-row scales; a quarter sweep over the conditional half of every
-   * tile): measured token mismatch of the fp16x2-weight mode (5.8e-4 / 7.1e-4 against 4.7e-4 / 6.6e-4 on the 12-bit / 14-bit runs) for +17 % time;
-   * not combined with act_split = 4 or weight_split.
-   * Pair forwards need seq = 256, hidden 768 / 1024, mlp % 256 == 0, post-norm; otherwise the engine falls back to the plain forward. */
+  /* Precision mode of the engine (DESIGN.md "Precision").
+   * 0 = independent streams: the guided forward is the plain forward over [cond | uncond].
+   * 1 = classifier-free guidance in DIFFERENTIAL form (mb_gen_forward_cfg / mb_sample): the unconditional stream's GEMM operands are carried as
+   *     fp16(x_u - x_c) next to fp16(x_c), so the operand rounding of x_c is common to both streams and cancels in (c - u), the term the guidance
+   *     scale multiplies -- at no extra GEMM work (weight_split = 1 composes: the pair GEMMs sweep twice).
+   * 2 = 1 + an MX-fp4 correction of the fp16 rounding of the WEIGHTS of all four trunk GEMMs (the product default): e2m1 of the operand VALUES
+   *     with per-(row, 64 columns) scales against e2m1(W - fp16(W)) with per-row scales, as 24 KiB mini-tiles staged under the fp16 K-tiles and
+   *     multiplied between them (gemm_ht.hip, XP = 6) -- on the conditional rows of the guided forward (the unconditional outputs inherit it through
+   *     the shared accumulator) and on every row of the plain forward (act_split 0).  Not combined with weight_split.
+   * 3 = 2 + the same kind of pass for the fp16 rounding of the conditional LayerNorm OUTPUTS in the guided forward's QKV / FFN-up GEMMs (e2m1 of
+   *     their lo halves against e2m1 of the weights): what the 7-bit-per-group codebooks need for margin (tests/diag/error_budget.py).
+   * Pair forwards need seq = 256, hidden 768 / 1024, mlp % 256 == 0, post-norm; modes 2 / 3 also hidden / heads = 64.  Otherwise the engine falls
+   * back (guided: plain forward over [cond | uncond]; plain: act_split). */
   int cfg_pair;
 } mb_gen_cfg;
 
@@ -80,7 +80,7 @@ typedef struct {
   int channel_mult[8]; /* [1,1,2,2,4]                               */
   int latent_size;     /* token grid side: 16 (=> 256x256 output)   */
   int build_encoder;   /* 1: also build ConvEncoder (autoencoder.py:230-286) for mb_enc_encode */
-  int sample_with_conv;/* encoder downsampling by stride-2 conv (every shipped config); 0 (avg-pool) is not built */
+  int sample_with_conv;/* encoder downsampling by stride-2 conv (every shipped config); 0 = 2x2 average pooling */
   int enc_res_blocks;  /* num_res_blocks of the encoder (num_res_blocks above is the decoder's); 0 = same */
 } mb_dec_cfg;
 
@@ -109,11 +109,11 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out);
 void mb_gen_destroy(mb_gen* g);
 /* One call per checkpoint entry (key names of SURVEY.md 8b / BaseModel.load_pretrained,
  * modeling/modules/base_model.py:87-141).  `data` is a device fp32 tensor in the checkpoint's
- * own layout; GEMM weights are repacked to fp16 here (plus the 8- / 4-bit lo-pass copies of the strict mode).  Unknown names return -2. */
+ * own layout; GEMM weights are repacked to fp16 here (plus the e2m1 / e4m3 operands of the correction passes; the two head weights as fp16
+ * hi + lo planes).  Unknown names return -2. */
 int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream);
-/* cfg_pair == 2 only: the weight-correction pass of the guided forward runs in trunk layers >= `layer` (default 0 = every layer; depth = none).  The
- * second half of the trunk alone (layer = depth / 2) costs half as much and measured 6.3e-4 instead of 5.0e-4 / 8.4e-4 (all / no layers) on the
- * 12-bit 64-step run of the reference, but 1.26e-3 instead of 6.5e-4 on the 14-bit 256-step one (profiles/r03_parity.md). */
+/* cfg_pair >= 2 only: the correction passes of the GUIDED forward run in trunk layers >= `layer` (default 0 = every layer; depth = none).  An
+ * experiment knob (profiles/r03_parity.md: partial coverage buys less than its share), not used by the product path. */
 int mb_gen_set_wcorr_from(mb_gen* g, int layer);
 /* tokens int64 [nb,seq,m] (value C = masked), labels int64 [nb], drop uint8 [nb] (1 => label
  * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */
@@ -168,57 +168,13 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
               const float* exp_noise, const float* conf_noise, int64_t* step_tokens, int64_t* tokens_out,
               float* img_nchw, uint8_t* img_nhwc_u8, mb_stream stream);
 
-/* ---- introspection used by bench.py (not part of the reference surface) -------------------- */
-/* Name + accumulated device time (HIP events on the launch stream) of the engine's kernels. */
-/* One GEMM of the trunk family, out[M,N] = A[M,K] . W[N,K]^T + bias with epilogue `epi` (0 fp16 out,
- * 1 gelu->fp16, 2 +residual->fp32, 3 gelu->fp32, 4 logits fp32 with every `period`-th row dropped);
- * A, W, out_h16 are fp16 device buffers.  variant: 0 auto, -1 the 128x128 kernel, 6 / 8 the half-tile kernel with
- * 192 / 256-row tiles, 257 its sequence-aligned tiles (M % 257 == 0). */
-/* Split-weight diagnostics: repack W[N,K] fp32 -> dst[N,2K] fp16 (hi | lo) + *scale_out, and the GEMM over such a weight
- * (mb_gemm_ex with K = 2*ka, A is [M,ka]); `tmp` is 4 bytes of device scratch. */
-int mb_split_weights(const float* W, int N, int K, void* dst_h16, float* scale_out, void* tmp, mb_stream stream);
-int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
-               int M, int N, int K, int ka /*0, or K/2: split weights*/, const float* scale /*split weights*/,
-               const float* ln_stats /*or NULL: residual = LayerNorm(residual rows) from {mean,rstd}[M]*/, const float* ln_g,
-               const float* ln_b, int period, int variant, mb_stream stream);
-/* LayerNorm over rows (modeling/bert.py:69-70,137-139): any of x_f32 / x_h16 / stats ({mean, rstd} per row) may be NULL. */
-int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x_lo, float* stats,
-                 int M, int d, mb_stream stream);
-/* A GEMM with split activations: out = (A_hi + A_lo) . W^T + bias through the engine's kernels (A_hi, A_lo fp16 [M, kw], W fp16
- * [N, kw]; x_lo as written by mb_layernorm).  Diagnostic / test entry for mb_gen_cfg.act_split. */
-/* The same with an e4m3 lo pass: A8 = e4m3(lo * 2^12) and W8 = e4m3(W * 2^(*w8_exp)), both with the row stride of their fp16 siblings
- * (2*kw bytes, first kw used); kw % 128 == 0.  Diagnostic / test entry for mb_gen_cfg.act_split == 3. */
-int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const void* W8, const int* w8_exp, const float* bias,
-                 const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
-/* The same with an MX-fp4 lo pass (mb_gen_cfg.act_split == 4): A4 = e2m1(lo * 2^s_m) two values per byte with one E8M0 scale byte per row
- * (a_scale[m], as mb_layernorm_f4 writes them), W4 / w_scale from mb_w4_from_f32 (per-row scales in the kernel's lane order); both 4-bit
- * operands with the row stride of their fp16 siblings (2*kw bytes, first kw/2 used); kw % 256 == 0, N % 64 == 0. */
-int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
-/* the same layout for the weight's fp16 rounding error W - fp16(W) (operand of the weight-correction pass, mb_gen_cfg.cfg_pair == 2) */
-int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
-int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x4, void* x4_scale,
-                    int M, int d, mb_stream stream);
-int mb_gemm_f4lo(int epi, const void* A_hi, const void* A4, const void* a_scale, const void* W, const void* W4, const void* w_scale,
-                 const float* bias, const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
-/* A "CFG pair" GEMM (mb_gen_cfg.cfg_pair): rows [0, pair_rows) of A / out are conditional, [pair_rows, 2 pair_rows) their unconditional twins whose
- * A rows hold the difference operand; out_c = f(A_c.W), out_u = f(A_c.W + A_delta.W) (GELU epilogue: the u rows receive gelu(u) - gelu(c)).
- * pair_rows % 257 == 0.  A4 / a_scale / W4 / w_scale (all four or none): an MX-fp4 correction pass over kw/256 extra K-tiles. */
-int mb_gemm_pair(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
-                 int pair_rows, int N, int kw, const void* A4, const void* a_scale, const void* W4, const void* w_scale, mb_stream stream);
-/* Attention of a CFG pair batch (the generator's guided forward, bert.py:84,137 on both streams): qkv [2 pairs N, 3d] fp16 packed in_proj rows, the
- * conditional sequences first, their unconditional twins `pairs` sequences later.  out rows of conditional sequences = softmax(QK^T/sqrt(dh))V in
- * fp16; rows of unconditional sequences = fp16(o_u - o_c), the difference operand of the out-proj pair GEMM.  aux [pairs N, d] fp32: scratch of the
- * two-launch form (MASKBIT_AMD_ATT_PAIR=2); the default form keeps the conditional rows in registers and leaves it untouched. */
-int mb_attention_pair(const void* qkv, void* out_h16, float* aux, int pairs, int N, int d, int heads, mb_stream stream);
-int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual,
-                      float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
-int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
-            void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
-/* Persistent kernels launch one workgroup per CU.  On a stream created with a CU mask (hipExtStreamCreateWithCUMask) fewer CUs serve the launch:
- * n = the CUs the following launches should size their grids for, 0 = the device's count (default).  Process-wide, not thread-safe. */
-int mb_set_cu_count(int n);
+/* ---- measurement hooks used by bench.py (not part of the reference surface) ----------------- */
 int mb_prof_enable(int on); /* 0 off; n >= 1: HIP-event timing of every kernel of every n-th generator forward (forwards n/2, n/2 + n, ..) and of all other calls */
 int mb_prof_read(char* buf, int buflen); /* host buffer; writes "name calls total_ms\n" lines */
+/* fp16 activation stores of the trunk saturate at +-65504 instead of producing infinities.  Number of QKV / FFN-up / attention / LayerNorm output
+ * groups of this handle's forwards that were clamped since the last reset (0 for every configuration tested, synthetic heavy-tailed weights
+ * included; a checkpoint that needs more range shows up here instead of being clipped silently).  Synchronises `stream`. */
+int mb_gen_saturation_count(mb_gen* g, unsigned* count, int reset, mb_stream stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmaskbit_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GenCfg(C.Structure):
@@ -30,8 +30,9 @@ class SamplePlan(C.Structure):
                 ("temperature", C.POINTER(C.c_float)), ("mask_len", C.POINTER(C.c_int)), ("step_begin", C.c_int), ("step_end", C.c_int)]
 
 
-# name -> (restype, argtypes); every symbol include/maskbit_hip.h declares
+# name -> (restype, argtypes); every symbol include/maskbit_hip.h (the ABI) and include/maskbit_hip_diag.h (single-kernel test entries) declare
 SIGNATURES = {
+    "mb_gen_saturation_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
     "mb_abi_version": (C.c_int, []),
     "mb_last_error": (C.c_char_p, []),
     "mb_gen_create": (C.c_int, [C.POINTER(GenCfg), C.c_int, C.POINTER(C.c_void_p)]),
@@ -59,12 +60,11 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_w4_from_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mb_w4lo_from_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mb_layernorm_f4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "mb_gemm_f4lo": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mb_layernorm_f4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_void_p]),
     "mb_attention_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "mb_gemm_pair": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mb_gemm_mini": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
     "mb_gemm_act_split": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),
     "mb_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

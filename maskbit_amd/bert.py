@@ -21,15 +21,15 @@ from . import _lib
 from .base_model import BaseModel, ParamSpec
 
 DEFAULT_WEIGHT_SPLIT = 0
-# -1 = "strict": the cheapest activation precision that meets the <= 1e-3 token mismatch against the fp32 reference
-# (act_split 3 where the lo-pass kernels take the shape, i.e. hidden and mlp multiples of 256; act_split 2 otherwise).
+# Activation precision of the PLAIN forward where the weight-correction mode does not serve it (mb_gen_cfg.act_split): -1 = auto -- 0 when the
+# engine's mode (below) covers the plain forward, otherwise the cheapest hi + lo activation mode the shape allows (3 = e4m3 lo halves where hidden
+# and mlp are multiples of 256, else 2).
 DEFAULT_ACT_SPLIT = -1
-STRICT_LEVEL = int(os.environ.get("MASKBIT_AMD_STRICT_LEVEL", "3"))   # lo-pass format behind "strict": 3 = e4m3, 4 = MX-fp4 for the LayerNorm outputs
-# Differential classifier-free guidance (mb_gen_cfg.cfg_pair) for the GUIDED forward (forward_cfg / sample() with guidance): -1 = auto (2 where
-# the shape allows it), 0 = off, 1 = differential operands alone -- the fastest guided forward; its token mismatch against the reference's own
-# 12-bit / 64-step runs is 1.03e-3 over three runs (8.4e-4 / 9.9e-4 / 1.14e-3): AT the 1e-3 bound, not under it --, 2 = the default: + an MX-fp4
-# correction pass for the fp16 rounding of every trunk weight (0.85 of the speed of 1; 4.8e-4 over the three runs, 4.4-5.5e-4 per run; the 14-bit /
-# 256-step runs 9.1e-4 over two runs against 1.42e-3 without it: profiles/r03_parity.md).  act_split keeps governing the plain (unguided) forward.
+# Precision mode of the engine (mb_gen_cfg.cfg_pair): -1 = auto, 0 = independent streams, 1 = classifier-free guidance in differential form alone --
+# the fastest guided forward; its token mismatch against the reference's own 12-bit / 64-step runs is 1.03e-3 over three runs (8.4e-4 / 9.9e-4 /
+# 1.14e-3): AT the 1e-3 bound, not under it --, 2 = + the MX-fp4 weight-correction mini-tiles on every trunk GEMM, in the guided AND the plain forward
+# (the default below 7 bits per group), 3 = + the activation-lo mini-tiles for the LayerNorm outputs in the guided forward (the default from 7 bits
+# per group on: the 14-bit / 256-step configuration sits at the bound without it; tests/diag/error_budget.py, profiles/r04_parity.md).
 DEFAULT_CFG_PAIR = -1
 
 
@@ -37,12 +37,15 @@ def pair_capable(seq_len: int, hidden: int, mlp: int, prenorm: bool) -> bool:
     return seq_len == 256 and hidden in (768, 1024) and mlp % 256 == 0 and not prenorm
 
 
+def mini_capable(seq_len: int, hidden: int, mlp: int, heads: int) -> bool:
+    """Shapes the MX-fp4 mini-tile passes serve (mb_gen_create: mini_ok)."""
+    return seq_len == 256 and hidden in (768, 1024) and mlp % 128 == 0 and hidden // heads == 64
+
+
 def resolve_act_split(act_split: int, hidden: int, mlp: int) -> int:
     if act_split >= 0:
         return act_split
-    if hidden % 256 == 0 and mlp % 256 == 0:
-        return STRICT_LEVEL if (STRICT_LEVEL < 4 or hidden in (768, 1024)) else 3
-    return 2
+    return 3 if (hidden % 256 == 0 and mlp % 256 == 0) else 2
 
 
 def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int, prenorm: bool = False,
@@ -98,11 +101,10 @@ class LFQBert(BaseModel):
         # GEMM weight precision of the device engine (not a reference argument): 0 = fp16, 1 = fp16 hi+lo pairs ("fp16x2",
         # twice the GEMM work, weight rounding 2^-22).  Default from MASKBIT_AMD_WEIGHT_SPLIT; may be changed before a call.
         self.weight_split = int(os.environ.get("MASKBIT_AMD_WEIGHT_SPLIT", str(DEFAULT_WEIGHT_SPLIT)))
-        # Activation precision of the trunk GEMMs: 0 = single fp16 (fastest; 1.4-1.6e-3 token mismatch, the operating point of the reference's
-        # own TF32 GPU runs); 1 = fp16 hi+lo pairs for the LayerNorm outputs; 2 = also for the attention output and the FFN hidden (all four
-        # trunk GEMMs do twice the work); 3 = as 2 with the lo halves and a weight copy in 8 / 4 bits (the correction pass costs a fraction
-        # of a sweep).  2 and 3 meet the <= 1e-3 token mismatch against the fp32 reference (DESIGN.md "Precision").  -1 (DEFAULT) = 3 where
-        # the shape allows, else 2.  Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
+        # Activation precision of the plain forward's trunk GEMMs where the engine's weight-correction mode does not serve it: 0 = single fp16;
+        # 1 = fp16 hi+lo pairs for the LayerNorm outputs; 2 = also for the attention output and the FFN hidden (all four trunk GEMMs do twice the
+        # work); 3 = as 2 with the lo halves and a weight copy in 8 bits (half a sweep).  -1 (DEFAULT): see DEFAULT_ACT_SPLIT.
+        # Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
         self.act_split = int(os.environ.get("MASKBIT_AMD_ACT_SPLIT", str(DEFAULT_ACT_SPLIT)))
         self.cfg_pair = int(os.environ.get("MASKBIT_AMD_CFG_PAIR", str(DEFAULT_CFG_PAIR)))
         # cfg_pair 2 only: first trunk layer that carries the weight-correction pass (0 = all, the default; depth // 2 = the second half of the trunk:
@@ -130,20 +132,23 @@ class LFQBert(BaseModel):
         return h
 
     def resolved_precision(self):
-        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch with margin": guided forwards
-        in differential form WITH the weight-correction pass (cfg_pair 2) wherever the shape allows it, for every codebook -- the differential
-        form alone measures 1.03e-3 over three full-size 12-bit runs of the reference (one of them 1.14e-3) and 1.42e-3 on the 14-bit one, i.e. the
-        fp16 rounding of the weights alone reaches the bound -- and plain forwards with hi + lo activation pairs."""
+        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch": the fp16 rounding of the trunk
+        WEIGHTS is ~80 % of the sampled-logit error variance in every configuration (tests/diag/error_budget.py), so wherever the shape allows it
+        every trunk GEMM carries the MX-fp4 weight-correction mini-tiles -- guided forwards in differential form (cfg_pair 2; 3 from 7 bits per
+        group on: + the activation-lo pass of the LayerNorm outputs), plain forwards with single fp16 activations (act_split 0).  Measured
+        (profiles/r04_parity.md): 12-bit / 64 steps 4.9e-4 over three reference runs; other shapes fall back to the differential form alone /
+        hi + lo activation pairs."""
         capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm)
+        mini = mini_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.heads) and not self.weight_split
         pair, act = int(self.cfg_pair), int(self.act_split)
-        if act < 0:
-            act = 0 if self.weight_split else resolve_act_split(act, self.hidden_dim, self.mlp_dim)   # fp16x2 weights are not combined with act_split
         if pair < 0:
-            pair = 2
-        if not capable:
+            pair = 3 if self.bits // self.splits >= 7 else 2
+        if pair >= 2 and not mini:
+            pair = 1                                               # no mini-tile passes for this shape (or fp16x2 weights, which do not need them)
+        if pair == 1 and not capable:
             pair = 0
-        if pair == 2 and (act == 4 or self.weight_split):
-            pair = 1                                               # the weight-correction pass shares buffers with act_split 4; fp16x2 weights do not need it
+        if act < 0:                                                # the plain forward: covered by the weight correction, else hi + lo activation pairs
+            act = 0 if (self.weight_split or pair >= 2) else resolve_act_split(act, self.hidden_dim, self.mlp_dim)
         return act, pair
 
     def _engine_destroy(self, h) -> None:
@@ -164,6 +169,17 @@ class LFQBert(BaseModel):
             _lib.check(_lib.load().mb_gen_set_wcorr_from(h, wf), "mb_gen_set_wcorr_from")
             self._engine_wfrom = wf
         return h
+
+    def saturation_count(self, reset: bool = True) -> int:
+        """Lanes of the trunk's fp16 QKV / FFN-up epilogues that clamped a value at +-65504 since the last reset (mb_gen_saturation_count): 0 for every
+        configuration tested; a checkpoint whose activations need more range shows up here instead of being clipped silently."""
+        if self._engine is None:
+            return 0
+        n = C.c_uint(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().mb_gen_saturation_count(self._engine, C.byref(n), int(reset), torch.cuda.current_stream().cuda_stream),
+                       "mb_gen_saturation_count")
+        return int(n.value)
 
     def _check_labels(self, labels: torch.Tensor) -> None:
         """Host-resident labels are range-checked here (an out-of-range class would index past class_emb, where the

@@ -55,9 +55,10 @@ __device__ long long* g_att_trace = nullptr;
 template <int DH, int AUX = 0>
 __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
                                                           int N, int d, int heads, float scale_log2e, float* __restrict__ aux = nullptr, int sq_off = 0,
-                                                          uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr) {
-  // out4 / out4s (AUX 1, optional): e2m1 of the conditional output VALUES (row stride 2d bytes) with one E8M0 scale byte per (row, head) --
-  // out4s[row][d / 64], DH = 64 -- the token operand of the out-proj GEMM's weight-correction pass
+                                                          uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0) {
+  // out4 / out4s (AUX 1 / 4: conditional sequences; AUX 5: the plain forward, every sequence; optional): e2m1 of the output VALUES (row stride 2d
+  // bytes) with one E8M0 scale byte per (row, head) in the lane-ordered layout of the GEMM's mini-tile passes (GemmArgs.lo; out4_nseq sequences),
+  // DH = 64, N = 257 -- the token operand of the out-proj GEMM's weight-correction pass
   constexpr int ROW = DH * 2;            // bytes per K / V row
   constexpr int SL = DH / 8;             // 16-byte slots per row (8 or 4)
   constexpr int KS = DH / 32;            // k-steps of the QK^T MFMA
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
     MB_ATRACE(5 + 4 * i);
     // ---- o[nt][r] = O[q = l15][dh = nt*16 + g*4 + r]
     const int q = qt * 16 + l15;
-    if constexpr ((AUX == 1 || AUX == 4) && DH == 64) {
-      if (out4 && (AUX == 1 || pass == 0)) {                          // block (row, head) = this lane's 16 values x its 4 lane groups
+    if constexpr ((AUX == 1 || AUX == 4 || AUX == 5) && DH == 64) {
+      if (out4 && (AUX != 4 || pass == 0)) {                          // block (row, head) = this lane's 16 values x its 4 lane groups
         float am = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -289,9 +290,9 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         am = fmaxf(am, __shfl_xor(am, 16));
         am = fmaxf(am, __shfl_xor(am, 32));
         const float mul = fp4_scale_mul_nosat(am);
-        if (q < N) {
+        if (q < 256) {                                                // (class-token rows take no part in the mini-tile passes)
           const size_t row = (size_t)sq * N + q;
-          if (g == 0) out4s[row * (d / 64) + h] = (uint8_t)fp4_scale_byte_nosat(am);
+          if (g == 0) out4s[fp4_scale_index(h, out4_nseq, sq, q)] = (uint8_t)fp4_scale_byte_nosat(am);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             *(uint16_t*)(out4 + row * 2 * d + (h * DH + nt * 16 + g * 4) / 2) = (uint16_t)fp4_pack4(o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv, mul);
@@ -533,7 +534,7 @@ int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, in
   return 0;
 }
 
-void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo, uint8_t* out_lo8) {
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo, uint8_t* out_lo8, uint8_t* out4, uint8_t* out4s) {
   const int dh = d / heads;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   if (N > ATT_NP) {                                           // longer than one head's K/V fits in LDS: streaming kernel
@@ -544,7 +545,9 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
     return;
   }
   dim3 grid(nb * heads), block(64 * ATT_NW);
-  if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
+  if (out4 && dh == 64 && N == 257)        // plain forward with the weight-correction mini-tiles: also the e2m1 copy of the outputs
+    hipLaunchKernelGGL((attention_kernel<64, 5>), grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e, (float*)nullptr, 0, out4, out4s, nb);
+  else if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
   else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
 }
 
@@ -583,15 +586,15 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
   dim3 grid(P * heads), block(64 * ATT_NW);
   // A/B switch, read once per process: 4 (default) = one launch / 2 = two launches through the fp32 aux rows
   static const int pair_mode = getenv("MASKBIT_AMD_ATT_PAIR") ? atoi(getenv("MASKBIT_AMD_ATT_PAIR")) : 4;
-  if (out4 && dh != 64) return -1;         // the fp4 output exists for head dimension 64
+  if (out4 && (dh != 64 || N != 257)) return -1;         // the fp4 output exists for head dimension 64 and 257-token sequences
   if (pair_mode == 4) {                    // one workgroup per (pair, head): conditional pass, then the twin; conditional outputs parked in registers
     // 88 us against 119 us for the two launches (B = 64 pairs): a third of the traffic was the fp32 aux round trip
-    if (dh == 64) hipLaunchKernelGGL((attention_kernel<64, 4>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P, out4, out4s);
+    if (dh == 64) hipLaunchKernelGGL((attention_kernel<64, 4>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P, out4, out4s, P);
     else hipLaunchKernelGGL((attention_kernel<32, 4>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P);
     return 0;
   }
   if (dh == 64) {
-    hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0, out4, out4s);
+    hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0, out4, out4s, P);
     hipLaunchKernelGGL((attention_kernel<64, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
   } else {
     hipLaunchKernelGGL((attention_kernel<32, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/maskbit_hip.h"
+#include "../../include/maskbit_hip_diag.h"
 #include "mb_decoder.h"
 #include "mb_kernels.h"
 
@@ -116,17 +116,25 @@ struct mb_gen {
   h16 *att_lo = nullptr, *h_lo = nullptr;                                                // cfg.act_split == 2: lo halves of att and h
   // cfg.act_split == 3: the lo halves as e4m3 (row stride 2 * width bytes) + e4m3 copies of the four trunk weights per layer
   uint8_t *x8 = nullptr, *att8 = nullptr, *h8 = nullptr;
-  // cfg.act_split == 4: the LayerNorm outputs' lo halves as MX-fp4 (x4, one E8M0 scale byte per row in x4s) + e2m1 copies of the two
-  // weights that read them (qkv, net.0) with per-row scales; attention output / FFN hidden keep the e4m3 lo halves of act_split 3
-  uint8_t *x4 = nullptr, *x4s = nullptr;
-  std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {qkv, -, 1, -}]
   std::vector<uint8_t*> w8;                                                              // [4 * layer + {qkv, o, 1, 2}]
-  // cfg.cfg_pair: differential CFG forward.  pair_ok = the shape allows it; aux = the conditional attention output in fp32 (attention_pair);
-  // cfg_pair == 2 ("W mode"): x4 / x4s hold e2m1(x_c) of the LayerNorm outputs, w4lo / w4los the e2m1 rounding errors of qkv / net.0
-  bool pair_ok = false;
+  // cfg.cfg_pair: differential CFG forward.  pair_ok = the shape allows it; aux = the conditional attention output in fp32 (attention_pair).
+  // cfg_pair >= 2 ("W mode", mini_ok = the shape allows it): every trunk GEMM carries the MX-fp4 weight-correction mini-tiles (gemm_ht.hip,
+  // XP = 6) -- in the guided forward on the conditional rows, in the plain forward on every row: x4 / att4 / h4 hold e2m1 of the LayerNorm outputs,
+  // attention outputs and FFN hiddens (values; x4s / att4s / h4s their lane-ordered block scales), w4lo / w4los e2m1 of the weights' fp16 rounding
+  // errors.  cfg_pair == 3 additionally corrects the fp16 rounding of the LayerNorm OUTPUTS in the guided forward's QKV / FFN-up GEMMs: xl4 / xl4s =
+  // e2m1 of their lo halves, w4 / w4s = e2m1 of the (fp16) weights qkv / net.0.
+  bool pair_ok = false, mini_ok = false;
+  uint8_t *x4 = nullptr, *x4s = nullptr, *xl4 = nullptr, *xl4s = nullptr;
+  std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {qkv, -, 1, -}]
   float* att_aux = nullptr;
   float* logits_tmp = nullptr;                          // guided forwards over more pairs than one pass holds
-  h16 *wl_plain = nullptr, *wp_plain = nullptr;         // fp16x2 weights + pair forward: single-fp16 copies of the two head weights (the head takes hi + lo INPUTS there)
+  // The two head GEMMs run hi + lo inputs against hi + lo WEIGHTS in every mode (GemmArgs.W2: three sweeps): their rounding reaches the logits
+  // un-averaged -- fp16 head weights alone were a quarter of the sampled-logit error variance left after the trunk's weight correction
+  // (tests/diag/error_budget.py) -- and the two GEMMs are 0.4 % of a forward.  wl / wp = fp16(w 2^S), wl_lo / wp_lo = the remainders, head_scale = 2^-S.
+  // (Bert's tied head, embed_tables: wp holds the tables' first C rows per group as single fp16, no lo plane.)
+  h16 *wl_lo = nullptr, *wp_lo = nullptr;
+  float* head_scale = nullptr;
+  unsigned* sat = nullptr;                              // lanes of the QKV / FFN-up epilogues that clamped a fp16 store (mb_gen_saturation_count)
   std::vector<uint8_t*> w4lo, w4los;                                                     // [4 * layer + {qkv, o, 1, 2}]
   uint8_t *att4 = nullptr, *att4s = nullptr, *h4 = nullptr, *h4s = nullptr;              // e2m1 of the conditional attention outputs / FFN hiddens + block scales
   int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
@@ -158,6 +166,28 @@ bool attn_f8_diag() {
   return on;
 }
 
+// The head (bert.py:411-417, 500-503): last_layer.0 + GELU, LayerNorm, prediction layer, on the hi + lo rows the trunk's last LayerNorm left in
+// x_h16 / x_lo -- hi + lo inputs against hi + lo weights in every mode (mb_gen::wl_lo)
+int head_gemms(mb_gen* g, float* logits, int M, hipStream_t s) {
+  using namespace mb;
+  const mb_gen_cfg& c = g->c;
+  const int d = c.hidden;
+  int rc = 0;
+  { ProfScope p("gemm_head", s, true);
+    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 3 * d, 0, 0, g->head_scale};
+    ga.A2 = g->x_lo; ga.kw = d; ga.W2 = g->wl_lo;
+    rc |= gemm_tn(s, EPI_GELU_F32, ga); }
+  { ProfScope p("layernorm", s, true);
+    layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
+  { ProfScope p("gemm_head", s, true);
+    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, (g->wp_lo ? 3 : 2) * d, g->N, 0,
+                g->wp_lo ? g->head_scale + 1 : nullptr};
+    ga.A2 = g->x_lo; ga.kw = d; ga.W2 = g->wp_lo;
+    ga.bias_per_pos = c.embed_tables;
+    rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
+  return rc;
+}
+
 int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits,
                      int nb, hipStream_t s, float* attn = nullptr) {
   using namespace mb;
@@ -170,14 +200,17 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   int attn_rc = 0, gemm_rc = 0;
   h16* const xlo_trunk = (c.act_split == 1 || c.act_split == 2) ? g->x_lo : nullptr;   // LayerNorms that feed trunk GEMMs write lo halves only when those GEMMs use them
   const bool f8 = c.act_split >= 3;                       // e4m3 lo halves + e4m3 weight copies: the lo pass costs half a sweep
-  const bool x4m = c.act_split == 4;                      // ... and the LayerNorm outputs' lo halves as MX-fp4: their lo pass costs a quarter sweep
-  uint8_t* const x8p = x4m ? nullptr : g->x8;
-  // cfg_pair == 2 outside a guided forward (plain forward(), sampling without guidance): weight rounding is the dominant logit error there, so the
-  // QKV / FFN-up GEMMs always carry the MX-fp4 weight-correction pass (x4 = e2m1 of the LayerNorm VALUES against e2m1(W - fp16(W)))
-  const bool wm = g->pair_ok && c.cfg_pair == 2 && !c.act_split && !c.weight_split;   // (with act_split the plain forward runs its hi + lo pairs instead)
+  uint8_t* const x8p = g->x8;
+  // cfg_pair >= 2 outside a guided forward (plain forward(), sampling without guidance, the zero-scale steps of a guided run): the fp16 rounding of
+  // the WEIGHTS is 80 % of the sampled-logit error variance there (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
+  // activation pairs, 0.0045 with the weight correction alone), so all four trunk GEMMs carry the MX-fp4 weight-correction mini-tiles on every row
+  const bool wm = g->mini_ok && c.cfg_pair >= 2 && !c.act_split && !c.weight_split;   // (with act_split the plain forward runs its hi + lo pairs instead)
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
-  uint8_t* const x4p = (x4m || wm) ? g->x4 : nullptr;
-  uint8_t* const x4sp = (x4m || wm) ? g->x4s : nullptr;
+  Fp4Rows f4x;
+  if (wm) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; }
+  auto lo_set = [&](GemmArgs& ga, const uint8_t* a4, const uint8_t* a4s, int widx) {
+    ga.nlo = 1; ga.lo[0] = {a4, a4s, g->w4lo[widx], g->w4los[widx]};
+  };
   g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
@@ -185,12 +218,12 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc, h16* out_lo = nullptr,
                    const uint8_t* w8 = nullptr, const int* w8e = nullptr, uint8_t* out_lo8 = nullptr, int widx = -1) {
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
-    if (wm) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4los[widx]; }
-    else if (x4m) { ga.K = d + d / 4; ga.ka = 0; ga.kw = d; ga.A4 = g->x4; ga.W4 = g->w4[widx]; ga.a_scale = g->x4s; ga.w_scale = g->w4s[widx]; ga.out_lo8 = out_lo8; }
+    if (wm) { ga.ka = 0; lo_set(ga, g->x4, g->x4s, widx); if (epi == EPI_GELU_H16) { ga.out4 = g->h4; ga.out4_scale = g->h4s; } }
     else if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
     else if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
     ga.out_lo = out_lo;
-    gemm_rc |= gemm_tn(s, epi, ga);
+    ga.sat = g->sat;
+    gemm_rc |= gemm_tn(s, epi, ga, wm ? 257 : 0);
   };
   // act_split == 2: the attention output and the FFN hidden also exist as hi + lo pairs, so the two residual GEMMs sweep their weight twice as well
   auto split2 = [&](GemmArgs& ga, const h16* lo, int kw) { if (lo) { ga.K = 2 * kw; ga.ka = 0; ga.A2 = lo; ga.kw = kw; } };
@@ -202,7 +235,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
     e.x_lo = c.depth ? xlo_trunk : g->x_lo;
-    e.x8 = x8p; e.x4 = x4p; e.x4_scale = x4sp; e.x4_values = wm;
+    e.x8 = x8p; e.f4 = f4x;
     embed_ln(s, e);
   }
   if (c.prenorm) {
@@ -210,23 +243,25 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
     for (int l = 0; l < c.depth; ++l) {
       const mb_gen::Layer& L = g->layers[l];
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, x4p, x4sp, wm); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, f4x); }
       { ProfScope p("gemm_qkv", s, true);
         xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
       if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
+      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wm ? g->att4 : nullptr, wm ? g->att4s : nullptr); }
       attn_rc |= attn_maps(l);
       { ProfScope p("gemm_attn_out", s, true);
         GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
         split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
-        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, x4p, x4sp, wm); }
+        if (wm) { ga.ka = 0; lo_set(ga, g->att4, g->att4s, 4 * l + 1); }
+        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
+      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, f4x); }
       { ProfScope p("gemm_ffn_up", s, true);
         xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
       { ProfScope p("gemm_ffn_down", s, true);
         GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
         split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
-        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
+        if (wm) { ga.ka = 0; lo_set(ga, g->h4, g->h4s, 4 * l + 3); }
+        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
     }
     { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }   // norm_after_transformer
   } else {
@@ -235,7 +270,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     { ProfScope p("gemm_qkv", s, true);
       xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
     if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8); }
+    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wm ? g->att4 : nullptr, wm ? g->att4s : nullptr); }
     attn_rc |= attn_maps(l);
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
     // GEMM operand and {mean, rstd}; the next residual GEMM re-derives the normalised rows in its epilogue and updates
@@ -244,30 +279,22 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
-      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, x4p, x4sp, wm); }
+      if (wm) { ga.ka = 0; lo_set(ga, g->att4, g->att4s, 4 * l + 1); }
+      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, f4x); }
     { ProfScope p("gemm_ffn_up", s, true);
       xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
     { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
-      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p, x4p, x4sp, wm); }   // the last one feeds the head
+      if (wm) { ga.ka = 0; lo_set(ga, g->h4, g->h4s, 4 * l + 3); }
+      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
+    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p,
+                                                          l + 1 == c.depth ? Fp4Rows{} : f4x); }   // the last one feeds the head
   }
   }
-  { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * c.depth)};
-    if (!g->split) split2(ga, g->x_lo, d);   // the two head GEMMs always take their LayerNorm inputs as hi + lo pairs: their rounding lands on the logits
-                              // un-averaged and is amplified by the guidance scale, and the two GEMMs are 0.4 % of a forward (DESIGN.md "Precision")
-    gemm_rc |= gemm_tn(s, EPI_GELU_F32, ga); }
-  { ProfScope p("layernorm", s, true);
-    layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
-  { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, d * ks, N, d, g->sc(4 * c.depth + 1)};
-    if (!g->split) split2(ga, g->x_lo, d);
-    ga.bias_per_pos = c.embed_tables;
-    gemm_rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
+  gemm_rc |= head_gemms(g, logits, M, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   if (attn_rc) return fail(-3, "attention maps: head dim %d / %d tokens not supported", d / c.heads, N);
@@ -291,13 +318,22 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- an option
   // (mb_gen_set_wcorr_from), not the default
   const int wfrom = g->wcorr_from;
-  auto x4_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4 : nullptr; };
-  auto x4s_for = [&](int consumer_layer) { return (wmode && consumer_layer >= wfrom) ? g->x4s : nullptr; };
-  auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, bool lo,
+  const bool alo = wmode && c.cfg_pair == 3;             // + activation-lo mini-tiles of the LayerNorm outputs (QKV / FFN-up)
+  auto f4_for = [&](int consumer_layer) {                // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
+    Fp4Rows f;
+    if (wmode && consumer_layer >= wfrom) { f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; if (alo) { f.xl4 = g->xl4; f.xl4s = g->xl4s; } }
+    return f;
+  };
+  // lo: 0 = fp16 only, 1 = weight-correction mini-tiles (a4 / a4s = e2m1 of the conditional operand values), 2 = + the activation-lo set (x only)
+  auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, int lo,
                    const uint8_t* a4 = nullptr, const uint8_t* a4s = nullptr) {
     GemmArgs ga{A, W, bias, res, res, out16, M, Nout, g->split ? 2 * K : K, 0, g->split ? K : 0, g->sc(widx)};   // fp16x2 weights: A swept twice
     ga.pair_rows = P;
-    if (lo) { ga.K = K + K / 4; ga.kw = K; ga.A4 = a4 ? a4 : g->x4; ga.W4 = g->w4lo[widx]; ga.a_scale = a4s ? a4s : g->x4s; ga.w_scale = g->w4los[widx]; }
+    if (epi != EPI_RES_F32) ga.sat = g->sat;
+    if (lo) {
+      ga.nlo = lo; ga.lo[0] = {a4, a4s, g->w4lo[widx], g->w4los[widx]};
+      if (lo == 2) ga.lo[1] = {g->xl4, g->xl4s, g->w4[widx], g->w4s[widx]};
+    }
     return ga;
   };
   {
@@ -305,49 +341,40 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     // (tokens / labels / drop are laid out [B conditional | B twins]; the twins repeat the conditional tokens and labels with the drop flag set)
     EmbedArgs e{tokens, labels, nullptr, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, B, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
-    if (embed_pair(s, e, x4_for(0), x4s_for(0))) {         // shapes the fused kernel does not serve: the two-kernel path
-      e.drop = drop; e.nb = nb;
+    e.f4 = f4_for(0);
+    if (embed_pair(s, e)) {         // shapes the fused kernel does not serve: the two-kernel path
+      e.drop = drop; e.nb = nb; e.f4 = Fp4Rows{};
       embed_ln(s, e);
-      rc |= pairify_rows(s, g->y_f32, g->x_h16, P, d, x4_for(0), x4s_for(0));        // y_f32 holds the embedding LayerNorm's fp32 rows here
+      rc |= pairify_rows(s, g->y_f32, g->x_h16, P, d, f4_for(0));        // y_f32 holds the embedding LayerNorm's fp32 rows here
     }
   }
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
+    const bool wl = wmode && l >= wfrom;
+    const int xlo_mode = wl ? (alo ? 2 : 1) : 0;
     { ProfScope p("gemm_qkv", s, true);
-      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wmode && l >= wfrom);
+      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, xlo_mode, g->x4, g->x4s);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
     if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-    const bool wl = wmode && l >= wfrom;
     { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads, wl ? g->att4 : nullptr, wl ? g->att4s : nullptr); }
     { ProfScope p("gemm_attn_out", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl, g->att4, g->att4s);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? 1 : 0, g->att4, g->att4s);
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
-    { ProfScope p("layernorm", s, true); rc |= layernorm_pair(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_h16, g->ln_stats, P, d, x4_for(l), x4s_for(l)); }
+    { ProfScope p("layernorm", s, true); rc |= layernorm_pair(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_h16, g->ln_stats, P, d, f4_for(l)); }
     { ProfScope p("gemm_ffn_up", s, true);
-      GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, wl);
+      GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, xlo_mode, g->x4, g->x4s);
       if (wl) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
       rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
     { ProfScope p("gemm_ffn_down", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl, g->h4, g->h4s);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? 1 : 0, g->h4, g->h4s);
       ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     { ProfScope p("layernorm", s, true);
       if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi (+ lo) rows
-      else rc |= layernorm_pair(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_h16, g->ln_stats, P, d, x4_for(l + 1), x4s_for(l + 1)); }
+      else rc |= layernorm_pair(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_h16, g->ln_stats, P, d, f4_for(l + 1)); }
   }
-  // head: hi + lo INPUT pairs in every mode (that rounding reaches the logits un-averaged and guidance multiplies it); single-fp16 head weights
-  { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->split ? g->wl_plain : g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 2 * d, 0, 0, nullptr};
-    ga.A2 = g->x_lo; ga.kw = d;
-    rc |= gemm_tn(s, EPI_GELU_F32, ga); }
-  { ProfScope p("layernorm", s, true);
-    layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
-  { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->split ? g->wp_plain : g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, 2 * d, N, 0, nullptr};
-    ga.A2 = g->x_lo; ga.kw = d;
-    ga.bias_per_pos = c.embed_tables;
-    rc |= gemm_tn(s, EPI_LOGITS_F32, ga); }
+  rc |= head_gemms(g, logits, M, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   if (rc) return fail(-3, "differential CFG forward: a kernel refused the shape (%d pairs x %d tokens, hidden %d, mlp %d)", B, N, d, f);
@@ -375,7 +402,7 @@ int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, flo
   const size_t P = (size_t)g->c.seq * g->c.splits;
   const bool pair = g->pair_ok && g->c.cfg_pair > 0;
   (void)scale;
-  const bool wmode = pair && g->c.cfg_pair == 2;        // weight-rounding correction pass (every step: weight rounding costs parity late in the run too)
+  const bool wmode = pair && g->c.cfg_pair >= 2;        // weight-rounding correction pass (every step: weight rounding costs parity late in the run too)
   const int chunk = g->chunk_seqs / 2;                  // pairs per pass
   if (chunk < 1) return fail(-1, "engine holds %d sequences: too few for a guided forward", g->chunk_seqs);
   for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -447,15 +474,17 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
-int mb_gemm_pair(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
-                 int pair_rows, int N, int kw, const void* A4, const void* a_scale, const void* W4, const void* w_scale, mb_stream stream) {
-  if (!A || !W || !bias || epi < 0 || epi > 2 || pair_rows <= 0 || kw <= 0 || kw % 64) return fail(-1, "mb_gemm_pair: bad arguments");
-  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, 2 * pair_rows, N, kw, 0, 0, nullptr};
-  a.pair_rows = pair_rows;
-  if (A4) { a.K = kw + kw / 4; a.kw = kw; a.A4 = (const uint8_t*)A4; a.a_scale = (const uint8_t*)a_scale; a.W4 = (const uint8_t*)W4; a.w_scale = (const uint8_t*)w_scale; }
-  if (!mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_pair: shape not supported by the pair tiles");
+int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
+                 void* out4_scale, int rows, int pair, int N, int K, int nlo, const void* const* lo /* nlo x {A4, a_scale, W4, w_scale} */, mb_stream stream) {
+  if (!A || !W || !bias || epi < 0 || epi > 2 || rows <= 0 || K <= 0 || K % 64 || nlo < 0 || nlo > 2 || (nlo && !lo)) return fail(-1, "mb_gemm_mini: bad arguments");
+  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, pair ? 2 * rows : rows, N, K, 0, 0, nullptr};
+  if (pair) a.pair_rows = rows;
+  a.nlo = nlo;
+  for (int i = 0; i < nlo; ++i) a.lo[i] = {(const uint8_t*)lo[4 * i], (const uint8_t*)lo[4 * i + 1], (const uint8_t*)lo[4 * i + 2], (const uint8_t*)lo[4 * i + 3]};
+  a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale;
+  if (a.M % 257 || !mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_mini: shape not supported by the sequence-aligned tiles");
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, 257)) return fail(-3, "mb_gemm_pair: shape refused");
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, 257)) return fail(-3, "mb_gemm_mini: shape refused");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -506,22 +535,12 @@ int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, 
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
-int mb_gemm_f4lo(int epi, const void* A_hi, const void* A4, const void* a_scale, const void* W, const void* W4, const void* w_scale, const float* bias,
-                 const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
-  if (!A_hi || !A4 || !a_scale || !W || !W4 || !w_scale || !bias || epi < 0 || epi > 2 || kw <= 0 || kw % 256) return fail(-1, "mb_gemm_f4lo: bad arguments");
-  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, kw + kw / 4, 0, 0, nullptr};
-  a.kw = kw; a.A4 = (const uint8_t*)A4; a.W4 = (const uint8_t*)W4; a.a_scale = (const uint8_t*)a_scale; a.w_scale = (const uint8_t*)w_scale;
-  if (!mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_f4lo: shape not supported by the half-tile kernel");
-  ProfScope p("gemm_diag", (hipStream_t)stream);
-  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
-  return 0;
-}
-int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x4, void* x4_scale, int M, int d,
-                    mb_stream stream) {
-  if (!y || !gamma || !beta || !x4 || !x4_scale || M <= 0 || (d != 768 && d != 1024)) return fail(-1, "mb_layernorm_f4: bad arguments (d must be 768 or 1024)");
-  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, nullptr, M, d, nullptr, nullptr, (uint8_t*)x4, (uint8_t*)x4_scale);
+int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x4, void* x4_scale, void* xl4,
+                    void* xl4_scale, int M, int d, mb_stream stream) {
+  if (!y || !gamma || !beta || (!x4 && !xl4) || (x4 && !x4_scale) || (xl4 && !xl4_scale) || M <= 0 || M % 257 || (d != 768 && d != 1024))
+    return fail(-1, "mb_layernorm_f4: bad arguments (d must be 768 or 1024, M a multiple of 257)");
+  mb::Fp4Rows f4{(uint8_t*)x4, (uint8_t*)x4_scale, (uint8_t*)xl4, (uint8_t*)xl4_scale, M / 257};
+  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, nullptr, M, d, nullptr, nullptr, f4);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -565,12 +584,11 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if ((c.prenorm != 0 && c.prenorm != 1) || (c.embed_tables != 0 && c.embed_tables != 1)) return fail(-1, "prenorm / embed_tables must be 0 or 1");
   if (c.embed_tables && c.weight_split) return fail(-1, "weight_split is not supported with embed_tables (the tied head spans one table per group)");
   if (c.embed_tables && c.splits > 8) return fail(-1, "embed_tables supports up to 8 token groups");
-  if (c.act_split < 0 || c.act_split > 4) return fail(-1, "act_split must be 0 .. 4");
-  if (c.act_split >= 3 && (c.hidden % 256 || c.mlp % 256)) return fail(-1, "act_split = 3 / 4 (8- / 4-bit lo pass) needs hidden and mlp to be multiples of 256");
-  if (c.act_split == 4 && c.hidden != 768 && c.hidden != 1024) return fail(-1, "act_split = 4 (MX-fp4 lo pass) is built for hidden = 768 or 1024");
+  if (c.act_split < 0 || c.act_split > 3) return fail(-1, "act_split must be 0 .. 3 (4, the MX-fp4 lo K-tiles of rounds 2-3, was retired with the mini-tile passes of cfg_pair 2 / 3)");
+  if (c.act_split >= 3 && (c.hidden % 256 || c.mlp % 256)) return fail(-1, "act_split = 3 (8-bit lo pass) needs hidden and mlp to be multiples of 256");
   if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
-  if (c.cfg_pair < 0 || c.cfg_pair > 2) return fail(-1, "cfg_pair must be 0, 1 or 2");
-  if (c.cfg_pair == 2 && (c.act_split == 4 || c.weight_split)) return fail(-1, "cfg_pair = 2 (weight-correction pass) is not combined with act_split = 4 / weight_split");
+  if (c.cfg_pair < 0 || c.cfg_pair > 3) return fail(-1, "cfg_pair must be 0 .. 3");
+  if (c.cfg_pair >= 2 && c.weight_split) return fail(-1, "cfg_pair = 2 / 3 (weight-correction passes) is not combined with weight_split");
   mb_gen* g = new mb_gen();
   g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
@@ -583,6 +601,8 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   g->layers.resize(c.depth);
   const size_t ws = g->split ? 2 : 1;                  // fp16 values per weight
   rc |= galloc(g, &g->wscale, (size_t)4 * c.depth + 2); rc |= galloc(g, &g->split_tmp, 1);
+  rc |= galloc(g, &g->sat, 1);
+  if (!rc) (void)hipMemset(g->sat, 0, sizeof(unsigned));
   for (auto& L : g->layers) {
     rc |= galloc(g, &L.wqkv, ws * 3 * d * d); rc |= galloc(g, &L.bqkv, 3 * d);
     rc |= galloc(g, &L.wo, ws * d * d); rc |= galloc(g, &L.bo, d);
@@ -595,56 +615,54 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (c.embed_tables) { rc |= galloc(g, &g->tables, (size_t)c.splits * (C + 1) * d); rc |= galloc(g, &g->bias_pos, (size_t)c.seq * c.splits * C); }
   rc |= galloc(g, &g->class_emb, (size_t)(c.nclass + 1) * d); rc |= galloc(g, &g->pos, (size_t)g->N * d);
   rc |= galloc(g, &g->ln0g, d); rc |= galloc(g, &g->ln0b, d);
-  rc |= galloc(g, &g->wl, ws * d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
-  rc |= galloc(g, &g->wp, ws * c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C);
+  rc |= galloc(g, &g->wl, d * d); rc |= galloc(g, &g->wl_lo, d * d); rc |= galloc(g, &g->bl, d); rc |= galloc(g, &g->lnhg, d); rc |= galloc(g, &g->lnhb, d);
+  rc |= galloc(g, &g->wp, (size_t)c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C); rc |= galloc(g, &g->head_scale, 2);
+  if (!c.embed_tables) rc |= galloc(g, &g->wp_lo, (size_t)c.splits * C * d);
   rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->ln_stats, M * 2); rc |= galloc(g, &g->x_h16, M * d);
-  if (!c.weight_split || c.cfg_pair) rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, act_split >= 1 for the trunk
-  if (c.weight_split && c.cfg_pair) { rc |= galloc(g, &g->wl_plain, d * d); rc |= galloc(g, &g->wp_plain, (size_t)c.splits * C * d); }
+  rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, act_split 1 / 2 for the trunk
   if (c.act_split == 2) { rc |= galloc(g, &g->att_lo, M * d); rc |= galloc(g, &g->h_lo, M * f); }
   if (c.act_split >= 3) {
-    const bool x4m = c.act_split == 4;
-    if (x4m) { rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, M + 256); } else rc |= galloc(g, &g->x8, M * 2 * d);
+    rc |= galloc(g, &g->x8, M * 2 * d);
     rc |= galloc(g, &g->att8, M * 2 * d); rc |= galloc(g, &g->h8, M * 2 * f);
     rc |= galloc(g, &g->w8_exp, (size_t)4 * c.depth);
-    g->w8.assign((size_t)4 * c.depth, nullptr); g->w4.assign((size_t)4 * c.depth, nullptr); g->w4s.assign((size_t)4 * c.depth, nullptr);
+    g->w8.assign((size_t)4 * c.depth, nullptr);
     for (int l = 0; l < c.depth; ++l) {
-      if (x4m) {
-        rc |= galloc(g, &g->w4[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4s[4 * l], 3 * d);
-        rc |= galloc(g, &g->w4[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4s[4 * l + 2], f);
-      } else { rc |= galloc(g, &g->w8[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w8[4 * l + 2], 2 * f * d); }
+      rc |= galloc(g, &g->w8[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w8[4 * l + 2], 2 * f * d);
       rc |= galloc(g, &g->w8[4 * l + 1], 2 * d * d); rc |= galloc(g, &g->w8[4 * l + 3], 2 * d * f);
     }
-    if (!rc) {
-      if (x4m) { (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, M + 256); } else (void)hipMemset(g->x8, 0, M * 2 * d);
-      (void)hipMemset(g->att8, 0, M * 2 * d); (void)hipMemset(g->h8, 0, M * 2 * f);
-    }
+    if (!rc) { (void)hipMemset(g->x8, 0, M * 2 * d); (void)hipMemset(g->att8, 0, M * 2 * d); (void)hipMemset(g->h8, 0, M * 2 * f); }
   }
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
+  // MX-fp4 mini-tile passes (cfg_pair 2 / 3): 257-token sequences, vector LayerNorm widths, heads of 64 (the attention kernels' e2m1 output), whole mini-tiles
+  g->mini_ok = c.cfg_pair >= 2 && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 128 == 0 && c.hidden / c.heads == 64 && !c.weight_split;
   // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
-  // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice; the weight-correction pass of
-  // cfg_pair 2 needs plain fp16 operands)
+  // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice)
   g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && !c.prenorm && g->chunk_seqs >= 2 &&
-               (c.cfg_pair == 1 || (c.act_split != 4 && !c.weight_split));      // (act_split 4 owns the x4 buffers; fp16x2 weights need no correction pass)
-  if (g->pair_ok) {
-    rc |= galloc(g, &g->att_aux, (M / 2) * d);
-    if (c.cfg_pair == 2) {
-      // x4s: per-row bytes in the plain forward (M), block bytes [row][d / 64] of the conditional rows in the pair forward (M / 2 * d / 64)
-      const size_t x4s_n = std::max<size_t>(M + 256, (M / 2) * (d / 64) + 256);
-      rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, x4s_n);
-      // (all M rows: the class-row DMA of a pair tile also stages the twin's row of the 4-bit operand; it is multiplied with scale 2^-127)
-      rc |= galloc(g, &g->att4, M * 2 * d); rc |= galloc(g, &g->att4s, (M / 2) * (d / 64) + 256);
-      rc |= galloc(g, &g->h4, M * 2 * f); rc |= galloc(g, &g->h4s, (M / 2) * (f / 64) + 256);
-      if (!rc) {
-        (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, x4s_n);
-        (void)hipMemset(g->att4, 0, M * 2 * d); (void)hipMemset(g->att4s, 0, (M / 2) * (d / 64) + 256);
-        (void)hipMemset(g->h4, 0, M * 2 * f); (void)hipMemset(g->h4s, 0, (M / 2) * (f / 64) + 256);
-      }
-      g->w4lo.assign((size_t)4 * c.depth, nullptr); g->w4los.assign((size_t)4 * c.depth, nullptr);
-      for (int l = 0; l < c.depth; ++l) {
-        rc |= galloc(g, &g->w4lo[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4los[4 * l], 3 * d);
-        rc |= galloc(g, &g->w4lo[4 * l + 1], 2 * d * d); rc |= galloc(g, &g->w4los[4 * l + 1], d);
-        rc |= galloc(g, &g->w4lo[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4los[4 * l + 2], f);
-        rc |= galloc(g, &g->w4lo[4 * l + 3], 2 * d * f); rc |= galloc(g, &g->w4los[4 * l + 3], d);
+               (c.cfg_pair == 1 || g->mini_ok);
+  if (g->pair_ok) rc |= galloc(g, &g->att_aux, (M / 2) * d);
+  if (g->mini_ok) {
+    // e2m1 operands: row stride of the fp16 sibling (2 * width bytes, first width / 2 used); scale bytes in lane order: [width / 64][sequences][256]
+    const size_t ns = (size_t)g->chunk_seqs * 256;
+    rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, (d / 64) * ns + 256);
+    rc |= galloc(g, &g->att4, M * 2 * d); rc |= galloc(g, &g->att4s, (d / 64) * ns + 256);
+    rc |= galloc(g, &g->h4, M * 2 * f); rc |= galloc(g, &g->h4s, (f / 64) * ns + 256);
+    if (c.cfg_pair == 3) { rc |= galloc(g, &g->xl4, M * 2 * d); rc |= galloc(g, &g->xl4s, (d / 64) * ns + 256); }
+    if (!rc) {
+      (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, (d / 64) * ns + 256);
+      (void)hipMemset(g->att4, 0, M * 2 * d); (void)hipMemset(g->att4s, 0, (d / 64) * ns + 256);
+      (void)hipMemset(g->h4, 0, M * 2 * f); (void)hipMemset(g->h4s, 0, (f / 64) * ns + 256);
+      if (g->xl4) { (void)hipMemset(g->xl4, 0, M * 2 * d); (void)hipMemset(g->xl4s, 0, (d / 64) * ns + 256); }
+    }
+    g->w4lo.assign((size_t)4 * c.depth, nullptr); g->w4los.assign((size_t)4 * c.depth, nullptr);
+    g->w4.assign((size_t)4 * c.depth, nullptr); g->w4s.assign((size_t)4 * c.depth, nullptr);
+    for (int l = 0; l < c.depth; ++l) {
+      rc |= galloc(g, &g->w4lo[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4los[4 * l], 3 * d);
+      rc |= galloc(g, &g->w4lo[4 * l + 1], 2 * d * d); rc |= galloc(g, &g->w4los[4 * l + 1], d);
+      rc |= galloc(g, &g->w4lo[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4los[4 * l + 2], f);
+      rc |= galloc(g, &g->w4lo[4 * l + 3], 2 * d * f); rc |= galloc(g, &g->w4los[4 * l + 3], d);
+      if (c.cfg_pair == 3) {
+        rc |= galloc(g, &g->w4[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4s[4 * l], 3 * d);
+        rc |= galloc(g, &g->w4[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4s[4 * l + 2], f);
       }
     }
   }
@@ -733,18 +751,16 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   if (!dst_f && !dst_h) return fail(-2, "mb_gen_load: unknown checkpoint entry '%s'", name);
   if (numel != want) return fail(-4, "mb_gen_load: '%s' has %zu elements, expected %zu", name, numel, want);
   if (dst_f == g->w_in) mb::transpose_f32(s, data, g->w_in, (int)d, c.bits);       // [d,K] -> [K,d] for the embed kernel
-  else if (dst_h && g->split) {
-    mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
-    if (dst_h == g->wl && g->wl_plain) mb::cast_f32_to_h16(s, data, g->wl_plain, numel);
-    if (dst_h == g->wp && g->wp_plain) mb::cast_f32_to_h16(s, data, g->wp_plain, numel);
-  }
+  else if (dst_h == g->wl) mb::split_f32_to_h16_planes(s, data, g->wl, g->wl_lo, wrows, wcols, g->head_scale, g->split_tmp);
+  else if (dst_h == g->wp) mb::split_f32_to_h16_planes(s, data, g->wp, g->wp_lo, wrows, wcols, g->head_scale + 1, g->split_tmp);
+  else if (dst_h && g->split) mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
   else if (dst_h) {
     mb::cast_f32_to_h16(s, data, dst_h, numel);
-    if (g->pair_ok && c.cfg_pair == 2 && sidx >= 0 && sidx < 4 * c.depth && g->w4lo[sidx]) mb::w4lo_from_f32(s, data, g->w4lo[sidx], wrows, wcols, g->w4los[sidx]);
-    if (c.act_split >= 3 && sidx >= 0 && sidx < 4 * c.depth) {
+    if (g->mini_ok && sidx >= 0 && sidx < 4 * c.depth) {
+      mb::w4lo_from_f32(s, data, g->w4lo[sidx], wrows, wcols, g->w4los[sidx]);
       if (g->w4[sidx]) mb::w4_from_f32(s, data, g->w4[sidx], wrows, wcols, g->w4s[sidx]);
-      else mb::w8_from_f32(s, data, g->w8[sidx], wrows, wcols, g->w8_exp + sidx, g->split_tmp);
     }
+    if (c.act_split >= 3 && sidx >= 0 && sidx < 4 * c.depth) mb::w8_from_f32(s, data, g->w8[sidx], wrows, wcols, g->w8_exp + sidx, g->split_tmp);
   }
   else HIP_TRY(hipMemcpyAsync(dst_f, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   g->loaded++;
@@ -754,6 +770,14 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
 int mb_gen_set_wcorr_from(mb_gen* g, int layer) {
   if (!g || layer < 0 || layer > g->c.depth) return fail(-1, "mb_gen_set_wcorr_from: layer outside [0, depth]");
   g->wcorr_from = layer;
+  return 0;
+}
+
+int mb_gen_saturation_count(mb_gen* g, unsigned* count, int reset, mb_stream stream) {
+  if (!g || !count) return fail(-1, "mb_gen_saturation_count: null argument");
+  HIP_TRY(hipMemcpyAsync(count, g->sat, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (reset) HIP_TRY(hipMemsetAsync(g->sat, 0, sizeof(unsigned), (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   const h16* xsrc[4];
   const h16* wsrc[4];
   const ptrdiff_t a2 = a.A2 ? a.A2 - a.A : 0;       // second sweep of A: the lo halves (split activations) or A itself (split weights)
+  const ptrdiff_t w2 = a.W2 ? a.W2 - a.W : 0;       // three sweeps (GemmArgs.W2): the third pairs A with the weights' lo halves
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = wave * 32 + j * 8 + (lane >> 3);
@@ -50,6 +51,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     const int ta = t < nka ? t : t - nka;          // split weights: A is swept once per weight half
     char* xb = smem + buf * 2 * TILE_BYTES + wave * 32 * 128;
     char* wb = xb + TILE_BYTES;
+    if (a.W2) {                                    // sweeps (A, W), (A2, W), (A, W2)
+      const int seg = t / nkw, tt = t - seg * nkw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        MB_GLDS16(xsrc[j] + (seg == 1 ? a2 : 0) + tt * BK, xb + j * 8 * 128);
+        MB_GLDS16(wsrc[j] + (seg == 2 ? w2 : 0) + tt * BK, wb + j * 8 * 128);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       MB_GLDS16(xsrc[j] + (t < nka ? 0 : a2) + ta * BK, xb + j * 8 * 128);
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
 
   // ---- epilogue: lane holds out[m][n..n+3], m = ..+(lane&15), n = ..+(lane>>4)*4
   const float sc = a.scale ? *a.scale : 1.0f;
+  float satm = 0.f;                                  // fp16 epilogues: largest |value| this lane stores (GemmArgs.sat)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + (lane & 15);
@@ -126,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
         v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y;
       }
       if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
+        satm = fmaxf(satm, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
         h16x4 o = {to_h(v0), to_h(v1), to_h(v2), to_h(v3)};
         *(h16x4*)(a.out_h16 + orow * a.N + n) = o;
         if (a.out_lo)
@@ -135,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
       }
     }
   }
+  if ((EPI == EPI_H16 || EPI == EPI_GELU_H16) && a.sat && !(satm <= MB_H16_MAX)) atomicAdd(a.sat, 1u);
 }
 
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
@@ -142,7 +155,8 @@ int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
   // Returns 0, or -1 when the request needs the half-tile kernel (8-bit / 4-bit lo pass) and the shape is outside it
   // (the caller reports it; nothing is launched).
   if ((a.A8 || a.A4) && variant < 0) variant = 0;     // the lo pass exists in the half-tile kernel only
-  if (variant >= 0 && gemm_ht_supported(epi, a)) {
+  if (a.W2 && (!a.A2 || !a.kw || a.K != 3 * a.kw || !a.scale || a.ka)) return -1;
+  if (variant >= 0 && !a.W2 && gemm_ht_supported(epi, a)) {
     if (variant % 1000 == 257 && a.M % 257) variant = variant - variant % 1000;
     gemm_ht(s, epi, a, variant);
     return 0;
@@ -266,7 +280,7 @@ __global__ void absmax_kernel(const float* __restrict__ src, size_t n, unsigned*
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
 }
 __global__ void split_kernel(const float* __restrict__ src, h16* __restrict__ dst, int N, int K, const unsigned* __restrict__ amax,
-                             float* __restrict__ scale_out) {
+                             float* __restrict__ scale_out, h16* __restrict__ lo_plane) {
   const float mx = __uint_as_float(*amax);
   int e = 0;
   if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);                   // mx = f * 2^e, f in [0.5, 1)
@@ -277,6 +291,7 @@ __global__ void split_kernel(const float* __restrict__ src, h16* __restrict__ ds
     const size_t r = i / K, k = i - r * K;
     const float w = ldexpf(src[i], S);
     const h16 hi = to_h(w);
+    if (lo_plane) { dst[i] = hi; lo_plane[i] = to_h(w - (float)hi); continue; }   // two [N,K] planes
     dst[r * 2 * K + k] = hi;
     dst[r * 2 * K + K + k] = to_h(w - (float)hi);
   }
@@ -286,7 +301,14 @@ void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K,
   const int blocks = (int)min((size_t)2048, (n + 255) / 256);
   (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
-  hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K, tmp, scale_out);
+  hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K, tmp, scale_out, (h16*)nullptr);
+}
+void split_f32_to_h16_planes(hipStream_t s, const float* src, h16* hi, h16* lo, int N, int K, float* scale_out, unsigned* tmp) {
+  const size_t n = (size_t)N * K;
+  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+  (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
+  hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, hi, N, K, tmp, scale_out, lo);
 }
 void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out) {
   (void)hipMemsetAsync(dst4, 0, 2 * (size_t)N * K, s);

@@ -93,10 +93,20 @@ __device__ long long* g_ht_trace = nullptr;
 #define MB_TRACE(k) do { } while (0)
 #endif
 
-template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass
+// XP = 6 (round 4): MX-fp4 correction passes as MINI-TILES between the fp16 K-tiles (GemmArgs.lo / nlo).  A mini-tile = 128 token rows (pair
+// tiles: the conditional rows; plain tiles: one 128-row half of the sequence) x the tile's 256 weight rows x 128 K-elements = 8 + 16 KiB in a
+// buffer behind the two K-tile parities.  Its DMA is issued in phases 1 / 2 of a fp16 K-tile (one + two instructions per wave, older than the
+// half-tiles the K-tile's own counted wait leaves in flight, so that wait covers it), and it is multiplied in a FIFTH phase after phase 3 of the
+// K-tile that follows its landing: 8 fragment reads, 16 scaled MFMAs per wave, same two-barrier rhythm and wave-group stagger as the other phases.
+// What the old lo K-tiles (XP = 5) paid -- a K-tile skeleton of eight barriers and a one-K-tile DMA lead for a quarter of a tile's arithmetic,
+// 1.9-2.6 us each -- shrinks to the fifth phase itself; the staging hides under the fp16 K-tiles, whose L2 -> LDS path has the slack.
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass, 6 = MX-fp4 mini-tiles
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   static_assert(!PAIR || (SEQ && XP != 4), "pair tiles are sequence-aligned (fp16 or fp4 lo pass)");
+  constexpr bool MINI = XP == 6;
+  static_assert(!MINI || SEQ, "mini-tile passes are written for sequence-aligned tiles");
+  constexpr int MINI_A = 128 * 64, MINI_B = 256 * 64;   // bytes: 128 token rows / 256 weight rows x 128 e2m1 values
   // Every fp16 / fp4 instance walks the tile list persistently (round 1 kept the fp32+residual epilogue at one tile per workgroup: it spilled
   // VGPRs inside the K loop then; with the present epilogue it does not: 244-248 VGPRs, no scratch).
   constexpr bool PERSIST = XP != 4;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
@@ -106,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   constexpr int AH_BYTES = AH_ROWS * 128, BH_BYTES = 128 * 128;
   constexpr int X_BYTES = SEQ ? 1024 : 0;
   constexpr int PAR_BYTES = 2 * AH_BYTES + 2 * BH_BYTES + X_BYTES;
+  constexpr int MINI_OFF = 2 * PAR_BYTES;
   constexpr int TILE_ROWS = SEQ ? 257 : BM;
   constexpr int A_INSTR = AH_ROWS / 8;                 // 1 KiB DMA instructions per A half-tile (12 or 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     int m0, n0;
     int cls;                                 // PAIR: the conditional class-token row of this tile's sequence pair; odd tiles store it
     int q;                                   // PAIR: which 128-token half of the sequence this tile covers
+    int seq;                                 // SEQ: the (conditional) sequence of this tile
   };
   int dstA[2], dstB[2];                       // byte offset of the instruction inside its half-tile buffer
 #pragma unroll
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
     p.m0 = PAIR ? (tm >> 1) * 257 + (tm & 1) * 128 : tm * TILE_ROWS; p.n0 = tn * 256;
     p.cls = PAIR ? (tm >> 1) * 257 + 256 : 0; p.q = tm & 1;
+    p.seq = PAIR ? tm >> 1 : tm;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ja = min(wave + 8 * j, A_INSTR - 1);   // surplus slot re-loads the last chunk (uniform vmcnt)
@@ -217,13 +230,48 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       MB_GLDS16_AUX((t < nkw ? a.W : Wlo) + u + o + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
     }
   };
+  // ---- mini-tiles (XP = 6).  nmk per operand set / row half; mini j: set or half ps = j / nmk, K-elements [128 jj, 128 jj + 128), jj = j % nmk.
+  // One DMA instruction covers 16 rows x 64 B (lane -> row lane >> 2, 16-byte chunk lane & 3, swizzled with (row >> 2) & 3 = (lane >> 4) & 3 so
+  // that the 16 lane rows of a fragment read hit 16 distinct bank groups); the per-lane part of the address is the same for both operands.
+  const int nmk = K / 128;
+  const int nseq = PAIR ? a.pair_rows / 257 : a.M / 257;
+  const bool mini_every = MINI && (!PAIR || a.nlo == 2);       // one mini-tile per fp16 K-tile (else one per two)
+  auto mini_lane = [&]() -> uint32_t {
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
+    return (uint32_t)((lo_ >> 2) * 2 * K + (((lo_ & 3) ^ ((lo_ >> 4) & 3)) * 16));
+  };
+  auto mini_dma_a = [&](const Plan& p, int j) {          // 1 instruction per wave
+    const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
+    const uint8_t* base = a.lo[PAIR ? ps : 0].A4;
+    const uint32_t row0 = PAIR ? p.m0 + wave * 16 : p.m0 + (wave >> 2) * 128 + ps * 64 + (wave & 3) * 16;
+    MB_GLDS16_AUX(base + (size_t)row0 * 2 * K + jj * 64 + mini_lane(), smem + MINI_OFF + wave * 1024, AUX);
+  };
+  auto mini_dma_b = [&](const Plan& p, int j) {          // 2 instructions per wave
+    const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
+    const uint8_t* base = a.lo[PAIR ? ps : 0].W4;
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx)
+      MB_GLDS16_AUX(base + (size_t)(p.n0 + (wave + 8 * jx) * 16) * 2 * K + jj * 64 + mini_lane(), smem + MINI_OFF + MINI_A + (wave + 8 * jx) * 1024, AUX);
+  };
+  // the token operand's scale dword of this lane for mini j: its four m-tiles' bytes of block 2 jj + (lane >= 32) (GemmArgs.lo: lane order)
+  auto mini_scale_off = [&](const Plan& p, int j) -> uint32_t {
+    const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
+    const int gq = PAIR ? p.q * 2 + wm : wm * 2 + ps;
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
+    return ((uint32_t)(2 * jj + (lo_ >> 5)) * nseq + p.seq) * 256 + gq * 64 + (lo_ & 15) * 4;
+  };
+  int mwsc0 = 0, mwsc1 = 0, mxs = 0;                    // MINI: weight scale dwords of the (two) operand sets, the current mini's token scale dword
+  auto mini_scale_issue = [&](const Plan& p, int j) {    // inline asm: counted by the K loop's own vmcnt wait, which the register is tied through
+    const uint8_t* base = a.lo[PAIR ? (j >= nmk ? 1 : 0) : 0].a_scale;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(mxs) : "v"(mini_scale_off(p, j)), "s"(base) : "memory");
+  };
   // all of K-tiles 0 and 1 of a tile (both LDS parities must be free)
   // (nk >= 2 is a precondition of this kernel: gemm_ht_supported)
   auto prologue_rest = [&](const Plan& p) {            // 16 instructions per wave
     dma_a(p, 0, 0); dma_b(p, 0, 0); dma_b(p, 0, 1); dma_a(p, 0, 1);
     dma_a(p, 1, 0); dma_b(p, 1, 1); dma_a(p, 1, 1); dma_b(p, 1, 0);
   };
-  auto prologue = [&](const Plan& p) { dma_x(p, 0); dma_x(p, 1); prologue_rest(p); };
+  auto prologue = [&](const Plan& p) { dma_x(p, 0); dma_x(p, 1); prologue_rest(p); if constexpr (MINI) { mini_dma_a(p, 0); mini_dma_b(p, 0); } };
 
   // ---- fragment read offsets inside a half-tile (rows 128 B, slot swizzled with (row>>1)&7)
   int foff[2], xoffe[2];
@@ -285,6 +333,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();
 #define MB_MMA(AH, BH) MB_MMA_DO(AH, BH) MB_MMA_END
+  // one mini-tile: 4 m-tiles of accumulator half AH x 4 n-tiles, one scaled MFMA of K = 128 each; op_sel picks the n-tile's / m-tile's scale byte
+#define MB_MINI_ONE(AH, N, I)                                                                       \
+  acc[N][(AH) * MH + (I)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                        \
+      __builtin_shufflevector(mwb[N], mwb[N], 0, 1, 2, 3, -1, -1, -1, -1), __builtin_shufflevector(mxa[I], mxa[I], 0, 1, 2, 3, -1, -1, -1, -1), \
+      acc[N][(AH) * MH + (I)], 4, 4, N, mws, I, mxs);
+#define MB_MINI_MMA(AH)                                                                             \
+  MB_MINI_ONE(AH, 0, 0) MB_MINI_ONE(AH, 1, 0) MB_MINI_ONE(AH, 2, 0) MB_MINI_ONE(AH, 3, 0)           \
+  MB_MINI_ONE(AH, 0, 1) MB_MINI_ONE(AH, 1, 1) MB_MINI_ONE(AH, 2, 1) MB_MINI_ONE(AH, 3, 1)           \
+  MB_MINI_ONE(AH, 0, 2) MB_MINI_ONE(AH, 1, 2) MB_MINI_ONE(AH, 2, 2) MB_MINI_ONE(AH, 3, 2)           \
+  MB_MINI_ONE(AH, 0, 3) MB_MINI_ONE(AH, 1, 3) MB_MINI_ONE(AH, 2, 3) MB_MINI_ONE(AH, 3, 3)           \
+  _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 4; ++n)      \
+    asm volatile("" : "+v"(acc[n][(AH) * MH + i]));
 #define MB_MMA_DO(AH, BH)                                                                           \
   {                                                                                                 \
     if (F4 && f8t) {                                                                                \
@@ -311,6 +371,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   auto scales_load = [&](const Plan& p) {             // plain loads; scales_pack() after a vmcnt(0) that the loaded registers are tied through
     int lo_ = lane; asm volatile("" : "+v"(lo_));
     const int r15 = lo_ & 15;
+    if constexpr (MINI) {
+      mwsc0 = ((const int*)a.lo[0].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
+      if (PAIR && a.nlo > 1) mwsc1 = ((const int*)a.lo[1].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
+      mxs = *(const int*)(a.lo[0].a_scale + mini_scale_off(p, 0));
+      return;
+    }
     wsc = ((const int*)a.w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
     if (BS) {
       const uint32_t nb = (uint32_t)(a.kw >> 6);
@@ -339,15 +405,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     for (int i = 0; i < 5; ++i) asm volatile("global_load_dword %0, %1, %2" : "=v"(xs_nxt[i]) : "v"(bs_off[i]), "s"(base) : "memory");
   };
   auto scales_pack = [&]() {
+    if constexpr (MINI && PAIR) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwsc0), "+v"(mwsc1), "+v"(mxs) :: "memory"); asm volatile("" : "+v"(mwsc0), "+v"(mwsc1)); return; }
+    if constexpr (MINI) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwsc0), "+v"(mxs) :: "memory"); asm volatile("" : "+v"(mwsc0)); return; }
     if (BS) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc) :: "memory"); asm volatile("" : "+v"(wsc)); return; }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc), "+v"(xscc), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]) :: "memory");
     xsc0 = sb[0] | (sb[1] << 8) | (sb[2] << 16) | (sb[3] << 24);
     xsc1 = sb[4] | (sb[5] << 8) | (sb[6] << 16) | (sb[7] << 24);
     asm volatile("" : "+v"(wsc), "+v"(xsc0), "+v"(xsc1), "+v"(xscc));   // held in VGPRs of their own through the K loops (cf. sc_ab)
   };
-  if constexpr (F4) scales_load(cur);
+  if constexpr (F4 || MINI) scales_load(cur);
   prologue(cur);
-  if constexpr (F4) scales_pack();
+  if constexpr (F4 || MINI) scales_pack();
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // K-tiles 0 and 1 of the first tile are in LDS for everyone
 
@@ -365,7 +433,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     h16x16 xa[MH], wb[2][2];      // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
     if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
-#define MB_KTILE(F8T)                                                                                  \
+#define MB_KTILE(F8T) MB_KTILE_(F8T, 0)
+#define MB_KTILE_(F8T, MAH)         /* MAH: plain tiles with mini-tiles: the accumulator half this K loop's mini-tiles update (compile time) */ \
     {                                                                                                    \
       const char* par = smem + (t & 1) * PAR_BYTES; \
       constexpr bool f8t = LO && (F8T);                 /* this K-tile holds e4m3 / fp4 operands */ \
@@ -407,6 +476,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       MB_LOAD_B(1) \
       if (SEQ && wm == 1 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       /* PAIR: the difference rows (A1) take no part in the lo pass (their scale byte is 0): lo K-tiles neither stage nor multiply them */ \
+      /* MINI: the next mini-tile's scale dword and A part go out first (older than everything the phase-3 wait leaves in flight) */ \
+      const bool mini_issue = MINI && t >= 1 && (mini_every || !(t & 1)); \
+      const int mini_j = mini_every ? t : (t >> 1); \
+      if (MINI && mini_issue) { mini_scale_issue(cur, mini_j); mini_dma_a(cur, mini_j); } \
       if (n1 && !(PAIR && LO && t + 1 >= nka)) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
       if (SEQ && wm == 1 && cls_on) { \
@@ -421,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       MB_MMA(0, 1) \
       /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
       if (!(PAIR && f8t)) { MB_LOAD_A(1) } \
+      if (MINI && mini_issue) mini_dma_b(cur, mini_j); \
       if (n2) dma_a(cur, t + 2, 0); \
       MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 1) } MB_MMA_END \
       /* ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed. */ \
@@ -435,22 +509,55 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(7)\n\ts_branch 3f\n" \
                        "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(6)\n3:" \
                        : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) : [w] "s"(wsel) : "memory", "scc"); \
+        } else if (MINI) {                               /* the mini-tile's scale dword (requested in phase 1) is older than those: tied through, */ \
+          /* ONE asm statement for the three cases (see the block-scale wait above) */ \
+          const int wsel = __builtin_amdgcn_readfirstlane(n2 ? (wave == 7 ? 2 : 1) : 0); \
+          asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(7)\n\ts_branch 3f\n" \
+                       "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(6)\n3:" \
+                       : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
         } else if (n2) {                                 /* A0, B1, (X,) B0 of K-tile t+2 may stay in flight */ \
           if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
       } \
       MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 0) } MB_MMA_END \
+      /* ---- phase 4 (MINI): the mini-tile that landed under this (or the previous) K-tile's wait x the accumulators of its 128 token rows */ \
+      if constexpr (MINI) { \
+        if (mini_every || (t & 1)) { \
+          const int mj = mini_every ? t : (t >> 1); \
+          const int mps = __builtin_amdgcn_readfirstlane(mj >= nmk ? 1 : 0); \
+          int lo_ = lane; \
+          asm volatile("" : "+v"(lo_)); \
+          const int mfo = (lo_ & 15) * 64 + (((lo_ >> 4) ^ ((lo_ >> 2) & 3)) * 16); \
+          const char* mbuf = smem + MINI_OFF; \
+          i32x4 mxa[4], mwb[4]; \
+          _Pragma("unroll") for (int n = 0; n < 4; ++n) mwb[n] = *(const i32x4*)(mbuf + MINI_A + (wn * 64 + n * 16) * 64 + mfo); \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) mxa[i] = *(const i32x4*)(mbuf + (wm * 64 + i * 16) * 64 + mfo); \
+          const int mws = (PAIR && mps) ? mwsc1 : mwsc0; \
+          MB_SYNC_L() \
+          MB_MINI_MMA(MAH) \
+          /* (v_mfma_scale results must not be read by a VALU copy too early, see the class-row blocks above) */ \
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
+          MB_MMA_END \
+        } \
+        if constexpr (PAIR) asm volatile("" :: "v"(mwsc0), "v"(mwsc1)); else asm volatile("" :: "v"(mwsc0)); \
+      } \
       if (F8) asm volatile("" :: "v"(sc_ab)); \
       if (F4 && !BS) asm volatile("" :: "v"(wsc), "v"(xsc0), "v"(xsc1), "v"(xscc)); \
       if (BS) asm volatile("" :: "v"(wsc)); \
     }
     {
       int t = 0;
-      for (; t < (LO ? nka : nk); ++t) MB_KTILE(false)
-      if (LO) for (; t < nk; ++t) MB_KTILE(true)
+      if constexpr (MINI && !PAIR) {        // plain tiles: mini-tile t belongs to K-tile t; the first K / 128 update rows 0..127 of the tile, the others rows 128..255
+        for (; t < nk / 2; ++t) MB_KTILE_(false, 0)
+        for (; t < nk; ++t) MB_KTILE_(false, 1)
+      } else {
+        for (; t < (LO ? nka : nk); ++t) MB_KTILE(false)
+        if (LO) for (; t < nk; ++t) MB_KTILE(true)
+      }
     }
 #undef MB_KTILE
+#undef MB_KTILE_
     if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the two groups
     MB_TRACE(1);
 
@@ -482,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     Plan nxt;
     if (has_next) { make_plan(nvb, nxt); dma_x(nxt, 0); dma_x(nxt, 1); }
     f32x4 bias4[4], bcls[2];           // bcls: class-token row (indexing bias4 by wave id would put the array in scratch)
-    if constexpr (LO) {
+    if constexpr (LO || MINI) {
       // The e4m3 kernels run at the 256-VGPR limit, where the allocator may move registers around: an asm load whose result it does
       // not track could be copied while still in flight.  Plain loads here (the compiler waits for them; the overlap with the next
       // tile's prologue DMA is given up in this mode).
@@ -490,10 +597,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       for (int nt = 0; nt < 4; ++nt) bias4[nt] = *(const f32x4*)(a.bias + col_of(0, nt));
       if (SEQ) { bcls[0] = *(const f32x4*)(a.bias + col_of(MT, 0)); bcls[1] = *(const f32x4*)(a.bias + col_of(MT, 1)); }
       else { bcls[0] = bias4[0]; bcls[1] = bias4[1]; }
-      if constexpr (F4) { if (has_next) scales_load(nxt); }                  // this tile's K loops are over: the scale registers are free
+      if constexpr (F4 || MINI) { if (has_next) scales_load(nxt); }          // this tile's K loops are over: the scale registers are free
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]), "+v"(bcls[0]), "+v"(bcls[1]) :: "memory");
-      if constexpr (F4) { if (has_next) scales_pack(); }
-      if (has_next) prologue_rest(nxt);
+      if constexpr (F4 || MINI) { if (has_next) scales_pack(); }
+      if (has_next) { prologue_rest(nxt); if constexpr (MINI) { mini_dma_a(nxt, 0); mini_dma_b(nxt, 0); } }
     } else {
 #define MB_LDG16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #pragma unroll
@@ -570,26 +677,35 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     // group's stores now go out under the trailing group's arithmetic instead of after it.
     if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MB_TRACE(3);
-    if constexpr (PAIR && EPI == EPI_GELU_H16) {
+    if constexpr (SEQ && EPI == EPI_GELU_H16) {
       if (a.out4) {
-        // e2m1 copy of the conditional GELU outputs for the next GEMM's weight-correction pass: this wave's 64 columns of a row are one scale block
-        // (4 n-tiles x 4 lane groups x 4 columns); class-token rows are skipped (their scale bytes stay 0)
-        const uint32_t nb = (uint32_t)a.N >> 6, blk = (uint32_t)(n0 >> 6) + wn;
+        // e2m1 copy of the (conditional) GELU outputs for the next GEMM's weight-correction mini-tiles: this wave's 64 columns of a row are one scale
+        // block (4 n-tiles x 4 lane groups x 4 columns), and the four m-tiles of a lane in one 64-row group are one dword of the lane-ordered scale
+        // array (GemmArgs.lo); class-token rows are skipped (they take no part in those passes)
+        const uint32_t blk = (uint32_t)(n0 >> 6) + wn;
+        const uint32_t nsq = PAIR ? (uint32_t)a.pair_rows / 257 : (uint32_t)a.M / 257;
 #pragma unroll
-        for (int i = 0; i < MH; ++i) {
-          float am = 0.f;
+        for (int hh = 0; hh < (PAIR ? 1 : 2); ++hh) {
+          uint32_t sc4 = 0;
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
+          for (int ii = 0; ii < MH; ++ii) {
+            const int i = hh * MH + ii;
+            float am = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(acc[nt][i][e]));
-          am = fmaxf(am, __shfl_xor(am, 16));
-          am = fmaxf(am, __shfl_xor(am, 32));
-          const float mul = fp4_scale_mul_nosat(am);
-          const uint32_t row = (uint32_t)row_of(i);
-          if (ge == 0) a.out4_scale[row * nb + blk] = (uint8_t)fp4_scale_byte_nosat(am);
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            *(uint16_t*)(a.out4 + (size_t)row * 2 * a.N + (col_of(i, nt) >> 1)) = (uint16_t)fp4_pack4(acc[nt][i][0], acc[nt][i][1], acc[nt][i][2], acc[nt][i][3], mul);
+              for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(acc[nt][i][e]));
+            am = fmaxf(am, __shfl_xor(am, 16));
+            am = fmaxf(am, __shfl_xor(am, 32));
+            const float mul = fp4_scale_mul_nosat(am);
+            const uint32_t row = (uint32_t)row_of(i);
+            sc4 |= fp4_scale_byte_nosat(am) << (8 * ii);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              *(uint16_t*)(a.out4 + (size_t)row * 2 * a.N + (col_of(i, nt) >> 1)) = (uint16_t)fp4_pack4(acc[nt][i][0], acc[nt][i][1], acc[nt][i][2], acc[nt][i][3], mul);
+          }
+          const uint32_t gq = PAIR ? (uint32_t)tq * 2 + wm : (uint32_t)wm * 2 + hh;
+          if (ge == 0) ((uint32_t*)a.out4_scale)[((blk * nsq + (uint32_t)cur.seq) * 4 + gq) * 16 + l15e] = sc4;
         }
       }
     }
@@ -603,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       // made every wait for a residual row also wait for the ACKNOWLEDGEMENT of the store two rows back (tools/micro/store_path.hip: 19 us per tile
       // interleaved, 15 / 12 / 9 us with 4 / 8 / 16 loads batched ahead of their stores).  Now: batches of two rows, the next batch's loads issued
       // BEFORE the current batch's stores: 22.8 -> 19.5 us per tile.
-      constexpr int RB = (PAIR && F4) ? 1 : 2;        // rows per batch: 4 float4 per lane -- what fits next to 136 accumulator registers without spilling (2 in the fp4 pair kernel)
+      constexpr int RB = (PAIR && (F4 || MINI)) ? 1 : 2;        // rows per batch: 4 float4 per lane -- what fits next to 136 accumulator registers without spilling (2 in the fp4 pair kernel)
       // (Measured with larger / growing batches -- 4 rows, or 2 + 2 + 4 rows then a whole sweep into the registers the first sweep vacated: 16-42 spilled
       // VGPRs in the pair kernels and no gain in the kernels that did not spill: with every CU in its epilogue at once the pass runs at the chip's
       // ~6.5-6.9 TB/s of mixed read + write traffic, profiles/r03_power_and_streams.md section 6.)
@@ -681,6 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         }
       }
     } else {
+      float satm = 0.f;                                  // fp16 epilogues: largest |value| this lane stores (saturation census, GemmArgs.sat)
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
         const bool ok = row_ok(r);
@@ -690,6 +807,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           for (int pr = 0; pr < nn / 2; ++pr) {
             const f32x4 ca = r < MT ? acc[2 * pr][r < MT ? r : 0] : acce[0];
             const f32x4 cb = r < MT ? acc[2 * pr + 1][r < MT ? r : 0] : acce[1];
+            if (a.sat && ok) satm = fmaxf(fmaxf(satm, fmaxf(fmaxf(fabsf(ca[0]), fabsf(ca[1])), fmaxf(fabsf(ca[2]), fabsf(ca[3])))),
+                                          fmaxf(fmaxf(fabsf(cb[0]), fabsf(cb[1])), fmaxf(fabsf(cb[2]), fabsf(cb[3]))));
             const h16x2 ta0 = {to_h(ca[0]), to_h(ca[1])}, ta1 = {to_h(ca[2]), to_h(ca[3])};
             const h16x2 tb0 = {to_h(cb[0]), to_h(cb[1])}, tb1 = {to_h(cb[2]), to_h(cb[3])};
             // swap: lane rows with odd g of the first operand <-> even g of the second (16-lane rows)
@@ -720,6 +839,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             }
         }
       }
+      if ((EPI == EPI_H16 || EPI == EPI_GELU_H16) && a.sat && !(satm <= MB_H16_MAX)) atomicAdd(a.sat, 1u);   // (NaN counts too)
     }
     if (has_next) __builtin_amdgcn_s_barrier();        // everyone's share of the next tile's K-tiles 0 and 1 has landed (each wave waited above)
     MB_TRACE(4);
@@ -741,6 +861,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #undef MB_MMA_DO
 #undef MB_MMA_END
 #undef MB_F4_ONE
+#undef MB_MINI_ONE
+#undef MB_MINI_MMA
 }
 
 static int g_cu_override = 0;   // mb_set_cu_count: the CUs a persistent grid is sized for (a stream created with a CU mask sees fewer than the device has)
@@ -763,7 +885,7 @@ static int num_cu_cached() {
 template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>
 static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) {
   constexpr int BM = 32 * MT;
-  constexpr int LDS = 2 * (BM * 128 + 2 * 128 * 128 + (SEQ ? 1024 : 0));
+  constexpr int LDS = 2 * (BM * 128 + 2 * 128 * 128 + (SEQ ? 1024 : 0)) + (XP == 6 ? 128 * 64 + 256 * 64 : 0);
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -781,6 +903,10 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
   if (a.pair_rows && (a.pair_rows % 257 || a.M != 2 * a.pair_rows || a.A8 || a.A2 || (a.ka && a.A4) || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
+  if (a.nlo && (a.nlo > 2 || a.M % 257 || a.K % 128 || a.A8 || a.A4 || a.A2 || a.ka || a.kw || a.out_lo || a.out_lo8 || (!a.pair_rows && a.nlo != 1) ||
+                !a.lo[0].A4 || !a.lo[0].W4 || !a.lo[0].a_scale || !a.lo[0].w_scale ||
+                (a.nlo == 2 && (!a.lo[1].A4 || !a.lo[1].W4 || !a.lo[1].a_scale || !a.lo[1].w_scale)) || (uint64_t)a.M * a.K * 2 >= (1ull << 32) ||
+                epi == EPI_GELU_F32)) return false;
   if (a.A4 && (a.A8 || !a.W4 || !a.a_scale || !a.w_scale || a.kw % 256 || a.K != a.kw + a.kw / 4 || epi == EPI_GELU_F32)) return false;
   return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8 || a.A4) &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
@@ -802,6 +928,15 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
       const long tiles = (long)(a.M / 257) * (a.N / 256);
       if ((double)((tiles + num_cu - 1) / num_cu) * 272 < cost(mt)) mt = 257;
     }
+  }
+  if (a.nlo) {                                                             // MX-fp4 mini-tile passes (XP = 6; pair or plain sequence tiles)
+    switch (epi) {
+      case EPI_H16: if (a.pair_rows) launch_ht<8, EPI_H16, 6, true, true>(s, a, persistent); else launch_ht<8, EPI_H16, 6, true>(s, a, persistent); break;
+      case EPI_GELU_H16: if (a.pair_rows) launch_ht<8, EPI_GELU_H16, 6, true, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 6, true>(s, a, persistent); break;
+      case EPI_RES_F32: if (a.pair_rows) launch_ht<8, EPI_RES_F32, 6, true, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 6, true>(s, a, persistent); break;
+      default: break;
+    }
+    return;
   }
   if (a.pair_rows) {                                                       // CFG pair tiles (sequence-aligned; fp16, or fp16 + MX-fp4 lo pass)
     switch (epi) {

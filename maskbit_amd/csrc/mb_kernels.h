@@ -41,6 +41,9 @@ struct GemmArgs {
   // products land in the same fp32 accumulator.  A2 = null / kw = 0: plain GEMM.  Not combined with ka.
   const h16* A2 = nullptr;
   int kw = 0;
+  // ... with W2 != null as well (128x128 kernel only; the two head GEMMs): THREE sweeps of kw columns, K = 3 kw -- (A, W), (A2, W), (A, W2) with
+  // W = fp16(w * 2^S), W2 = fp16(w * 2^S - W) [N, kw] each and *scale = 2^-S: hi + lo inputs against hi + lo weights (the lo x lo term, 2^-22, is dropped)
+  const h16* W2 = nullptr;
   // fp16 epilogues only: also store the lo halves v - fp16(v) of the results ([M,N] like out_h16), so that the consumer GEMM can
   // take this output as a split-activation pair
   h16* out_lo = nullptr;
@@ -72,7 +75,27 @@ struct GemmArgs {
   // the token operand of the next GEMM's weight-correction pass; class-token rows are left untouched (their bytes stay 0: no correction).
   uint8_t* out4 = nullptr;
   uint8_t* out4_scale = nullptr;
+  // MX-fp4 MINI-TILE correction passes (round 4; sequence-aligned half-tile kernel, M % 257 == 0, K % 128 == 0): the corrections no longer run as
+  // K-tiles of their own behind the fp16 sweep -- those were bound by staging at a quarter of a tile's arithmetic -- but as mini-tiles of
+  // 128 token rows x 256 weight rows x 128 K-elements (24 KiB of LDS behind the two K-tile parities), staged while the fp16 K-tiles run and multiplied
+  // in a fifth phase between them (16 v_mfma_scale_f32_16x16x128_f8f6f4 per wave).  nlo = number of operand sets:
+  //   pair tiles : lo[0] (, lo[1]) on the CONDITIONAL rows: K / 128 mini-tiles per set (one per two fp16 K-tiles with one set, one per K-tile with two);
+  //   plain tiles: lo[0] on both 128-row halves of the sequence tile (nlo = 1): 2 K / 128 mini-tiles, one per fp16 K-tile.
+  // Operands: A4 = e2m1 token operand, two values per byte, row stride 2 K bytes (first K / 2 used); W4 = e2m1 weight operand, same stride;
+  // w_scale = the weights' E8M0 bytes in the kernel's lane order (entry ((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)); a_scale = the token
+  // operand's E8M0 bytes per (row, 64 K-elements) in LANE ORDER: a_scale[((blk * nseq + seq) * 4 + grp) * 64 + (r & 15) * 4 + ((r >> 4) & 3)] for
+  // token r = grp * 64 + (r & 63) of sequence seq (nseq = M / 257; pair tiles: conditional sequences, nseq = pair_rows / 257) -- one dword per lane
+  // holds the scales of its four m-tiles (fp4_scale_index).  Class-token rows take no part in these passes.
+  // fp16 epilogues (optional): lanes that clamped a result at +-65504 add 1 to *sat (mb_gen_saturation_count)
+  unsigned* sat = nullptr;
+  struct LoSet { const uint8_t* A4; const uint8_t* a_scale; const uint8_t* W4; const uint8_t* w_scale; };
+  LoSet lo[2] = {};
+  int nlo = 0;
 };
+// byte index of the scale of (token row r of sequence seq, 64-column block blk) in the lane-ordered scale arrays of the mini-tile passes
+__host__ __device__ inline size_t fp4_scale_index(int blk, int nseq, int seq, int r) {
+  return (((size_t)blk * nseq + seq) * 4 + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3);
+}
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   // 0, or -1: lo-pass request outside the half-tile kernel's shapes
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
@@ -86,17 +109,21 @@ void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, u
 // the same layout for the weight's fp16 ROUNDING ERROR: e2m1((W[n] - fp16(W[n])) * 2^r_n), r_n from the row's largest |error| (fp4_scale_mul)
 void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);
 
+// e2m1 copies written by the row-wise producers for the trunk GEMMs' mini-tile passes (GemmArgs.lo): the rows' VALUES (x4, with the
+// lane-ordered per-(row, 64 columns) scale bytes x4s) and / or their fp16 LO HALVES x - fp16(x) (xl4 / xl4s); rows are tokens of nseq sequences of
+// 257 (row stride 2d bytes, first d / 2 used; class-token rows are skipped).  hidden = 768 / 1024 only.
+struct Fp4Rows { uint8_t* x4 = nullptr; uint8_t* x4s = nullptr; uint8_t* xl4 = nullptr; uint8_t* xl4s = nullptr; int nseq = 0; };
+
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
                     float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr, uint8_t* x8 = nullptr,
-                    uint8_t* x4 = nullptr, uint8_t* x4_scale = nullptr, bool x4_values = false);   // x4: e2m1 lo halves -- or, x4_values, the values -- (row stride 2d bytes) + one E8M0 byte per row   // x8: e4m3(lo * 2^15), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
+                    const Fp4Rows& f4 = Fp4Rows{});   // x8: e4m3(lo * 2^12), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
 
 // "CFG pair" forms (hidden = 768 / 1024 only; -1 otherwise): rows r < P are conditional, r + P their unconditional twins.  Writes
-// x_h16[r] = fp16(x_c), x_h16[r + P] = fp16(x_u - x_c), both rows' {mean, rstd}; optional x4 / x4s: e2m1 of the conditional VALUES + their scale
-// bytes in the pair GEMM's block layout x4s[r][d / 64].
+// x_h16[r] = fp16(x_c), x_h16[r + P] = fp16(x_u - x_c), both rows' {mean, rstd}; optional f4: e2m1 copies of the CONDITIONAL rows.
 int layernorm_pair(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps, h16* x_h16, float* stats, int P, int d,
-                   uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
-int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
+                   const Fp4Rows& f4 = Fp4Rows{});
+int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, const Fp4Rows& f4 = Fp4Rows{});
 
 // ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------
 struct EmbedArgs {
@@ -114,25 +141,25 @@ struct EmbedArgs {
   const float* tables = nullptr;
   h16* x_lo = nullptr;     // optional: lo halves of x_h16 (split-activation GEMMs)
   uint8_t* x8 = nullptr;   // optional: e4m3 lo halves, row stride 2d bytes
-  uint8_t* x4 = nullptr;   // optional: e2m1 lo halves (row stride 2d bytes) with one E8M0 scale byte per row in x4_scale
-  uint8_t* x4_scale = nullptr;
-  bool x4_values = false;  // x4 = e2m1 of the values instead of the lo halves
+  Fp4Rows f4;              // optional: e2m1 copies for the mini-tile passes (embed_pair: of the conditional rows)
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
 // guided forward: a.nb = B conditional sequences (tokens [B, seq, m], labels [B]); rows of the label-dropped twins are written B * (seq + 1) rows further
-// down; x_h16 receives the pair operands (fp16(x_c) | fp16(x_u - x_c)), x4 / x4s (optional) the e2m1 conditional values + block scales.  -1: shape not
+// down; x_h16 receives the pair operands (fp16(x_c) | fp16(x_u - x_c)), a.f4 (optional) the e2m1 copies of the conditional rows.  -1: shape not
 // served (embedding tables, widths other than 768 / 1024) -> embed_ln over [cond | twins] + pairify_rows
-int embed_pair(hipStream_t s, const EmbedArgs& a, uint8_t* x4 = nullptr, uint8_t* x4s = nullptr);
+int embed_pair(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
-void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo = nullptr, uint8_t* out_lo8 = nullptr);   // out_lo: optional lo halves (split activations)
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo = nullptr, uint8_t* out_lo8 = nullptr,
+               uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);   // out_lo: optional lo halves (split activations); out4 / out4s (N = 257, head width 64):
+                                                                      // e2m1 of the outputs + lane-ordered scale bytes for the out-proj GEMM's mini-tile pass
 // "CFG pair" attention: sequences [0, P) are conditional, [P, 2P) their unconditional twins.  Two launches: the conditional sequences also
 // store their fp32 output rows to `aux` [P*N, d]; the unconditional ones then write out[r + P*N] = fp16(att_u - att_c) (difference operand of
 // the out-proj pair GEMM).  Short-sequence kernel only (N <= 288): returns -1 otherwise.
 void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width);   // diagnostic: Q/K/V rows -> e4m3 values (per token, head, operand scale), in place; width % 256 == 0
 int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads, uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);
-// (out4 / out4s, head dimension 64 only: e2m1 of the conditional output values, row stride 2d bytes, + E8M0 scale bytes out4s[row][d / 64])
+// (out4 / out4s, head dimension 64 only: e2m1 of the conditional output values, row stride 2d bytes, + lane-ordered E8M0 scale bytes, GemmArgs.lo)
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 
@@ -158,5 +185,7 @@ void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n);
 // W[N,K] fp32 -> dst[N,2K] = [fp16(W*2^S) | fp16(W*2^S - hi)], S chosen from max|W| (tmp: one device uint32 of scratch);
 // *scale_out = 2^-S.  Stream-ordered, no host synchronisation.
 void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K, float* scale_out, unsigned* tmp);
+// the same halves as two planes: hi[N,K] and lo[N,K] (GemmArgs.W / W2)
+void split_f32_to_h16_planes(hipStream_t s, const float* src, h16* hi, h16* lo, int N, int K, float* scale_out, unsigned* tmp);
 
 }  // namespace mb

@@ -11,13 +11,41 @@ constexpr int MAXS = 32;  // scalar fallback path: d <= 64 * MAXS = 2048
 // NV > 0: vector path, d == 256*NV, row lives in NV float4 registers per lane (fully unrolled).
 // NV == 0: generic scalar path for odd widths (tiny test configs).
 
+// e2m1 copy of a row held in registers (lane: columns q * 256 + lane * 4 .. + 3) for the trunk GEMMs' mini-tile passes (GemmArgs.lo): one
+// power-of-two scale per 64 columns -- 16 lanes of one q -- chosen from the block's largest element without saturation (3 < max <= 6), its E8M0
+// byte stored in the lane-ordered scale array.  A massive-activation channel then costs the resolution of its own 64-column block, not of the row.
+template <int NV>
+__device__ __forceinline__ void fp4_row_store(const float4* v, int lane, uint8_t* x4row, uint8_t* scales, int nseq, int seq, int tok) {
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    float am = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if ((lane & 15) == 0) scales[fp4_scale_index(q * 4 + (lane >> 4), nseq, seq, tok)] = (uint8_t)fp4_scale_byte_nosat(am);
+    *(uint16_t*)(x4row + q * 128 + lane * 2) = (uint16_t)fp4_pack4(v[q].x, v[q].y, v[q].z, v[q].w, fp4_scale_mul_nosat(am));
+  }
+}
+// values (f4.x4) and / or fp16 lo halves (f4.xl4) of row `row` (token row % 257 of sequence row / 257; class-token rows take no part)
+template <int NV>
+__device__ __forceinline__ void fp4_rows_out(const Fp4Rows& f4, float4* v, int lane, int row, int d) {
+  const int seq = row / 257, tok = row - seq * 257;
+  if (tok == 256) return;
+  if (f4.x4) fp4_row_store<NV>(v, lane, f4.x4 + (size_t)row * 2 * d, f4.x4s, f4.nseq, seq, tok);
+  if (f4.xl4) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      v[q] = make_float4(v[q].x - (float)to_h(v[q].x), v[q].y - (float)to_h(v[q].y), v[q].z - (float)to_h(v[q].z), v[q].w - (float)to_h(v[q].w));
+    fp4_row_store<NV>(v, lane, f4.xl4 + (size_t)row * 2 * d, f4.xl4s, f4.nseq, seq, tok);
+  }
+}
+
 // Two-pass mean / variance of a row held in registers, then affine + store.
 template <int NV>
 __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                           float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr, uint8_t* x8 = nullptr,
-                                          uint8_t* x4 = nullptr, uint8_t* x4s = nullptr, bool x4_values = false) {
-  // x4: e2m1 of the row's lo halves (act_split 4), or with x4_values of the VALUES themselves (operand of the weight-rounding correction pass)
+                                          const Fp4Rows* f4 = nullptr, int row = 0) {
+  // f4 (optional): e2m1 copies of the row for the mini-tile passes (vector path only)
   // xl (optional): the fp16 lo halves o - fp16(o) of the same row, for the split-activation GEMMs
   constexpr bool VEC = NV > 0;
   constexpr int nv = NV;
@@ -40,7 +68,6 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
   if (st && lane == 0) *(float2*)st = make_float2(mean, rstd);       // for the GEMM epilogue that re-derives these rows
-  float maxlo = 0.f;                                                  // x4: largest |lo| of the row -> its shared power-of-two scale
   if (VEC) {
 #pragma unroll
     for (int q = 0; q < nv; ++q) {
@@ -54,18 +81,9 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
       if (xb) *(h16x4*)(xb + c) = hi;
       if (xl) *(h16x4*)(xl + c) = h16x4{to_h(o.x - (float)hi[0]), to_h(o.y - (float)hi[1]), to_h(o.z - (float)hi[2]), to_h(o.w - (float)hi[3])};
       if (x8) *(uint32_t*)(x8 + c) = lo8_pack4h(o.x, o.y, o.z, o.w, hi);
-      if (x4) {                                                       // keep the lo halves in the row's registers for the second sweep
-        v[q] = x4_values ? o : make_float4(o.x - (float)hi[0], o.y - (float)hi[1], o.z - (float)hi[2], o.w - (float)hi[3]);
-        maxlo = fmaxf(maxlo, fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w))));
-      }
+      if (f4) v[q] = o;                                               // keep the normalised row for the e2m1 copies
     }
-    if (x4) {
-      maxlo = wave_max(maxlo);
-      const float mul = x4_values ? fp4_scale_mul_nosat(maxlo) : fp4_scale_mul(maxlo);
-      if (lane == 0) *x4s = (uint8_t)(x4_values ? fp4_scale_byte_nosat(maxlo) : fp4_scale_byte(maxlo));
-#pragma unroll
-      for (int q = 0; q < nv; ++q) *(uint16_t*)(x4 + q * 128 + lane * 2) = (uint16_t)fp4_pack4(v[q].x, v[q].y, v[q].z, v[q].w, mul);
-    }
+    if constexpr (VEC) { if (f4) fp4_rows_out<NV>(*f4, v, lane, row, d); }
   } else {
     for (int q = 0; q < ns; ++q) {
       const int c = lane + q * 64;
@@ -83,7 +101,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* x_f32,
-                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s, bool x4v) {
+                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, Fp4Rows f4) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -99,14 +117,14 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
                  x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr,
                  x_lo ? x_lo + (size_t)row * d : nullptr, x8 ? x8 + (size_t)row * 2 * d : nullptr,
-                 x4 ? x4 + (size_t)row * 2 * d : nullptr, x4s ? x4s + row : nullptr, x4v);
+                 (f4.x4 || f4.xl4) ? &f4 : nullptr, row);
 }
 
 // ---- "CFG pair" LayerNorm (differential classifier-free guidance, DESIGN.md "Precision"): one wave normalises row r of the conditional
 // stream and its unconditional twin r + P together and writes  x_h16[r] = fp16(x_c),  x_h16[r + P] = fp16(x_u - x_c)  -- the operands of
 // the pair GEMM (gemm_ht.hip): the rounding error of x_c is then common to both streams and cancels in (c - u).  Row statistics of both rows
-// go to `stats` (the residual GEMMs re-derive LayerNorm(y) from them).  x4 / x4s (optional, weight-correction pass): e2m1(x_c * 2^s) of the
-// conditional row and its E8M0 scale byte in the pair GEMM's block layout x4s[row][d / 64] (the difference rows take no part in that pass).
+// go to `stats` (the residual GEMMs re-derive LayerNorm(y) from them).  f4 (optional, mini-tile passes): e2m1 of the conditional row's values
+// and / or lo halves with per-64-column scales (fp4_rows_out; the difference rows take no part in those passes).
 template <int NV>
 __device__ __forceinline__ float2 ln_normalize(float4* v, int d, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int lane) {
   float s = 0.f;
@@ -132,28 +150,19 @@ __device__ __forceinline__ float2 ln_normalize(float4* v, int d, const float* __
 
 // store the pair operands of one row pair held in registers (xc, xu = the two fp32 rows)
 template <int NV>
-__device__ __forceinline__ void pair_store(const float4* xc, const float4* xu, int lane, h16* oc, h16* ou, uint8_t* x4, uint8_t* x4s_c, uint8_t* x4s_u) {
-  float amax = 0.f;
+__device__ __forceinline__ void pair_store(float4* xc, const float4* xu, int lane, h16* oc, h16* ou, const Fp4Rows& f4, int row, int d) {
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c = q * 256 + lane * 4;
     *(h16x4*)(oc + c) = h16x4{to_h(xc[q].x), to_h(xc[q].y), to_h(xc[q].z), to_h(xc[q].w)};
     *(h16x4*)(ou + c) = h16x4{to_h(xu[q].x - xc[q].x), to_h(xu[q].y - xc[q].y), to_h(xu[q].z - xc[q].z), to_h(xu[q].w - xc[q].w)};
-    if (x4) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(xc[q].x), fabsf(xc[q].y)), fmaxf(fabsf(xc[q].z), fabsf(xc[q].w))));
   }
-  if (x4) {
-    amax = wave_max(amax);
-    const float mul = fp4_scale_mul_nosat(amax);
-    // block-scale layout of the pair GEMM (a_scale[row][d / 64]): one scale for the whole row, replicated into its d / 64 = 4 * NV block bytes
-    if (lane < NV) ((uint32_t*)x4s_c)[lane] = fp4_scale_byte_nosat(amax) * 0x01010101u;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) *(uint16_t*)(x4 + q * 128 + lane * 2) = (uint16_t)fp4_pack4(xc[q].x, xc[q].y, xc[q].z, xc[q].w, mul);
-  }
+  if (f4.x4 || f4.xl4) fp4_rows_out<NV>(f4, xc, lane, row, d);      // (last use of xc: the lo halves overwrite it)
 }
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                      h16* __restrict__ x_h16, float* __restrict__ stats, int P, int d, uint8_t* x4, uint8_t* x4s) {
+                                                      h16* __restrict__ x_h16, float* __restrict__ stats, int P, int d, Fp4Rows f4) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= P) return;
@@ -162,45 +171,43 @@ __global__ __launch_bounds__(256) void ln_pair_kernel(const float* __restrict__ 
   for (int q = 0; q < NV; ++q) { vc[q] = *(const float4*)(y + (size_t)row * d + q * 256 + lane * 4); vu[q] = *(const float4*)(y + (size_t)(row + P) * d + q * 256 + lane * 4); }
   const float2 sc = ln_normalize<NV>(vc, d, gamma, beta, eps, lane), su = ln_normalize<NV>(vu, d, gamma, beta, eps, lane);
   if (stats && lane == 0) { *(float2*)(stats + 2 * (size_t)row) = sc; *(float2*)(stats + 2 * (size_t)(row + P)) = su; }
-  pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
-                 x4s ? x4s + (size_t)row * (d / 64) : nullptr, nullptr);
+  pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, f4, row, d);
 }
 
 // pair operands from fp32 rows that already exist (the embedding LayerNorm's output, the first residual): x32 [2P, d] -> x_h16 as above
 template <int NV>
-__global__ __launch_bounds__(256) void pairify_kernel(const float* __restrict__ x32, h16* __restrict__ x_h16, int P, int d, uint8_t* x4, uint8_t* x4s) {
+__global__ __launch_bounds__(256) void pairify_kernel(const float* __restrict__ x32, h16* __restrict__ x_h16, int P, int d, Fp4Rows f4) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= P) return;
   float4 vc[NV], vu[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) { vc[q] = *(const float4*)(x32 + (size_t)row * d + q * 256 + lane * 4); vu[q] = *(const float4*)(x32 + (size_t)(row + P) * d + q * 256 + lane * 4); }
-  pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
-                 x4s ? x4s + (size_t)row * (d / 64) : nullptr, nullptr);
+  pair_store<NV>(vc, vu, lane, x_h16 + (size_t)row * d, x_h16 + (size_t)(row + P) * d, f4, row, d);
 }
 
 int layernorm_pair(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps, h16* x_h16, float* stats, int P, int d,
-                   uint8_t* x4, uint8_t* x4s) {
+                   const Fp4Rows& f4) {
   dim3 grid((P + 3) / 4), block(256);
-  if (d == 1024) hipLaunchKernelGGL(ln_pair_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_h16, stats, P, d, x4, x4s);
-  else if (d == 768) hipLaunchKernelGGL(ln_pair_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_h16, stats, P, d, x4, x4s);
+  if (d == 1024) hipLaunchKernelGGL(ln_pair_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_h16, stats, P, d, f4);
+  else if (d == 768) hipLaunchKernelGGL(ln_pair_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_h16, stats, P, d, f4);
   else return -1;
   return 0;
 }
-int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, uint8_t* x4, uint8_t* x4s) {
+int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, const Fp4Rows& f4) {
   dim3 grid((P + 3) / 4), block(256);
-  if (d == 1024) hipLaunchKernelGGL(pairify_kernel<4>, grid, block, 0, s, x32, x_h16, P, d, x4, x4s);
-  else if (d == 768) hipLaunchKernelGGL(pairify_kernel<3>, grid, block, 0, s, x32, x_h16, P, d, x4, x4s);
+  if (d == 1024) hipLaunchKernelGGL(pairify_kernel<4>, grid, block, 0, s, x32, x_h16, P, d, f4);
+  else if (d == 768) hipLaunchKernelGGL(pairify_kernel<3>, grid, block, 0, s, x32, x_h16, P, d, f4);
   else return -1;
   return 0;
 }
 
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, uint8_t* x4, uint8_t* x4s, bool x4v) {
-  dim3 grid((M + 3) / 4), block(256);      // x4 (e2m1 lo halves / values): vector path only (d = 768 / 1024; mb_gen_create restricts the modes to those)
-  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s, x4v);
-  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, x4, x4s, x4v);
-  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, nullptr, nullptr, false);
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, const Fp4Rows& f4) {
+  dim3 grid((M + 3) / 4), block(256);      // f4 (e2m1 values / lo halves): vector path only (d = 768 / 1024; mb_gen_create restricts the modes to those)
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, f4);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, f4);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, Fp4Rows{});
 }
 
 // One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
   }
   ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d, nullptr,
                  a.x_lo ? a.x_lo + (size_t)row * d : nullptr, a.x8 ? a.x8 + (size_t)row * 2 * d : nullptr,
-                 a.x4 ? a.x4 + (size_t)row * 2 * d : nullptr, a.x4_scale ? a.x4_scale + row : nullptr, a.x4_values);
+                 (a.f4.x4 || a.f4.xl4) ? &a.f4 : nullptr, row);
 }
 
 // The same for the guided (CFG pair) forward: sequences [0, nb) conditional, their label-dropped twins nb sequences further down.  A twin has the
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
 // class-token row differs (class_emb[nclass] instead of class_emb[label]).  Writes what embed_ln over [cond | twins] + pairify_rows wrote, bit for
 // bit: x_f32 (both rows), x_h16 = fp16(x_c) | fp16(x_u - x_c), and optionally the e2m1 values + block scales of the conditional rows.
 template <int NV>
-__global__ __launch_bounds__(256) void embed_pair_kernel(EmbedArgs a, uint8_t* x4, uint8_t* x4s) {
+__global__ __launch_bounds__(256) void embed_pair_kernel(EmbedArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int N = a.seq + 1, P = a.nb * N;
@@ -349,16 +356,15 @@ __global__ __launch_bounds__(256) void embed_pair_kernel(EmbedArgs a, uint8_t* x
     *(float4*)(a.x_f32 + (size_t)row * d + c) = vc[q];
     *(float4*)(a.x_f32 + (size_t)(row + P) * d + c) = vu[q];
   }
-  pair_store<NV>(vc, vu, lane, a.x_h16 + (size_t)row * d, a.x_h16 + (size_t)(row + P) * d, x4 ? x4 + (size_t)row * 2 * d : nullptr,
-                 x4s ? x4s + (size_t)row * (d / 64) : nullptr, nullptr);
+  pair_store<NV>(vc, vu, lane, a.x_h16 + (size_t)row * d, a.x_h16 + (size_t)(row + P) * d, a.f4, row, d);
 }
 
-int embed_pair(hipStream_t s, const EmbedArgs& a, uint8_t* x4, uint8_t* x4s) {
+int embed_pair(hipStream_t s, const EmbedArgs& a) {
   if (a.tables || a.m * a.gbits > MAXBITS) return -1;     // (the embedding-table Bert takes the two-kernel path)
   const int rows = a.nb * (a.seq + 1);
   dim3 grid((rows + 3) / 4), block(256);
-  if (a.d == 1024) hipLaunchKernelGGL(embed_pair_kernel<4>, grid, block, 0, s, a, x4, x4s);
-  else if (a.d == 768) hipLaunchKernelGGL(embed_pair_kernel<3>, grid, block, 0, s, a, x4, x4s);
+  if (a.d == 1024) hipLaunchKernelGGL(embed_pair_kernel<4>, grid, block, 0, s, a);
+  else if (a.d == 768) hipLaunchKernelGGL(embed_pair_kernel<3>, grid, block, 0, s, a);
   else return -1;
   return 0;
 }

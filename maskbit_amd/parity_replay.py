@@ -30,6 +30,9 @@ RUN_C3_S2 = "sample_full12_64_s2"        # configs[2] again: other generator wei
 RUN_C3_S3 = "sample_full12_64_s3"        # ... and a third time at twice the batch (168 568 sampled positions)
 RUN_CFG1_S2 = "sample_full10_16_nocfg_s2"   # second runs of configs[1] and configs[4] (other weights, head gain, noise, labels)
 RUN_CFG5_S2 = "sample_full14_256_s2"
+RUN_CFG5_S3 = "sample_full14_256_s3"     # round 4: configs[4] a third time at twice the batch (334 248 positions)
+RUN_C3_OUTLIER = "sample_full12_64_outlier"          # configs[2] / configs[1] on "trained-like" weights (synth._trained_like: heavy tails,
+RUN_CFG1_OUTLIER = "sample_full10_16_nocfg_outlier"  # massive-activation channels)
 
 
 def load_run(name: str = "sample_full12_64") -> Dict[str, object]:
@@ -83,7 +86,8 @@ def build_models(device, with_tokenizer: bool = True, name: str = "sample_full12
     from maskbit_amd import ConvVQModel, LFQBert, synth
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     bits = int(z["bits"]) if "bits" in z.files else 12
-    gsd = synth.make_generator_weights(synth.GenCfg(bits=bits, splits=2), seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]))
+    style = str(z["gen_style"]) if "gen_style" in z.files else "gaussian"
+    gsd = synth.make_generator_weights(synth.GenCfg(bits=bits, splits=2), seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]), style=style)
     sha = lambda t: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
     assert sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]) == str(z["w_sha_in_proj0"]), "synthetic generator weights changed"
     gen = LFQBert(img_size=256, hidden_dim=1024, codebook_size=2 ** bits, codebook_splits=2, depth=24, heads=16, mlp_dim=4096, dropout=0.1,

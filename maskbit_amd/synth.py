@@ -61,11 +61,11 @@ def _index_to_bits(idx: Tensor, nbits: int) -> Tensor:
 
 
 # --------------------------------------------------------------------------- seeded synthetic weights
-def make_generator_weights(cfg: GenCfg, seed: int = 0, head_gain: float = 1.0) -> StateDict:
+def make_generator_weights(cfg: GenCfg, seed: int = 0, head_gain: float = 1.0, style: str = "gaussian") -> StateDict:
     """Build-own seeded weights with the reference checkpoint's key names and shapes
     (SURVEY.md 8b).  randn*0.02 for Linear / Embedding / pos_emb, LN gamma=1 beta=0;
     ``head_gain`` scales prediction_layer.weight so the softmax is peaky enough to
-    make logit errors visible in the sampled tokens."""
+    make logit errors visible in the sampled tokens.  ``style`` "outlier": see _trained_like."""
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g) * 0.02
     d, f = cfg.hidden, cfg.mlp
@@ -100,7 +100,46 @@ def make_generator_weights(cfg: GenCfg, seed: int = 0, head_gain: float = 1.0) -
         sd["prediction_layer.bias"] = rn(cfg.splits * cfg.group_codes)
     if cfg.prenorm:                   # drawn last: the streams of the post-norm configurations are unchanged
         sd["norm_after_transformer.weight"] = torch.ones(d) + rn(d); sd["norm_after_transformer.bias"] = rn(d)
+    if style != "gaussian":
+        _trained_like(sd, cfg, seed, style)
     return sd
+
+
+OUTLIER_CHANNELS = 6       # "trained-like" style: hidden channels that carry massive, nearly input-independent LayerNorm outputs
+OUTLIER_BETA = 12.0        # ... of this magnitude (LayerNorm beta = +-OUTLIER_BETA, gamma x OUTLIER_GAMMA there): ~16x the rms of a normal channel
+OUTLIER_GAMMA = 0.1
+OUTLIER_CONSUMER = 0.0625  # the consumers' columns of those channels (an outlier channel then contributes about a normal channel's share of an output)
+
+
+def _trained_like(sd: StateDict, cfg: GenCfg, seed: int, style: str) -> None:
+    """Post-transform of the Gaussian draw towards the statistics trained transformers show and Gaussian weights do not (what per-row / per-block
+    MX-fp4 scales and fp16 activations are sensitive to):  style "outlier" = (1) heavy-tailed Linear weights -- every 2-D trunk / head weight is
+    multiplied elementwise by sqrt(nu / chi2_nu) with nu = 6 (a Student-t_6 draw) and by 1 / sqrt(var t_6): the Gaussian draw's standard deviation;
+    (2) OUTLIER_CHANNELS hidden channels carry massive LayerNorm outputs, the same channels in every layer ("massive activations"): beta =
+    +-OUTLIER_BETA and gamma x OUTLIER_GAMMA in first_layer.0 and both norms of every layer -- in a post-norm trunk the residual stream then holds
+    +-12 in those channels next to ~0.75 rms in the others, a stable fixed point at which the logits still depend on tokens and class as much as
+    the Gaussian draw's do (a large gamma instead runs away -- the next LayerNorm divides everything else by the outliers' magnitude -- and from
+    +-15 on the random trunk stops passing information) -- and the matching in_proj / net.0 / last_layer.0 columns x OUTLIER_CONSUMER.  Deterministic
+    from the seed (a generator of its own, so the Gaussian draw and every existing fixture stay what they were)."""
+    if style != "outlier":
+        raise ValueError(f"unknown weight style '{style}'")
+    g = torch.Generator().manual_seed(1_000_003 * (seed + 1))
+    d = cfg.hidden
+    for k in sorted(sd):
+        v = sd[k]
+        if v.dim() == 2 and (k.startswith("transformer.layers.") or k.startswith("last_layer.0") or k.startswith("prediction_layer")):
+            e = sum(torch.empty(v.shape).exponential_(1.0, generator=g) for _ in range(3))    # chi2_6 / 2
+            sd[k] = v * torch.sqrt(3.0 / e) * (1.0 / math.sqrt(1.5))      # var(t_6) = 6 / 4; elementwise only: bit-reproducible on any host
+    ch = torch.randperm(d, generator=g)[:OUTLIER_CHANNELS]
+    sign = torch.where(torch.rand(OUTLIER_CHANNELS, generator=g) < 0.5, -1.0, 1.0)
+    norms = ["first_layer.0"] + [f"transformer.layers.{l}.{s}.norm" for l in range(cfg.depth) for s in (0, 1)]
+    for n in norms:
+        sd[n + ".weight"][ch] *= OUTLIER_GAMMA
+        sd[n + ".bias"][ch] = OUTLIER_BETA * sign
+    for l in range(cfg.depth):
+        sd[f"transformer.layers.{l}.0.mha.in_proj_weight"][:, ch] *= OUTLIER_CONSUMER
+        sd[f"transformer.layers.{l}.1.net.0.weight"][:, ch] *= OUTLIER_CONSUMER
+    sd["last_layer.0.weight"][:, ch] *= OUTLIER_CONSUMER       # the last layer's second norm feeds the head
 
 
 def decoder_plan(cfg: TokCfg) -> List[Tuple[str, int, int, bool]]:

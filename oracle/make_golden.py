@@ -119,6 +119,12 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     "sample_full12_64_s3": (12, 180, 12.0, 8, FULL64, False, 4324, 0),
     "sample_full10_16_nocfg_s2": (10, 178, 16.0, 16, CFG1_16, False, 4322, 0),
     "sample_full14_256_s2": (14, 179, 16.0, 2, CFG5_256, False, 4323, 4),
+    # round 4: a third 14-bit / 256-step run at twice the batch (334 248 positions: as many as the first two together), and a 12-bit run on
+    # "trained-like" weights (heavy-tailed, six massive-activation channels: maskbit_amd/synth.py _trained_like) -- what per-row / per-block MX-fp4
+    # scales and fp16 activations are sensitive to and Gaussian draws do not show
+    "sample_full14_256_s3": (14, 181, 12.0, 4, CFG5_256, False, 4325, 8),
+    "sample_full12_64_outlier": (12, 190, 12.0, 4, FULL64, False, 4326, 2, "outlier"),
+    "sample_full10_16_nocfg_outlier": (10, 191, 12.0, 16, CFG1_16, False, 4327, 0, "outlier"),
 }
 
 
@@ -133,9 +139,10 @@ def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
         seed, lab0 = RUNS[name][6:8]
     else:
         lab0 = 0
+    style = RUNS[name][8] if len(RUNS[name]) > 8 else "gaussian"
     gcfg = O.GenCfg(bits=bits, splits=2)
     C_ = gcfg.group_codes
-    gsd = O.make_generator_weights(gcfg, seed=gseed, head_gain=gain)
+    gsd = O.make_generator_weights(gcfg, seed=gseed, head_gain=gain, style=style)
     gen = build_ref_gen(LFQBert, gcfg, gsd)
     tcfg = O.TokCfg(token_size=bits)
     tsd = O.make_tokenizer_weights(tcfg, seed=200)
@@ -158,7 +165,7 @@ def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
     masks = torch.stack(seen) == C_                     # [S, B, 256, 2] positions masked when step i ran
     assert masks[0].all() and steps.max() < C_
     assert torch.equal(torch.where(masks[1:], torch.full_like(steps[:-1], C_), steps[:-1]), torch.stack(seen)[1:])
-    out = dict(seed=seed, gen_seed=gseed, head_gain=gain, tok_seed=200, bits=bits, labels=labels.numpy(), steps=steps.numpy().astype(np.int16),
+    out = dict(seed=seed, gen_seed=gseed, head_gain=gain, gen_style=style, tok_seed=200, bits=bits, labels=labels.numpy(), steps=steps.numpy().astype(np.int16),
                masks=np.packbits(masks.numpy().reshape(S, -1), axis=1), w_sha_in_proj0=sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]),
                w_sha_conv_in=sha(tsd["decoder.conv_in.weight"]), kw_keys=np.array(list(kw.keys())), kw_vals=np.array([str(v) for v in kw.values()]))
     if decode:

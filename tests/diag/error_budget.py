@@ -1,0 +1,213 @@
+"""CPU emulation of the engine's rounding points on the REFERENCE's own full-size runs: which rounding is left in the sampled-logit error?
+
+For a subset of the steps of a recorded run (tests/golden/sample_full*.npz, teacher-forced like maskbit_amd/parity_replay.py) the forward is evaluated in
+fp32 on the CPU with each of the engine's rounding points switchable:
+
+  x     LayerNorm outputs feeding QKV / FFN-up          att   attention outputs feeding out-proj        h    GELU outputs feeding FFN-down
+  qkv   the packed q / k / v rows the attention reads    p     the probabilities of the PV product
+  wt    trunk GEMM weights                               wh    the two head GEMMs' weights
+
+each "f16" (rounded to fp16), "exact", and for the guided forward in the engine's DIFFERENTIAL form (the unconditional stream's operand is
+fp16(x_c) + fp16(x_u - x_c)) or as two independent streams.  qkv additionally "diff" (q_u stored as fp16(q_c) + fp16(q_u - q_c)).  wt "corr4": fp16
+weights + the engine's MX-fp4 correction (e2m1 of the operand values, block scales per `blk` columns, against e2m1 of W - fp16(W), one scale per weight
+row) on the conditional rows.  Reported per case: rms of the centred error of the SAMPLED logits c + s (c - u) over the masked positions, and the token
+mismatch against the reference's recorded predictions with the reference's noise.
+
+usage: python tests/diag/error_budget.py <run name> [every-nth step] [case filter substring ...]
+"""
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from maskbit_amd import parity_replay as R, synth          # noqa: E402
+from oracle import maskbit_oracle as O                       # noqa: E402
+
+h16 = lambda t: t.to(torch.float16).to(torch.float32)
+E2M1 = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def q_e2m1(v, blk):
+    """e2m1 with one power-of-two scale per `blk` consecutive columns (0 = per row), scaled so that 3 < max <= 6 (mb_common.h fp4_nosat_exp)."""
+    shp = v.shape
+    w = v.reshape(-1, shp[-1]) if blk == 0 else v.reshape(-1, blk)
+    am = w.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    e = torch.floor(torch.log2(am))
+    mant = am / torch.exp2(e)
+    e = e + (mant > 1.5).float()                     # amax * 2^-(e-2) in (3, 6]
+    sc = torch.exp2(e - 2)
+    a = (w / sc).abs().clamp(max=6.0)
+    idx = torch.bucketize(a, (E2M1[1:] + E2M1[:-1]) / 2)        # nearest grid point (ties: up; the hardware rounds to even -- immaterial here)
+    return (torch.sign(w) * E2M1[idx] * sc).reshape(shp)
+
+
+class Emu:
+    def __init__(self, sd, cfg, o):
+        self.sd, self.cfg, self.o = sd, cfg, o
+        self.w16 = {k: h16(v) for k, v in sd.items() if v.dim() == 2}
+        self.wlo4 = {}
+
+    def rnd(self, key, t):
+        return h16(t) if self.o[key] == "f16" else t
+
+    def weight(self, name, head=False):
+        m = self.o["wh" if head else "wt"]
+        return self.sd[name] if m == "exact" else self.w16[name]
+
+    def lin(self, name, bias, xc, xu, key, head=False):
+        """One Linear over the conditional rows xc and (guided) the unconditional rows xu -> (out_c, out_u)."""
+        W = self.weight(name, head)
+        b = self.sd[bias]
+        corr = (not head) and self.o["wt"] == "corr4"
+        if head:
+            ac = xc
+        else:
+            ac = self.rnd(key, xc)
+        oc = F.linear(ac, W)
+        if corr:
+            if name not in self.wlo4:
+                self.wlo4[name] = q_e2m1(self.sd[name] - self.w16[name], 0)
+            blk = self.o.get("blk", 64)
+            oc = oc + F.linear(q_e2m1(xc, blk), self.wlo4[name])
+        if xu is None:
+            return oc + b, None
+        if head:
+            return oc + b, F.linear(xu, W) + b
+        if self.o["pair"]:
+            ad = self.rnd(key, xu - xc)
+            return oc + b, oc + F.linear(ad, W) + b
+        ou = F.linear(self.rnd(key, xu), W)
+        if corr:
+            ou = ou + F.linear(q_e2m1(xu, self.o.get("blk", 64)), self.wlo4[name])
+        return oc + b, ou + b
+
+    def attention(self, qkv):
+        cfg = self.cfg
+        b = qkv.shape[0]
+        d, H = cfg.hidden, cfg.heads
+        dh = d // H
+        qq, kk, vv = [t.reshape(b, -1, H, dh).transpose(1, 2) for t in qkv.split(d, -1)]
+        s = (qq @ kk.transpose(-1, -2)) * (1 / math.sqrt(dh))
+        p = torch.exp(s - s.amax(-1, keepdim=True))
+        den = p.sum(-1, keepdim=True)
+        return ((self.rnd("p", p) @ vv) / den).transpose(1, 2).reshape(b, -1, d)
+
+    def forward(self, tokens, labels, guided):
+        sd, cfg = self.sd, self.cfg
+        B = tokens.shape[0]
+        x_tok = F.linear(O.token_bit_vectors(tokens, cfg), sd["input_proj.weight"], sd["input_proj.bias"])
+
+        def embed(lab):
+            x = torch.cat([x_tok, sd["class_emb.weight"][lab].unsqueeze(1)], 1) + sd["pos_emb"]
+            return O._ln(x, sd, "first_layer.0", 1e-12)
+        xc = embed(labels)
+        xu = embed(torch.full_like(labels, cfg.nclass)) if guided else None
+        for l in range(cfg.depth):
+            a, f = f"transformer.layers.{l}.0", f"transformer.layers.{l}.1"
+            qc, qu = self.lin(a + ".mha.in_proj_weight", a + ".mha.in_proj_bias", xc, xu, "x")
+            if self.o["qkv"] == "diff" and guided:
+                qcr = h16(qc)
+                qur = qcr + h16(qu - qc)
+            else:
+                qcr, qur = self.rnd("qkv", qc), (self.rnd("qkv", qu) if guided else None)
+            ac = self.attention(qcr)
+            au = self.attention(qur) if guided else None
+            oc, ou = self.lin(a + ".mha.out_proj.weight", a + ".mha.out_proj.bias", ac, au, "att")
+            xc = O._ln(oc + xc, sd, a + ".norm", 1e-12)
+            if guided:
+                xu = O._ln(ou + xu, sd, a + ".norm", 1e-12)
+            uc, uu = self.lin(f + ".net.0.weight", f + ".net.0.bias", xc, xu, "x")
+            hc = F.gelu(uc)
+            hu = F.gelu(uu) if guided else None
+            dc, du = self.lin(f + ".net.2.weight", f + ".net.2.bias", hc, hu, "h")
+            xc = O._ln(dc + xc, sd, f + ".norm", 1e-12)
+            if guided:
+                xu = O._ln(du + xu, sd, f + ".norm", 1e-12)
+        yc, yu = self.lin("last_layer.0.weight", "last_layer.0.bias", xc, xu, "x", head=True)
+        yc = O._ln(F.gelu(yc), sd, "last_layer.2", 1e-12)
+        yu = O._ln(F.gelu(yu), sd, "last_layer.2", 1e-12) if guided else None
+        lc, lu = self.lin("prediction_layer.weight", "prediction_layer.bias", yc, yu, "x", head=True)
+        shp = (B, cfg.seq + 1, cfg.splits, cfg.group_codes)
+        lc = lc.reshape(shp)[:, :cfg.seq]
+        lu = lu.reshape(shp)[:, :cfg.seq] if guided else None
+        return lc, lu
+
+
+EXACT = dict(x="exact", att="exact", h="exact", qkv="exact", p="exact", wt="exact", wh="exact", pair=True)
+F16 = dict(x="f16", att="f16", h="f16", qkv="f16", p="f16", wt="f16", wh="f16", pair=True)
+
+
+def cases(guided):
+    c = [("single fp16, independent streams", {**F16, "pair": False}),
+         ("differential form, fp16 weights (cfg_pair 1)", dict(F16)),
+         ("+ exact trunk weights (ideal cfg_pair 2)", {**F16, "wt": "exact"}),
+         ("+ fp4 correction, 64-column block scales", {**F16, "wt": "corr4", "blk": 64}),
+         ("+ fp4 correction, one scale per row", {**F16, "wt": "corr4", "blk": 0}),
+         ("exact trunk weights + exact head weights", {**F16, "wt": "exact", "wh": "exact"}),
+         ("exact weights, exact x", {**F16, "wt": "exact", "wh": "exact", "x": "exact"}),
+         ("exact weights, exact att", {**F16, "wt": "exact", "wh": "exact", "att": "exact"}),
+         ("exact weights, exact h", {**F16, "wt": "exact", "wh": "exact", "h": "exact"}),
+         ("exact weights, exact qkv", {**F16, "wt": "exact", "wh": "exact", "qkv": "exact"}),
+         ("exact weights, differential qkv", {**F16, "wt": "exact", "wh": "exact", "qkv": "diff"}),
+         ("exact weights, exact p", {**F16, "wt": "exact", "wh": "exact", "p": "exact"}),
+         ("exact weights, exact x att h", {**F16, "wt": "exact", "wh": "exact", "x": "exact", "att": "exact", "h": "exact"}),
+         ("exact weights, exact qkv p", {**F16, "wt": "exact", "wh": "exact", "qkv": "exact", "p": "exact"}),
+         ("only fp16 weights (trunk + head), rest exact", {**EXACT, "wt": "f16", "wh": "f16"}),
+         ("only fp16 head weights, rest exact", {**EXACT, "wh": "f16"})]
+    if not guided:
+        c = [(n, o) for n, o in c if "differential" not in n and "independent" not in n] + [("single fp16", dict(F16))]
+    return c
+
+
+def main():
+    torch.set_num_threads(int(os.environ.get("THREADS", "8")))
+    name = sys.argv[1] if len(sys.argv) > 1 else R.RUN_CFG5
+    every = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    filt = sys.argv[3:]
+    g = R.load_run(name)
+    z = g["z"]
+    cfg = synth.GenCfg(bits=g["bits"], splits=2)
+    style = str(z["gen_style"]) if "gen_style" in z.files else "gaussian"
+    sd = synth.make_generator_weights(cfg, seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]), style=style)
+    q, c = R.reference_noise(g, "cpu")
+    scale, temp, mask_len = R.plan_of(g)
+    S, B = g["steps"].shape[0], g["steps"].shape[1]
+    guided_run = float(g["kw"]["guidance_scale"]) != 0.0
+    steps = list(range(every // 2, S, every))
+    C_ = g["C"]
+    y = g["labels"]
+    print(f"{name}: {S} steps, B = {B}, C = {C_}, steps used {steps}, scales {[round(scale[i], 2) for i in steps]}", flush=True)
+    ref = {}
+    exact = Emu(sd, cfg, EXACT)
+    for i in steps:
+        guided = guided_run and scale[i] != 0.0
+        lc, lu = exact.forward(R.tokens_in(g, i), y, guided)
+        ref[i] = lc + scale[i] * (lc - lu) if guided else lc
+    for cname, o in cases(guided_run):
+        if filt and not any(f in cname for f in filt):
+            continue
+        t0 = time.time()
+        emu = Emu(sd, cfg, o)
+        se = n = bad = tot = 0
+        gap_err = 0.0
+        for i in steps:
+            tin = R.tokens_in(g, i)
+            guided = guided_run and scale[i] != 0.0
+            lc, lu = emu.forward(tin, y, guided)
+            L = lc + scale[i] * (lc - lu) if guided else lc
+            msk = g["masks"][i]
+            e = (L - ref[i])[msk]
+            ec = e - e.mean(-1, keepdim=True)
+            se += float(ec.pow(2).sum()); n += ec.numel()
+            pred, _ = O.sample_step(lc, lu, scale[i], temp[i], q[i], c[i], tin, C_, torch.tensor(1.0), 512)
+            bad += int((pred != g["steps"][i])[msk].sum()); tot += int(msk.sum())
+        print(f"{cname:52s}: rms centred error of the sampled logits {math.sqrt(se / n):.5f}   mismatch {bad}/{tot} = {bad / tot:.2e}   [{time.time() - t0:.0f} s]", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -35,3 +35,77 @@ def token_mismatch(a: torch.Tensor, b: torch.Tensor, where=None) -> float:
     if where is not None:
         return float(ne[where].float().mean()) if bool(where.any()) else 0.0
     return float(ne.float().mean())
+
+
+def gemm_mini(lib, epi, A, W, bias, res, out32, out16, rows, pair, N, K, lo_sets=(), out4=None, out4s=None):
+    """mb_gemm_mini (include/maskbit_hip_diag.h): a sequence-aligned (pair) GEMM with len(lo_sets) MX-fp4 mini-tile passes; a set = (A4, a_scale, W4,
+    w_scale) tensors."""
+    import ctypes as C
+    from maskbit_amd import _lib
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    flat = [t.data_ptr() for s in lo_sets for t in s]
+    arr = (C.c_void_p * max(1, len(flat)))(*flat)
+    _lib.check(lib.mb_gemm_mini(epi, ptr(A), ptr(W), ptr(bias), ptr(res), ptr(out32), ptr(out16), ptr(out4), ptr(out4s), rows, int(pair), N, K,
+                                len(lo_sets), arr, torch.cuda.current_stream().cuda_stream), "mb_gemm_mini")
+
+
+_F4V = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0], dtype=torch.float64)
+
+
+def f4_decode(buf: torch.Tensor, K: int) -> torch.Tensor:
+    """uint8 [R, >= K/2] (element 2j = low nibble of byte j) -> float64 [R, K] of e2m1 values (on the CPU)."""
+    b = buf[:, : K // 2].cpu().to(torch.int64)
+    codes = torch.stack([b & 15, b >> 4], dim=-1).reshape(b.shape[0], K)
+    return _F4V[codes]
+
+
+def f4_codes(v: torch.Tensor) -> torch.Tensor:
+    """float64 scaled values -> e2m1 codes 0..15 the way mb_common.h fp4_code rounds (nearest, ties to even on the local grid, saturate at 6)."""
+    a = v.abs().clamp(max=6.0)
+    k = torch.floor(torch.log2(a.clamp(min=1.0))).clamp(0, 2)
+    r = torch.round(a / 2.0 ** (k - 1))
+    return (r + 2 * k).to(torch.int64) | ((v < 0).to(torch.int64) << 3)
+
+
+def f4_block_exponent(amax: torch.Tensor) -> torch.Tensor:
+    """Biased exponent E of a block with largest element amax such that amax * 2^(129 - E) lies in (3, 6] (mb_common.h fp4_nosat_exp)."""
+    m, e = torch.frexp(amax)                                       # amax = m * 2^e, m in [0.5, 1)
+    return (e + 126) + (m > 0.75).to(torch.int32)
+
+
+def f4_scale_index(blk, nseq, seq, r):
+    """mb_kernels.h fp4_scale_index: byte index of (64-column block blk, token r of sequence seq) in a lane-ordered scale array."""
+    return ((blk * nseq + seq) * 4 + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3)
+
+
+def f4_encode_rows(v: torch.Tensor, nseq: int, dev="cuda"):
+    """What the engine's producers write for rows of values v [nseq * 257, K] (float64, CPU or GPU): (x4 uint8 [R, 2K] with garbage in the class-token
+    rows and the padding, lane-ordered scale bytes, the decoded float64 operand [R, K] with zeros in the class-token rows)."""
+    v = v.double().cpu()
+    R, K = v.shape
+    assert R == nseq * 257 and K % 64 == 0
+    blocks = v.reshape(R, K // 64, 64)
+    amax = blocks.abs().amax(-1)
+    E = f4_block_exponent(amax.clamp(min=1e-30))
+    sbyte = (E - 2).clamp(min=0)
+    codes = f4_codes(blocks * (2.0 ** (129 - E).double()).unsqueeze(-1)).reshape(R, K)
+    x4 = torch.randint(0, 256, (R, 2 * K), dtype=torch.uint8)
+    x4[:, : K // 2] = (codes[:, 0::2] | (codes[:, 1::2] << 4)).to(torch.uint8)
+    dec = (_F4V[codes].reshape(R, K // 64, 64) * (2.0 ** (sbyte.double() - 127)).unsqueeze(-1)).reshape(R, K)
+    scales = torch.randint(0, 256, ((K // 64) * nseq * 256 + 256,), dtype=torch.uint8)
+    rows = torch.arange(R)
+    seq, tok = rows // 257, rows % 257
+    keep = tok < 256
+    for b in range(K // 64):
+        idx = f4_scale_index(b, nseq, seq[keep], tok[keep])
+        scales[idx] = sbyte[keep, b].to(torch.uint8)
+    dec[~keep] = 0.0
+    x4[~keep] = torch.randint(0, 256, (int((~keep).sum()), 2 * K), dtype=torch.uint8)      # class-token rows: garbage, must not matter
+    return x4.to(dev), scales.to(dev), dec.to(dev)
+
+
+def w4_decode(w4: torch.Tensor, wsb: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """e2m1 weight operand + its lane-ordered per-row scale bytes (mb_w4_from_f32 / mb_w4lo_from_f32) -> float64 [N, K] on the device of w4."""
+    n = torch.arange(N, device=wsb.device)
+    row = wsb[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)].to(torch.float64)
+    return f4_decode(w4, K).to(w4.device) * (2.0 ** (row - 127)).reshape(N, 1)

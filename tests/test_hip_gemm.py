@@ -285,150 +285,11 @@ def test_f8_lo_pass_gemm(variant, epi, M, N, K):
         assert float((got - asked).abs().max()) < 2e-3 * max(1.0, float(asked.abs().max()))
 
 
-# ---- MX-fp4 lo pass (mb_gen_cfg.act_split == 4) ------------------------------------------------------------------------------------
-_F4 = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0], dtype=torch.float64)
-
-
-def _f4_decode(buf: torch.Tensor, K: int) -> torch.Tensor:
-    """uint8 [R, >= K/2] (element 2j = low nibble of byte j) -> float64 [R, K] of e2m1 values."""
-    b = buf[:, : K // 2].cpu().to(torch.int64)
-    codes = torch.stack([b & 15, b >> 4], dim=-1).reshape(b.shape[0], K)
-    return _F4[codes]
-
-
-def _f4_codes(v: torch.Tensor) -> torch.Tensor:
-    """float64 scaled values -> e2m1 codes 0..15 the way mb_common.h fp4_code rounds (nearest, ties to even on the local grid, saturate at 6)."""
-    a = v.abs().clamp(max=6.0)
-    k = torch.floor(torch.log2(a.clamp(min=1.0))).clamp(0, 2)
-    r = torch.round(a / 2.0 ** (k - 1))
-    return (r + 2 * k).to(torch.int64) | ((v < 0).to(torch.int64) << 3)
-
-
-@pytest.mark.parametrize("variant", [8, 257, 0])
-@pytest.mark.parametrize("epi,M,N,K", [(2, 1028, 512, 1024), (0, 771, 256, 256), (1, 1028, 1024, 1024), (2, 257, 256, 768)])
-def test_f4_lo_pass_gemm(variant, epi, M, N, K):
-    """The MX-fp4 lo pass: K/64 fp16 K-tiles of (x_hi, W), then K/256 K-tiles of 256 e2m1 values per row of (e2m1(x_lo * 2^s_m), e2m1(W * 2^r_n))
-    on v_mfma_scale_f32_16x16x128_f8f6f4 (cbsz = blgp = 4) whose per-lane E8M0 scales undo 2^s_m and 2^r_n.  The operands come from the engine's
-    own producers (mb_layernorm_f4, mb_w4_from_f32), which are checked first: LayerNorm bytes / scale bytes exactly against the rule of
-    mb_common.h, weight codes as a valid quantisation of fp16(W) within half a grid step.  The GEMM is checked (a) against the exact value of
-    what it is asked to compute (decoded 4-bit operands, fp64) and (b) against the fp32 rows: far closer than the hi halves alone."""
-    from maskbit_amd import _lib
-    lib = _lib.load()
-    if variant == 257 and M % 257:
-        pytest.skip("sequence-aligned tiles need M % 257 == 0")
-    torch.manual_seed(epi * 17 + (variant & 7))
-    st = torch.cuda.current_stream().cuda_stream
-    d = K
-    if d not in (768, 1024):                             # the fp4 LayerNorm output exists for the engine's widths; build the operands by hand otherwise
-        x32 = torch.randn(M, K, device=DEV) * 1.5
-        xh = x32.half()
-        lo = (x32 - xh.float()).double()
-        maxlo = lo.abs().amax(1, keepdim=True)
-        e = torch.floor(torch.log2(maxlo)).to(torch.int64) + 127
-        sbyte = (e - 2).clamp(min=0).to(torch.uint8).reshape(M)
-        codes = _f4_codes(lo * 2.0 ** (129 - e).double())
-        x4 = torch.zeros(M, 2 * K, device=DEV, dtype=torch.uint8)
-        x4[:, : K // 2] = (codes[:, 0::2] | (codes[:, 1::2] << 4)).to(torch.uint8)
-    else:
-        y = torch.randn(M, K, device=DEV) * 3.0
-        gam = torch.rand(K, device=DEV) + 0.5
-        bet = torch.randn(K, device=DEV) * 0.2
-        x32 = torch.empty(M, K, device=DEV)
-        xh = torch.empty(M, K, device=DEV, dtype=torch.float16)
-        x4 = torch.zeros(M, 2 * K, device=DEV, dtype=torch.uint8)
-        sbyte = torch.zeros(M, device=DEV, dtype=torch.uint8)
-        _lib.check(lib.mb_layernorm_f4(y.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-12, x32.data_ptr(), xh.data_ptr(), x4.data_ptr(), sbyte.data_ptr(), M, K, st))
-        torch.cuda.synchronize()
-        assert torch.equal(xh, x32.half())
-        lo = (x32 - xh.float()).double()
-        maxlo = lo.abs().amax(1, keepdim=True)
-        e = torch.floor(torch.log2(maxlo)).to(torch.int64) + 127
-        assert torch.equal(sbyte.to(torch.int64), (e - 2).reshape(M))
-        codes = _f4_codes(lo * 2.0 ** (129 - e).double())
-        want = (codes[:, 0::2] | (codes[:, 1::2] << 4)).to(torch.uint8)
-        assert torch.equal(x4[:, : K // 2], want), f"{int((x4[:, : K // 2] != want).sum())} LayerNorm fp4 bytes differ"
-    W32 = torch.randn(N, K, device=DEV) * 0.05 * (0.5 + torch.rand(N, 1, device=DEV) * 2)      # rows of different scale
-    W = W32.half()
-    w4 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8)
-    wsb = torch.zeros(N, device=DEV, dtype=torch.uint8)
-    _lib.check(lib.mb_w4_from_f32(W32.data_ptr(), N, K, w4.data_ptr(), wsb.data_ptr(), st))
-    torch.cuda.synchronize()
-    n = torch.arange(N, device=DEV)
-    wscale_row = wsb[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)].to(torch.float64)        # un-permute the lane order
-    w_dec = _f4_decode(w4, K).to(DEV) * (2.0 ** (wscale_row - 127)).reshape(N, 1)
-    rel = float(((w_dec - W.double()) ** 2).sum() / (W.double() ** 2).sum())
-    assert rel < 0.03, f"fp4 weight copy: relative squared error {rel:.3f}"
-    lo_dec = _f4_decode(x4, K).to(DEV) * (2.0 ** (sbyte.to(torch.float64) - 127)).reshape(M, 1)
-    rel_lo = float(((lo_dec - lo) ** 2).sum() / (lo ** 2).sum())
-    assert rel_lo < 0.05, f"fp4 lo halves: residual variance ratio {rel_lo:.3f}"
-    bias = torch.randn(N, device=DEV) * 0.1
-    res = torch.randn(M, N, device=DEV) if epi == 2 else None
-    out32 = torch.full((M, N), float("nan"), device=DEV) if epi == 2 else None
-    out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16) if epi != 2 else None
-    _lib.check(lib.mb_gemm_f4lo(epi, xh.data_ptr(), x4.data_ptr(), sbyte.data_ptr(), W.data_ptr(), w4.data_ptr(), wsb.data_ptr(), bias.data_ptr(),
-                                res.data_ptr() if res is not None else None, out32.data_ptr() if out32 is not None else None,
-                                out16.data_ptr() if out16 is not None else None, M, N, K, variant, st))
-    torch.cuda.synchronize()
-    asked = xh.double() @ W.double().t() + lo_dec @ w_dec.t() + bias.double()
-    true = x32.double() @ W.double().t() + bias.double()
-    if epi == 1:
-        asked, true = torch.nn.functional.gelu(asked), torch.nn.functional.gelu(true)
-    if res is not None:
-        asked, true = asked + res.double(), true + res.double()
-    got = (out32 if out32 is not None else out16).double()
-    assert torch.isfinite(got).all()
-    if epi == 2:
-        hi_only = (xh.double() @ W.double().t() + bias.double() + res.double())
-        e_asked, e_true, e_hi = float((got - asked).abs().max()), float((got - true).abs().max()), float((hi_only - true).abs().max())
-        rms_true, rms_hi = float((got - true).pow(2).mean().sqrt()), float((hi_only - true).pow(2).mean().sqrt())
-        print(f"max err vs the asked value {e_asked:.2e}, vs the fp32 rows {e_true:.2e} (rms {rms_true:.2e}); hi halves alone: max {e_hi:.2e}, rms {rms_hi:.2e}")
-        assert e_asked < 3e-5 and rms_true < rms_hi / 4
-    else:
-        assert float((got - asked).abs().max()) < 2e-3 * max(1.0, float(asked.abs().max()))
-
-
-@pytest.mark.parametrize("M,N,K", [(1028, 512, 1024), (771, 1024, 1024)])
-def test_f4_weight_correction_pass(M, N, K):
-    """The weight-correction use of the MX-fp4 pass (mb_gen_cfg.cfg_pair == 2): A4 = e2m1 of the activation VALUES, W4 = e2m1 of the weight's fp16
-    rounding error (mb_w4lo_from_f32).  x.W16^T + x4.Wlo4^T must be several times closer to x.W32^T than x.W16^T alone."""
-    from maskbit_amd import _lib
-    lib = _lib.load()
-    torch.manual_seed(M)
-    st = torch.cuda.current_stream().cuda_stream
-    x = (torch.randn(M, K, device=DEV) * 1.2).half()
-    W32 = torch.randn(N, K, device=DEV) * 0.02
-    W = W32.half()
-    xv = x.double()
-    amax = xv.abs().amax(1, keepdim=True)
-    e = torch.floor(torch.log2(amax)).to(torch.int64) + 127
-    sbyte = (e - 2).clamp(min=0).to(torch.uint8).reshape(M)
-    codes = _f4_codes(xv * 2.0 ** (129 - e).double())
-    x4 = torch.zeros(M, 2 * K, device=DEV, dtype=torch.uint8)
-    x4[:, : K // 2] = (codes[:, 0::2] | (codes[:, 1::2] << 4)).to(torch.uint8)
-    w4 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8)
-    wsb = torch.zeros(N, device=DEV, dtype=torch.uint8)
-    _lib.check(lib.mb_w4lo_from_f32(W32.data_ptr(), N, K, w4.data_ptr(), wsb.data_ptr(), st))
-    torch.cuda.synchronize()
-    n = torch.arange(N, device=DEV)
-    wscale_row = wsb[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)].to(torch.float64)
-    wlo_dec = _f4_decode(w4, K).to(DEV) * (2.0 ** (wscale_row - 127)).reshape(N, 1)
-    wlo = (W32.double() - W.double())
-    rel = float(((wlo_dec - wlo) ** 2).sum() / (wlo ** 2).sum())
-    assert rel < 0.05, f"fp4 copy of the weight rounding error: residual variance ratio {rel:.3f}"
-    bias = torch.zeros(N, device=DEV)
-    res = torch.zeros(M, N, device=DEV)
-    out = torch.full((M, N), float("nan"), device=DEV)
-    _lib.check(lib.mb_gemm_f4lo(2, x.data_ptr(), x4.data_ptr(), sbyte.data_ptr(), W.data_ptr(), w4.data_ptr(), wsb.data_ptr(), bias.data_ptr(),
-                                res.data_ptr(), out.data_ptr(), None, M, N, K, 0, st))
-    torch.cuda.synchronize()
-    true = xv @ W32.double().t()
-    plain = xv @ W.double().t()
-    e_corr, e_plain = float((out.double() - true).pow(2).mean().sqrt()), float((plain - true).pow(2).mean().sqrt())
-    print(f"rms error vs fp32 weights: fp16 weights {e_plain:.3e}, with the fp4 correction pass {e_corr:.3e}")
-    assert e_corr < e_plain / 3
+# (the MX-fp4 mini-tile passes: tests/test_hip_mini.py)
 
 
 def test_persistent_grids_sized_for_fewer_cus_give_the_same_bits():
+    from hip_helpers import gemm_mini
     """mb_set_cu_count (persistent grids on a CU-masked stream): 128 workgroups walk the tile list instead of 256 -- same tiles, same bits."""
     from maskbit_amd import _lib
     lib = _lib.load()
@@ -444,7 +305,7 @@ def test_persistent_grids_sized_for_fewer_cus_give_the_same_bits():
         for n in (0, 128, 8):
             assert lib.mb_set_cu_count(n) == 0
             o = torch.empty(M, N, device=DEV, dtype=torch.float16)
-            _lib.check(lib.mb_gemm_pair(0, A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, None, o.data_ptr(), P, N, K, None, None, None, None, st))
+            gemm_mini(lib, 0, A, W, bias, None, None, o, P, True, N, K)
             torch.cuda.synchronize()
             outs.append(o)
     finally:
