@@ -109,6 +109,9 @@ def self_launch(args) -> int:
     127.0.0.1) and pass their output through; rank 0 prints the JSON line."""
     import socket
     import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and "MB_BENCH_FORCE_DEVICE" not in os.environ:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (torch.cuda.device_count()); nothing was launched")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -219,6 +222,8 @@ def main():
     # MB_BENCH_FORCE_DEVICE / MB_BENCH_BACKEND exist only to exercise the N>1 code path on a 1-GPU box
     # (tests/test_hip_bench.py: two ranks share cuda:0 over gloo); the driver's runs use one GPU per rank over RCCL.
     dev_index = int(os.environ.get("MB_BENCH_FORCE_DEVICE", local_rank))
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{dev_index} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -230,6 +235,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # communicator warm-up: a 1-element all-reduce builds the RCCL rings (seconds on the first collective) outside every timed region, and what
+        # it returns is the number of ranks that actually answered -- `ranks_seen` in the JSON line comes from here, not from the environment
+        probe = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
+        dist.all_reduce(probe)
+        ranks_seen = int(probe.item())
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: {ranks_seen} of {world} ranks answered the warm-up all-reduce")
 
     from maskbit_amd import _lib
     from maskbit_amd.parallel import gather_images
@@ -244,11 +256,20 @@ def main():
     plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
                       SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])
 
+    gather_ev = []                                      # (start, end) event pairs around the one collective of a batch
+
     def one_batch(i: int):
         labels = ((torch.arange(B) + (rank * B + i * world * B)) * 37 % 1000).to(dev)
         # the product's own path (sample() / generate_uint8()): noise drawn chunk by chunk in the reference's generator order, overlapped with the loop
         _, u8, _, _ = run_chunked(gen, tok, labels, plan, SAMPLER["randomize_temperature"], want_steps=False, want_image=False, want_u8=True)
-        return gather_images(u8, equal=True) if world > 1 else u8      # every rank holds B images: one collective per batch, no size exchange
+        if world == 1:
+            return u8
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out_ = gather_images(u8, equal=True)            # every rank holds B images: one collective per batch, no size exchange
+        e1.record()
+        gather_ev.append((e0, e1))
+        return out_
 
     def fence():
         torch.cuda.synchronize()
@@ -259,21 +280,28 @@ def main():
     for i in range(args.warmup):
         one_batch(i)
     fence()
+    gather_ev.clear()
     if not args.no_prof:
         _lib.prof_enable(True, every=PROF_EVERY)        # sampled: the event pairs themselves cost 3-5 % when every launch carries them
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_batch(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    from maskbit_amd.telemetry import ClockSampler
+    with ClockSampler(dev_index) as clocks:             # shader clock / socket power while the timed region runs (the part is power-capped: boxes differ)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = one_batch(args.warmup + i)
+        fence()
+        elapsed = time.perf_counter() - t0
+    telemetry = clocks.summary()
     prof = {}
     if not args.no_prof:
         prof = _lib.prof_read()
         _lib.prof_enable(False)
+    gather_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        # time of the batch's one collective on this rank's stream (it includes waiting for the slowest rank to arrive), max over ranks
+        gms = sum(a.elapsed_time(b) for a, b in gather_ev) / max(1, len(gather_ev))
+        t = torch.tensor([elapsed, gms], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, gather_ms = float(t[0].item()), float(t[1].item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
     # Outside the timed region, N = 1 only: (1) the MEASURED token mismatch of the timed mode against the reference's own full-size run,
     # (2) the same workload and the same parity measurement in the other precision mode, one batch.
@@ -350,7 +378,11 @@ def main():
                         # executed sequence-forwards per image: two per guided step, one where the annealed scale is exactly 0 (the loop skips the
                         # unconditional forward there: c + 0 (c - u) == c)
                         "seq_forwards_per_image": sum(2 if a != 0.0 else 1 for a in plan[0]),
-                        "end_to_end_frac": value / world * (sum(2 if a != 0.0 else 1 for a in plan[0]) * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
+                        "end_to_end_frac": value / world * (sum(2 if a != 0.0 else 1 for a in plan[0]) * F_SEQ + F_DEC) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+                        # the shader clock this run sustained (telemetry) and the same fraction against the peak AT that clock (2.4 GHz behind the nominal figure)
+                        "effective_clock_mhz": telemetry.get("effective_clock_mhz"),
+                        "frac_at_effective_clock": (achieved / (MFMA_BF16_PEAK_TFLOPS * telemetry["effective_clock_mhz"] / 2400.0)
+                                                    if telemetry.get("effective_clock_mhz") else None)}
             # the two other rooflines the north star names: attention core on MFMA, decoder on HBM
             if "attention" in prof:
                 c_, ms_ = prof["attention"]
@@ -375,6 +407,9 @@ def main():
                                    f"batch {B}/GPU, conv_vqgan decode to 256x256 uint8" + (", RCCL all-gather of images" if world > 1 else ""),
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, one process per GPU)"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            # shader clock and socket power sampled during the timed region (maskbit_amd/telemetry.py): the nominal peaks assume 2.4 GHz; random fp16
+            # data on all 256 CUs holds 1.9-2.0 GHz under the power cap, and boxes differ -- read every fraction above next to this clock
+            "telemetry": telemetry,
             "precision": {"timed_mode": args.mode,
                           "strict": "the product default: fp16 MFMA, fp32 accumulate, classifier-free guidance in differential form (the unconditional "
                                     "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u) + an MX-fp4 "
@@ -384,7 +419,8 @@ def main():
                           "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
             "precision_modes": modes,
             "other_configs": others,
-            "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
+            "ranks_seen": ranks_seen if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
+            "gather_ms": gather_ms,       # N > 1: the batch's one all-gather of uint8 images incl. the wait for the slowest rank (max over ranks); part of ms_per_step
             "kernels_note": f"HIP events on the launch stream inside the timed region; generator kernels sampled on every {PROF_EVERY}th forward",
         }
         print(json.dumps(line), flush=True)

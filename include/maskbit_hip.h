@@ -112,9 +112,9 @@ void mb_gen_destroy(mb_gen* g);
  * own layout; GEMM weights are repacked to fp16 here (plus the e2m1 / e4m3 operands of the correction passes; the two head weights as fp16
  * hi + lo planes).  Unknown names return -2. */
 int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream);
-/* cfg_pair >= 2 only: the correction passes of the GUIDED forward run in trunk layers >= `layer` (default 0 = every layer; depth = none).  An
- * experiment knob (profiles/r03_parity.md: partial coverage buys less than its share), not used by the product path. */
-int mb_gen_set_wcorr_from(mb_gen* g, int layer);
+/* cfg_pair >= 2 only: the correction passes run in trunk layers >= from_layer (default 0 = every layer; depth = none; guided forward) and on the
+ * GEMMs of gemm_mask (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down; default 15; both forwards). */
+int mb_gen_set_wcorr(mb_gen* g, int from_layer, int gemm_mask);
 /* tokens int64 [nb,seq,m] (value C = masked), labels int64 [nb], drop uint8 [nb] (1 => label
  * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */
 int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop,

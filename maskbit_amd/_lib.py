@@ -38,7 +38,7 @@ SIGNATURES = {
     "mb_gen_create": (C.c_int, [C.POINTER(GenCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "mb_gen_destroy": (None, [C.c_void_p]),
     "mb_gen_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
-    "mb_gen_set_wcorr_from": (C.c_int, [C.c_void_p, C.c_int]),
+    "mb_gen_set_wcorr": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mb_gen_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_gen_forward_cfg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mb_gen_forward_attn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

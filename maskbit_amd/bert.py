@@ -31,6 +31,7 @@ DEFAULT_ACT_SPLIT = -1
 # (the default below 7 bits per group), 3 = + the activation-lo mini-tiles for the LayerNorm outputs in the guided forward (the default from 7 bits
 # per group on: the 14-bit / 256-step configuration sits at the bound without it; tests/diag/error_budget.py, profiles/r04_parity.md).
 DEFAULT_CFG_PAIR = -1
+DEFAULT_WCORR_MASK = 15
 
 
 def pair_capable(seq_len: int, hidden: int, mlp: int, prenorm: bool) -> bool:
@@ -110,6 +111,8 @@ class LFQBert(BaseModel):
         # cfg_pair 2 only: first trunk layer that carries the weight-correction pass (0 = all, the default; depth // 2 = the second half of the trunk:
         # half the cost, 7.6e-4 instead of 4.8e-4 over the three 12-bit / 64-step runs, no use on the 14-bit ones -- profiles/r03_parity.md)
         self.wcorr_from = int(os.environ.get("MASKBIT_AMD_WFROM", "0"))
+        # ... and which GEMMs of a layer carry them: 1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down (15 = all, the default)
+        self.wcorr_mask = int(os.environ.get("MASKBIT_AMD_WMASK", str(DEFAULT_WCORR_MASK)))
         self._engine_split = None
         if not self.embed_tables:
             self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
@@ -164,9 +167,9 @@ class LFQBert(BaseModel):
             self._drop_engine()                                    # precision mode changed: rebuild and repack
         have = self._engine_key[1] if self._engine_key else 0
         h = self._ensure_engine(max(min_seqs, have, 16))
-        wf = max(0, min(int(self.wcorr_from), self.depth))
+        wf = (max(0, min(int(self.wcorr_from), self.depth)), int(self.wcorr_mask) & 15)
         if getattr(self, "_engine_wfrom", None) != wf:
-            _lib.check(_lib.load().mb_gen_set_wcorr_from(h, wf), "mb_gen_set_wcorr_from")
+            _lib.check(_lib.load().mb_gen_set_wcorr(h, wf[0], wf[1]), "mb_gen_set_wcorr")
             self._engine_wfrom = wf
         return h
 

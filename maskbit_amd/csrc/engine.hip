@@ -141,7 +141,8 @@ struct mb_gen {
   // loop state for mb_sample
   // the run mb_sample is in the middle of (step chunks): samples, total steps, guidance flag, the step the next chunk must begin with (-1: no run)
   int loop_B = 0, loop_steps = 0, loop_guided = 0, loop_next = -1;
-  int wcorr_from = 0;                                   // cfg_pair 2: first trunk layer that carries the weight-correction pass (mb_gen_set_wcorr_from)
+  int wcorr_from = 0;                                   // cfg_pair >= 2: first trunk layer that carries the correction passes (mb_gen_set_wcorr)
+  int wcorr_mask = 15;                                  // ... and which GEMMs of a layer: 1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down
   const int64_t* cfg_labels_ready = nullptr;            // gen_forward_cfg: lab_cfg / drop_cfg already hold [labels | labels] / [0 | 1] for this many pairs
   int cfg_ready_B = 0;
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
@@ -207,8 +208,10 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   const bool wm = g->mini_ok && c.cfg_pair >= 2 && !c.act_split && !c.weight_split;   // (with act_split the plain forward runs its hi + lo pairs instead)
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
   Fp4Rows f4x;
-  if (wm) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; }
+  if (wm && (g->wcorr_mask & 5)) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; }
+  const bool wo4 = wm && (g->wcorr_mask & 2);
   auto lo_set = [&](GemmArgs& ga, const uint8_t* a4, const uint8_t* a4s, int widx) {
+    if (!((g->wcorr_mask >> (widx & 3)) & 1)) return;
     ga.nlo = 1; ga.lo[0] = {a4, a4s, g->w4lo[widx], g->w4los[widx]};
   };
   g_prof.next_forward();
@@ -218,7 +221,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc, h16* out_lo = nullptr,
                    const uint8_t* w8 = nullptr, const int* w8e = nullptr, uint8_t* out_lo8 = nullptr, int widx = -1) {
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
-    if (wm) { ga.ka = 0; lo_set(ga, g->x4, g->x4s, widx); if (epi == EPI_GELU_H16) { ga.out4 = g->h4; ga.out4_scale = g->h4s; } }
+    if (wm) { ga.ka = 0; lo_set(ga, g->x4, g->x4s, widx); if (epi == EPI_GELU_H16 && (g->wcorr_mask & 8)) { ga.out4 = g->h4; ga.out4_scale = g->h4s; } }
     else if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
     else if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
     ga.out_lo = out_lo;
@@ -247,7 +250,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       { ProfScope p("gemm_qkv", s, true);
         xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
       if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wm ? g->att4 : nullptr, wm ? g->att4s : nullptr); }
+      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
       attn_rc |= attn_maps(l);
       { ProfScope p("gemm_attn_out", s, true);
         GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
@@ -270,7 +273,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     { ProfScope p("gemm_qkv", s, true);
       xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
     if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wm ? g->att4 : nullptr, wm ? g->att4s : nullptr); }
+    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
     attn_rc |= attn_maps(l);
     // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
     // GEMM operand and {mean, rstd}; the next residual GEMM re-derives the normalised rows in its epilogue and updates
@@ -321,7 +324,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   const bool alo = wmode && c.cfg_pair == 3;             // + activation-lo mini-tiles of the LayerNorm outputs (QKV / FFN-up)
   auto f4_for = [&](int consumer_layer) {                // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
-    if (wmode && consumer_layer >= wfrom) { f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; if (alo) { f.xl4 = g->xl4; f.xl4s = g->xl4s; } }
+    if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) { f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; if (alo) { f.xl4 = g->xl4; f.xl4s = g->xl4s; } }
     return f;
   };
   // lo: 0 = fp16 only, 1 = weight-correction mini-tiles (a4 / a4s = e2m1 of the conditional operand values), 2 = + the activation-lo set (x only)
@@ -330,6 +333,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     GemmArgs ga{A, W, bias, res, res, out16, M, Nout, g->split ? 2 * K : K, 0, g->split ? K : 0, g->sc(widx)};   // fp16x2 weights: A swept twice
     ga.pair_rows = P;
     if (epi != EPI_RES_F32) ga.sat = g->sat;
+    if (lo && !((g->wcorr_mask >> (widx & 3)) & 1)) lo = 0;
     if (lo) {
       ga.nlo = lo; ga.lo[0] = {a4, a4s, g->w4lo[widx], g->w4los[widx]};
       if (lo == 2) ga.lo[1] = {g->xl4, g->xl4s, g->w4[widx], g->w4s[widx]};
@@ -356,7 +360,8 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, xlo_mode, g->x4, g->x4s);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
     if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads, wl ? g->att4 : nullptr, wl ? g->att4s : nullptr); }
+    const bool wo4 = wl && (g->wcorr_mask & 2), wh4 = wl && (g->wcorr_mask & 8);
+    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
     { ProfScope p("gemm_attn_out", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? 1 : 0, g->att4, g->att4s);
       if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
@@ -364,7 +369,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     { ProfScope p("layernorm", s, true); rc |= layernorm_pair(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_h16, g->ln_stats, P, d, f4_for(l)); }
     { ProfScope p("gemm_ffn_up", s, true);
       GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, xlo_mode, g->x4, g->x4s);
-      if (wl) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
+      if (wh4) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
       rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
     { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? 1 : 0, g->h4, g->h4s);
@@ -522,14 +527,14 @@ int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const
   return 0;
 }
 int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream) {
-  if (!W || !dst4 || !scale_out || N <= 0 || K <= 0 || N % 64 || K % 4) return fail(-1, "mb_w4_from_f32: bad arguments");
+  if (!W || !dst4 || !scale_out || N <= 0 || K <= 0 || N % 64 || K % 128) return fail(-1, "mb_w4_from_f32: bad arguments");
   mb::w4_from_f32((hipStream_t)stream, W, (uint8_t*)dst4, N, K, (uint8_t*)scale_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
 int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream) {
-  if (!W || !dst4 || !scale_out || N <= 0 || K <= 0 || N % 64 || K % 4) return fail(-1, "mb_w4lo_from_f32: bad arguments");
+  if (!W || !dst4 || !scale_out || N <= 0 || K <= 0 || N % 64 || K % 128) return fail(-1, "mb_w4lo_from_f32: bad arguments");
   mb::w4lo_from_f32((hipStream_t)stream, W, (uint8_t*)dst4, N, K, (uint8_t*)scale_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
@@ -656,13 +661,13 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
     g->w4lo.assign((size_t)4 * c.depth, nullptr); g->w4los.assign((size_t)4 * c.depth, nullptr);
     g->w4.assign((size_t)4 * c.depth, nullptr); g->w4s.assign((size_t)4 * c.depth, nullptr);
     for (int l = 0; l < c.depth; ++l) {
-      rc |= galloc(g, &g->w4lo[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4los[4 * l], 3 * d);
-      rc |= galloc(g, &g->w4lo[4 * l + 1], 2 * d * d); rc |= galloc(g, &g->w4los[4 * l + 1], d);
-      rc |= galloc(g, &g->w4lo[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4los[4 * l + 2], f);
-      rc |= galloc(g, &g->w4lo[4 * l + 3], 2 * d * f); rc |= galloc(g, &g->w4los[4 * l + 3], d);
+      rc |= galloc(g, &g->w4lo[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4los[4 * l], 3 * d);          // (mini-tile-packed: half a byte per weight)
+      rc |= galloc(g, &g->w4lo[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4los[4 * l + 1], d);
+      rc |= galloc(g, &g->w4lo[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4los[4 * l + 2], f);
+      rc |= galloc(g, &g->w4lo[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4los[4 * l + 3], d);
       if (c.cfg_pair == 3) {
-        rc |= galloc(g, &g->w4[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w4s[4 * l], 3 * d);
-        rc |= galloc(g, &g->w4[4 * l + 2], 2 * f * d); rc |= galloc(g, &g->w4s[4 * l + 2], f);
+        rc |= galloc(g, &g->w4[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4s[4 * l], 3 * d);
+        rc |= galloc(g, &g->w4[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4s[4 * l + 2], f);
       }
     }
   }
@@ -767,9 +772,10 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   return 0;
 }
 
-int mb_gen_set_wcorr_from(mb_gen* g, int layer) {
-  if (!g || layer < 0 || layer > g->c.depth) return fail(-1, "mb_gen_set_wcorr_from: layer outside [0, depth]");
-  g->wcorr_from = layer;
+int mb_gen_set_wcorr(mb_gen* g, int from_layer, int gemm_mask) {
+  if (!g || from_layer < 0 || from_layer > g->c.depth || gemm_mask < 0 || gemm_mask > 15) return fail(-1, "mb_gen_set_wcorr: layer outside [0, depth] or mask outside [0, 15]");
+  g->wcorr_from = from_layer;
+  g->wcorr_mask = gemm_mask;
   return 0;
 }
 

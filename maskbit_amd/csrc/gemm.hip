@@ -245,10 +245,9 @@ __global__ __launch_bounds__(256) void w4_kernel(const float* __restrict__ W, ui
   const int r = r0 - 1 + best;
   const float m = ldexpf(1.0f, r);
   if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)max(0, min(254, 127 - r));
-  uint8_t* o = out + (size_t)n * 2 * K;
   for (int k = tid * 4; k < K; k += 1024) {
     const float4 v = *(const float4*)(w + k);
-    *(uint16_t*)(o + k / 2) = (uint16_t)fp4_pack4((float)(h16)v.x, (float)(h16)v.y, (float)(h16)v.z, (float)(h16)v.w, m);
+    *(uint16_t*)(out + w4_packed_offset(n, k, K)) = (uint16_t)fp4_pack4((float)(h16)v.x, (float)(h16)v.y, (float)(h16)v.z, (float)(h16)v.w, m);
   }
 }
 
@@ -265,10 +264,9 @@ __global__ __launch_bounds__(256) void w4lo_kernel(const float* __restrict__ W, 
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   const float mul = fp4_scale_mul_nosat(mx);
   if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)fp4_scale_byte_nosat(mx);
-  uint8_t* o = out + (size_t)n * 2 * K;
   for (int k = tid * 4; k < K; k += 1024) {
     const float4 v = *(const float4*)(w + k);
-    *(uint16_t*)(o + k / 2) = (uint16_t)fp4_pack4(v.x - (float)(h16)v.x, v.y - (float)(h16)v.y, v.z - (float)(h16)v.z, v.w - (float)(h16)v.w, mul);
+    *(uint16_t*)(out + w4_packed_offset(n, k, K)) = (uint16_t)fp4_pack4(v.x - (float)(h16)v.x, v.y - (float)(h16)v.y, v.z - (float)(h16)v.z, v.w - (float)(h16)v.w, mul);
   }
 }
 
@@ -311,11 +309,11 @@ void split_f32_to_h16_planes(hipStream_t s, const float* src, h16* hi, h16* lo, 
   hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, hi, N, K, tmp, scale_out, lo);
 }
 void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out) {
-  (void)hipMemsetAsync(dst4, 0, 2 * (size_t)N * K, s);
+  (void)hipMemsetAsync(dst4, 0, (size_t)N * K / 2, s);
   hipLaunchKernelGGL(w4_kernel, dim3(N), dim3(256), 0, s, src, dst4, N, K, scale_out);
 }
 void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out) {
-  (void)hipMemsetAsync(dst4, 0, 2 * (size_t)N * K, s);
+  (void)hipMemsetAsync(dst4, 0, (size_t)N * K / 2, s);
   hipLaunchKernelGGL(w4lo_kernel, dim3(N), dim3(256), 0, s, src, dst4, N, K, scale_out);
 }
 void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp) {

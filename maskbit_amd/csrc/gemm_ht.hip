@@ -246,12 +246,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const uint32_t row0 = PAIR ? p.m0 + wave * 16 : p.m0 + (wave >> 2) * 128 + ps * 64 + (wave & 3) * 16;
     MB_GLDS16_AUX(base + (size_t)row0 * 2 * K + jj * 64 + mini_lane(), smem + MINI_OFF + wave * 1024, AUX);
   };
-  auto mini_dma_b = [&](const Plan& p, int j) {          // 2 instructions per wave
+  auto mini_dma_b = [&](const Plan& p, int j) {          // 2 instructions per wave, 1 KiB of contiguous memory each (w4_packed_offset)
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
     const uint8_t* base = a.lo[PAIR ? ps : 0].W4;
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
 #pragma unroll
     for (int jx = 0; jx < 2; ++jx)
-      MB_GLDS16_AUX(base + (size_t)(p.n0 + (wave + 8 * jx) * 16) * 2 * K + jj * 64 + mini_lane(), smem + MINI_OFF + MINI_A + (wave + 8 * jx) * 1024, AUX);
+      MB_GLDS16_AUX(base + ((size_t)((p.n0 >> 4) + wave + 8 * jx) * nmk + jj) * 1024 + lo_ * 16, smem + MINI_OFF + MINI_A + (wave + 8 * jx) * 1024, AUX);
   };
   // the token operand's scale dword of this lane for mini j: its four m-tiles' bytes of block 2 jj + (lane >= 32) (GemmArgs.lo: lane order)
   auto mini_scale_off = [&](const Plan& p, int j) -> uint32_t {
@@ -433,6 +434,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     h16x16 xa[MH], wb[2][2];      // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
     if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
+  // trace builds only (tools/ht_trace.py, HT_DEFS): leave parts of the mini-tile machinery out -- results are garbage, timing only
+#ifdef MB_MINI_NO_PHASE
+#define MB_MINI_PHASE_ON false
+#else
+#define MB_MINI_PHASE_ON true
+#endif
+#ifdef MB_MINI_NO_DMA
+#define MB_MINI_X_DMA(...)
+#else
+#define MB_MINI_X_DMA(...) __VA_ARGS__
+#endif
+#ifdef MB_MINI_NO_READ
+#define MB_MINI_X_READ(...) _Pragma("unroll") for (int n = 0; n < 4; ++n) { mwb[n] = i32x4{lo_, lo_, lo_, lo_}; mxa[n] = i32x4{lo_, lo_, lo_, lo_}; }
+#else
+#define MB_MINI_X_READ(...) __VA_ARGS__
+#endif
+#ifdef MB_MINI_NO_MMA
+#define MB_MINI_X_MMA(...) asm volatile("" :: "v"(mwb[0]), "v"(mwb[1]), "v"(mwb[2]), "v"(mwb[3]), "v"(mxa[0]), "v"(mxa[1]), "v"(mxa[2]), "v"(mxa[3]), "v"(mws), "v"(mxs));
+#else
+#define MB_MINI_X_MMA(...) __VA_ARGS__
+#endif
 #define MB_KTILE(F8T) MB_KTILE_(F8T, 0)
 #define MB_KTILE_(F8T, MAH)         /* MAH: plain tiles with mini-tiles: the accumulator half this K loop's mini-tiles update (compile time) */ \
     {                                                                                                    \
@@ -479,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       /* MINI: the next mini-tile's scale dword and A part go out first (older than everything the phase-3 wait leaves in flight) */ \
       const bool mini_issue = MINI && t >= 1 && (mini_every || !(t & 1)); \
       const int mini_j = mini_every ? t : (t >> 1); \
-      if (MINI && mini_issue) { mini_scale_issue(cur, mini_j); mini_dma_a(cur, mini_j); } \
+      if (MINI && mini_issue) { mini_scale_issue(cur, mini_j); MB_MINI_X_DMA(mini_dma_a(cur, mini_j);) } \
       if (n1 && !(PAIR && LO && t + 1 >= nka)) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
       if (SEQ && wm == 1 && cls_on) { \
@@ -494,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       MB_MMA(0, 1) \
       /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
       if (!(PAIR && f8t)) { MB_LOAD_A(1) } \
-      if (MINI && mini_issue) mini_dma_b(cur, mini_j); \
+      if (MINI && mini_issue) { MB_MINI_X_DMA(mini_dma_b(cur, mini_j);) } \
       if (n2) dma_a(cur, t + 2, 0); \
       MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 1) } MB_MMA_END \
       /* ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed. */ \
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 0) } MB_MMA_END \
       /* ---- phase 4 (MINI): the mini-tile that landed under this (or the previous) K-tile's wait x the accumulators of its 128 token rows */ \
       if constexpr (MINI) { \
-        if (mini_every || (t & 1)) { \
+        if (MB_MINI_PHASE_ON && (mini_every || (t & 1))) { \
           const int mj = mini_every ? t : (t >> 1); \
           const int mps = __builtin_amdgcn_readfirstlane(mj >= nmk ? 1 : 0); \
           int lo_ = lane; \
@@ -531,11 +553,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           const int mfo = (lo_ & 15) * 64 + (((lo_ >> 4) ^ ((lo_ >> 2) & 3)) * 16); \
           const char* mbuf = smem + MINI_OFF; \
           i32x4 mxa[4], mwb[4]; \
+          MB_MINI_X_READ( \
           _Pragma("unroll") for (int n = 0; n < 4; ++n) mwb[n] = *(const i32x4*)(mbuf + MINI_A + (wn * 64 + n * 16) * 64 + mfo); \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i) mxa[i] = *(const i32x4*)(mbuf + (wm * 64 + i * 16) * 64 + mfo); \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) mxa[i] = *(const i32x4*)(mbuf + (wm * 64 + i * 16) * 64 + mfo); ) \
           const int mws = (PAIR && mps) ? mwsc1 : mwsc0; \
           MB_SYNC_L() \
-          MB_MINI_MMA(MAH) \
+          MB_MINI_X_MMA(MB_MINI_MMA(MAH)) \
           /* (v_mfma_scale results must not be read by a VALU copy too early, see the class-row blocks above) */ \
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
           MB_MMA_END \
@@ -558,6 +581,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
 #undef MB_KTILE
 #undef MB_KTILE_
+#undef MB_MINI_X_DMA
+#undef MB_MINI_X_READ
+#undef MB_MINI_X_MMA
     if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the two groups
     MB_TRACE(1);
 
@@ -908,7 +934,7 @@ bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
                 (a.nlo == 2 && (!a.lo[1].A4 || !a.lo[1].W4 || !a.lo[1].a_scale || !a.lo[1].w_scale)) || (uint64_t)a.M * a.K * 2 >= (1ull << 32) ||
                 epi == EPI_GELU_F32)) return false;
   if (a.A4 && (a.A8 || !a.W4 || !a.a_scale || !a.w_scale || a.kw % 256 || a.K != a.kw + a.kw / 4 || epi == EPI_GELU_F32)) return false;
-  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8 || a.A4) &&
+  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8 || a.A4 || a.nlo) &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
          (uint64_t)a.M * a.N * 4 < (1ull << 32);      // 32-bit element / byte offsets inside the kernel
 }

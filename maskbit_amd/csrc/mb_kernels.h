@@ -81,7 +81,8 @@ struct GemmArgs {
   // in a fifth phase between them (16 v_mfma_scale_f32_16x16x128_f8f6f4 per wave).  nlo = number of operand sets:
   //   pair tiles : lo[0] (, lo[1]) on the CONDITIONAL rows: K / 128 mini-tiles per set (one per two fp16 K-tiles with one set, one per K-tile with two);
   //   plain tiles: lo[0] on both 128-row halves of the sequence tile (nlo = 1): 2 K / 128 mini-tiles, one per fp16 K-tile.
-  // Operands: A4 = e2m1 token operand, two values per byte, row stride 2 K bytes (first K / 2 used); W4 = e2m1 weight operand, same stride;
+  // Operands: A4 = e2m1 token operand, two values per byte, row stride 2 K bytes (first K / 2 used); W4 = e2m1 weight operand, mini-tile-packed
+  // (w4_packed_offset; N K / 2 bytes);
   // w_scale = the weights' E8M0 bytes in the kernel's lane order (entry ((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)); a_scale = the token
   // operand's E8M0 bytes per (row, 64 K-elements) in LANE ORDER: a_scale[((blk * nseq + seq) * 4 + grp) * 64 + (r & 15) * 4 + ((r >> 4) & 3)] for
   // token r = grp * 64 + (r & 63) of sequence seq (nseq = M / 257; pair tiles: conditional sequences, nseq = pair_rows / 257) -- one dword per lane
@@ -92,6 +93,14 @@ struct GemmArgs {
   LoSet lo[2] = {};
   int nlo = 0;
 };
+// Byte offset of element (row n, K-element k) of an e2m1 WEIGHT operand of the mini-tile passes.  The operand is stored MINI-TILE-PACKED:
+// [N / 16][K / 128] chunks of 1 KiB = 16 rows x 64 B, the 16-byte pieces of a row swizzled with (row >> 2) & 3 -- the LDS image of one DMA
+// instruction, so that every instruction of a weight mini-tile reads 1 KiB of CONTIGUOUS memory (8 full 128-byte lines) instead of 16 half lines
+// of a row-major operand (measured: the L2 -> LDS path pays per line, not per byte -- profiles/r04_gemm_minitiles.md).  N % 16 == 0, K % 128 == 0.
+__host__ __device__ inline size_t w4_packed_offset(int n, int k, int K) {
+  const int r = n & 15, c = (k & 127) >> 5;
+  return ((size_t)(n >> 4) * (K >> 7) + (k >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + ((k & 31) >> 1);
+}
 // byte index of the scale of (token row r of sequence seq, 64-column block blk) in the lane-ordered scale arrays of the mini-tile passes
 __host__ __device__ inline size_t fp4_scale_index(int blk, int nseq, int seq, int r) {
   return (((size_t)blk * nseq + seq) * 4 + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3);
@@ -103,8 +112,8 @@ void set_cu_count(int n);   // persistent grids are sized for n CUs (0 = the dev
 // e4m3 copy of a weight (row stride 2K bytes, first K used) for the fp8 correction pass; *exp_out = the power of two it was scaled by
 void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp);
 
-// e2m1 copy of a weight for the fp4 correction pass: dst4[n][2K bytes] (first K/2 used) = e2m1(fp16(W[n]) * 2^r_n), r_n per row chosen to
-// minimise the row's quantisation error; scale_out in the kernel's lane order (GemmArgs.w_scale)
+// e2m1 copy of a weight for the mini-tile passes: e2m1(fp16(W[n]) * 2^r_n) in the mini-tile-packed layout (w4_packed_offset; N K / 2 bytes), r_n
+// per row chosen to minimise the row's quantisation error; scale_out in the kernel's lane order (GemmArgs.lo w_scale).  N % 16 == 0, K % 128 == 0.
 void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);
 // the same layout for the weight's fp16 ROUNDING ERROR: e2m1((W[n] - fp16(W[n])) * 2^r_n), r_n from the row's largest |error| (fp4_scale_mul)
 void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);

@@ -33,17 +33,19 @@ RUN_CFG5_S2 = "sample_full14_256_s2"
 RUN_CFG5_S3 = "sample_full14_256_s3"     # round 4: configs[4] a third time at twice the batch (334 248 positions)
 RUN_C3_OUTLIER = "sample_full12_64_outlier"          # configs[2] / configs[1] on "trained-like" weights (synth._trained_like: heavy tails,
 RUN_CFG1_OUTLIER = "sample_full10_16_nocfg_outlier"  # massive-activation channels)
+RUN_C3_PRENORM = "sample_full12_64_prenorm"          # configs[2]'s sampler on the generator variants without a differential guided forward:
+RUN_C3_SEQ1024 = "sample_full12_64_seq1024"          # use_prenorm=True, and the 512 x 512 models' 1024 + 1 tokens
 
 
 def load_run(name: str = "sample_full12_64") -> Dict[str, object]:
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    steps = torch.from_numpy(z["steps"].astype(np.int64))                      # [S, B, 256, 2] predicted tokens per step
-    S, B = steps.shape[0], steps.shape[1]
-    masks = torch.from_numpy(np.unpackbits(z["masks"], axis=1)[:, : B * 512].reshape(S, B, 256, 2).astype(bool))
+    steps = torch.from_numpy(z["steps"].astype(np.int64))                      # [S, B, n, 2] predicted tokens per step (n = 256, or 1024 for the 512 x 512 models)
+    S, B, n = steps.shape[0], steps.shape[1], steps.shape[2]
+    masks = torch.from_numpy(np.unpackbits(z["masks"], axis=1)[:, : B * n * 2].reshape(S, B, n, 2).astype(bool))
     kw = {str(k): str(v) for k, v in zip(z["kw_keys"], z["kw_vals"])}
     bits = int(z["bits"]) if "bits" in z.files else 12
     g = {"z": z, "name": name, "steps": steps, "masks": masks, "labels": torch.from_numpy(z["labels"].astype(np.int64)), "kw": kw,
-         "seed": int(z["seed"]), "bits": bits, "C": 1 << (bits // 2)}
+         "seed": int(z["seed"]), "bits": bits, "C": 1 << (bits // 2), "n": n, "prenorm": bool(int(z["gen_prenorm"])) if "gen_prenorm" in z.files else False}
     if "codes" in z.files:
         g["codes"] = torch.from_numpy(z["codes"].astype(np.int64))
     return g
@@ -61,22 +63,22 @@ def tokens_in(g, i: int) -> torch.Tensor:
 
 
 def reference_noise(g, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(exp_noise [S, B*512, 64], conf_noise [S, B, 256, 2]) exactly as the reference drew them (CPU default generator)."""
-    S, B = g["steps"].shape[0], g["steps"].shape[1]
+    """(exp_noise [S, B*n*2, C], conf_noise [S, B, n, 2]) exactly as the reference drew them (CPU default generator)."""
+    S, B, n = g["steps"].shape[0], g["steps"].shape[1], g["steps"].shape[2]
     rt = float(g["kw"]["randomize_temperature"])
     torch.manual_seed(g["seed"])
     gum = torch.distributions.Gumbel(0.0, 1.0)
     qs, cs = [], []
     for i in range(S):
-        qs.append(torch.empty(B * 512, g["C"]).exponential_(1))
-        cs.append(gum.sample((B, 256, 2)) * rt * (1 - (i + 1) / S))
+        qs.append(torch.empty(B * n * 2, g["C"]).exponential_(1))
+        cs.append(gum.sample((B, n, 2)) * rt * (1 - (i + 1) / S))
     return torch.stack(qs).to(device), torch.stack(cs).to(device)
 
 
 def plan_of(g):
     from maskbit_amd.sampling import build_plan
     kw = g["kw"]
-    return build_plan(int(kw["num_steps"]), 512, float(kw["guidance_scale"]), kw["guidance_annealing"], float(kw["scale_pow"]), 1.0, False,
+    return build_plan(int(kw["num_steps"]), 2 * g["steps"].shape[2], float(kw["guidance_scale"]), kw["guidance_annealing"], float(kw["scale_pow"]), 1.0, False,
                       kw["mask_schedule_strategy"])
 
 
@@ -87,11 +89,14 @@ def build_models(device, with_tokenizer: bool = True, name: str = "sample_full12
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     bits = int(z["bits"]) if "bits" in z.files else 12
     style = str(z["gen_style"]) if "gen_style" in z.files else "gaussian"
-    gsd = synth.make_generator_weights(synth.GenCfg(bits=bits, splits=2), seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]), style=style)
+    seq = int(z["gen_seq"]) if "gen_seq" in z.files else 256
+    prenorm = bool(int(z["gen_prenorm"])) if "gen_prenorm" in z.files else False
+    gsd = synth.make_generator_weights(synth.GenCfg(bits=bits, splits=2, seq=seq, prenorm=prenorm), seed=int(z["gen_seed"]), head_gain=float(z["head_gain"]),
+                                       style=style)
     sha = lambda t: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
     assert sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]) == str(z["w_sha_in_proj0"]), "synthetic generator weights changed"
-    gen = LFQBert(img_size=256, hidden_dim=1024, codebook_size=2 ** bits, codebook_splits=2, depth=24, heads=16, mlp_dim=4096, dropout=0.1,
-                  nclass=1000, input_stride=16)
+    gen = LFQBert(img_size=16 * int(round(seq ** 0.5)), hidden_dim=1024, codebook_size=2 ** bits, codebook_splits=2, depth=24, heads=16, mlp_dim=4096,
+                  dropout=0.1, nclass=1000, input_stride=16, use_prenorm=prenorm)
     gen.load_state_dict(gsd, strict=True)
     gen = gen.eval().requires_grad_(False).to(device)
     tok = None
@@ -133,7 +138,7 @@ def teacher_forced(gen, g=None, noise=None):
             lc, lu = gen(tin, y, torch.zeros(B, dtype=torch.bool, device=dev)), None
         tout, pred = torch.empty_like(tin), torch.empty_like(tin)
         _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr() if lu is not None else None, scale[i], temp[i], q[i].data_ptr(), c[i].data_ptr(),
-                                      mask_len[i], tin.data_ptr(), tout.data_ptr(), pred.data_ptr(), B, 256, 2, g["C"],
+                                      mask_len[i], tin.data_ptr(), tout.data_ptr(), pred.data_ptr(), B, g["steps"].shape[2], 2, g["C"],
                                       torch.cuda.current_stream().cuda_stream), "mb_sample_step")
         msk = g["masks"][i]
         per_step.append(int((pred.cpu() != g["steps"][i])[msk].sum()))

@@ -111,10 +111,15 @@ OUTLIER_GAMMA = 0.1
 OUTLIER_CONSUMER = 0.0625  # the consumers' columns of those channels (an outlier channel then contributes about a normal channel's share of an output)
 
 
+# 48 x 0.75, 12 x 1.5, 3 x 2.5, 1 x 4 of 64, normalised to unit second moment: kurtosis 10.9 (a Gaussian's: 3; Student-t_6: 6)
+_HEAVY_TAIL_SCALES = torch.tensor([0.75] * 48 + [1.5] * 12 + [2.5] * 3 + [4.0]) / math.sqrt((48 * 0.75 ** 2 + 12 * 1.5 ** 2 + 3 * 2.5 ** 2 + 16.0) / 64)
+
+
 def _trained_like(sd: StateDict, cfg: GenCfg, seed: int, style: str) -> None:
     """Post-transform of the Gaussian draw towards the statistics trained transformers show and Gaussian weights do not (what per-row / per-block
     MX-fp4 scales and fp16 activations are sensitive to):  style "outlier" = (1) heavy-tailed Linear weights -- every 2-D trunk / head weight is
-    multiplied elementwise by sqrt(nu / chi2_nu) with nu = 6 (a Student-t_6 draw) and by 1 / sqrt(var t_6): the Gaussian draw's standard deviation;
+    multiplied elementwise by a random scale from _HEAVY_TAIL_SCALES (a scale mixture of normals with the Gaussian draw's standard deviation and
+    kurtosis 10.9: one weight in 64 is 4.7x its draw, three are 2.9x);
     (2) OUTLIER_CHANNELS hidden channels carry massive LayerNorm outputs, the same channels in every layer ("massive activations"): beta =
     +-OUTLIER_BETA and gamma x OUTLIER_GAMMA in first_layer.0 and both norms of every layer -- in a post-norm trunk the residual stream then holds
     +-12 in those channels next to ~0.75 rms in the others, a stable fixed point at which the logits still depend on tokens and class as much as
@@ -128,8 +133,9 @@ def _trained_like(sd: StateDict, cfg: GenCfg, seed: int, style: str) -> None:
     for k in sorted(sd):
         v = sd[k]
         if v.dim() == 2 and (k.startswith("transformer.layers.") or k.startswith("last_layer.0") or k.startswith("prediction_layer")):
-            e = sum(torch.empty(v.shape).exponential_(1.0, generator=g) for _ in range(3))    # chi2_6 / 2
-            sd[k] = v * torch.sqrt(3.0 / e) * (1.0 / math.sqrt(1.5))      # var(t_6) = 6 / 4; elementwise only: bit-reproducible on any host
+            # a scale mixture of normals from an integer draw and a table of exact constants: one multiply per weight, bit-reproducible on any host
+            # (torch's CPU exponential_ and even sqrt are not: both differ between this build container and the GPU boxes' hosts)
+            sd[k] = v * _HEAVY_TAIL_SCALES[torch.randint(0, 64, v.shape, generator=g)]
     ch = torch.randperm(d, generator=g)[:OUTLIER_CHANNELS]
     sign = torch.where(torch.rand(OUTLIER_CHANNELS, generator=g) < 0.5, -1.0, 1.0)
     norms = ["first_layer.0"] + [f"transformer.layers.{l}.{s}.norm" for l in range(cfg.depth) for s in (0, 1)]

@@ -79,9 +79,9 @@ FULL_TOK10 = O.TokCfg(token_size=10)
 
 
 def build_ref_gen(LFQBert, cfg: O.GenCfg, sd):
-    model = LFQBert(img_size=256, hidden_dim=cfg.hidden, codebook_size=2 ** cfg.bits, codebook_splits=cfg.splits,
+    model = LFQBert(img_size=16 * int(round(cfg.seq ** 0.5)), hidden_dim=cfg.hidden, codebook_size=2 ** cfg.bits, codebook_splits=cfg.splits,
                     depth=cfg.depth, heads=cfg.heads, mlp_dim=cfg.mlp, dropout=0.1, nclass=cfg.nclass,
-                    input_stride=16, use_prenorm=False)
+                    input_stride=16, use_prenorm=cfg.prenorm)
     model.load_state_dict(sd, strict=True)
     return model.eval().requires_grad_(False)
 
@@ -125,6 +125,10 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     "sample_full14_256_s3": (14, 181, 12.0, 4, CFG5_256, False, 4325, 8),
     "sample_full12_64_outlier": (12, 190, 12.0, 4, FULL64, False, 4326, 2, "outlier"),
     "sample_full10_16_nocfg_outlier": (10, 191, 12.0, 16, CFG1_16, False, 4327, 0, "outlier"),
+    # the two generator variants whose guided forward does not run in differential form on the engine (it falls back to the plain forward over
+    # [cond | uncond]): use_prenorm=True (bert.py:49-59,106-123) and the 512 x 512 models' 1024 + 1 tokens (scripts/eval_maskbit.py:125,139-144)
+    "sample_full12_64_prenorm": (12, 192, 12.0, 4, FULL64, False, 4328, 4, "gaussian", dict(prenorm=True)),
+    "sample_full12_64_seq1024": (12, 193, 12.0, 2, FULL64, False, 4329, 6, "gaussian", dict(seq=1024)),
 }
 
 
@@ -140,11 +144,14 @@ def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
     else:
         lab0 = 0
     style = RUNS[name][8] if len(RUNS[name]) > 8 else "gaussian"
-    gcfg = O.GenCfg(bits=bits, splits=2)
+    extra = RUNS[name][9] if len(RUNS[name]) > 9 else {}
+    gcfg = O.GenCfg(bits=bits, splits=2, **extra)
+    side = int(round(gcfg.seq ** 0.5))                  # latent side: 16 (256 x 256 images) or 32 (512 x 512)
     C_ = gcfg.group_codes
     gsd = O.make_generator_weights(gcfg, seed=gseed, head_gain=gain, style=style)
     gen = build_ref_gen(LFQBert, gcfg, gsd)
-    tcfg = O.TokCfg(token_size=bits)
+    # (the 1024-token run decodes with a small tokenizer: sample() always decodes, and a full-size 512 x 512 decode on the CPU buys nothing here)
+    tcfg = O.TokCfg(token_size=bits) if side == 16 else O.TokCfg(token_size=bits, hidden_channels=32, channel_mult=(1, 1, 2), num_resolutions=3, num_res_blocks=1)
     tsd = O.make_tokenizer_weights(tcfg, seed=200)
     tok = build_ref_tok(ConvVQModel, tcfg, O.make_tokenizer_weights(tcfg, seed=200, with_encoder=True))
     labels = torch.tensor([7, 282, 604, 980, 1, 404, 850, 33, 512, 111, 927, 65, 340, 771, 208, 999][lab0:lab0 + B])
@@ -158,14 +165,14 @@ def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
     gen.forward = spy
     torch.manual_seed(seed)
     image, steps = ref_sample(gen, tok, num_samples=B, labels=labels.clone(), softmax_temperature=1.0, mask_token=C_,
-                              patch_size=16, codebook_size=2 ** bits, codebook_splits=2, **kw)
+                              patch_size=side, codebook_size=2 ** bits, codebook_splits=2, **kw)
     gen.forward = inner
     steps = torch.stack(steps)                          # [S, B, 256, 2]
     S = steps.shape[0]
     masks = torch.stack(seen) == C_                     # [S, B, 256, 2] positions masked when step i ran
     assert masks[0].all() and steps.max() < C_
     assert torch.equal(torch.where(masks[1:], torch.full_like(steps[:-1], C_), steps[:-1]), torch.stack(seen)[1:])
-    out = dict(seed=seed, gen_seed=gseed, head_gain=gain, gen_style=style, tok_seed=200, bits=bits, labels=labels.numpy(), steps=steps.numpy().astype(np.int16),
+    out = dict(seed=seed, gen_seed=gseed, head_gain=gain, gen_style=style, gen_seq=gcfg.seq, gen_prenorm=int(gcfg.prenorm), tok_seed=200, bits=bits, labels=labels.numpy(), steps=steps.numpy().astype(np.int16),
                masks=np.packbits(masks.numpy().reshape(S, -1), axis=1), w_sha_in_proj0=sha(gsd["transformer.layers.0.0.mha.in_proj_weight"]),
                w_sha_conv_in=sha(tsd["decoder.conv_in.weight"]), kw_keys=np.array(list(kw.keys())), kw_vals=np.array([str(v) for v in kw.values()]))
     if decode:

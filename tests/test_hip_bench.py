@@ -55,3 +55,27 @@ def test_bench_two_ranks_on_one_gpu():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8
     assert abs(d["value"] - 8 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"] + 1e-9
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["gather_ms"] is not None and d["gather_ms"] >= 0
+
+
+def test_bench_two_gpus_over_rccl_when_two_devices_are_visible():
+    """`bench.py --gpus 2` over RCCL (backend "nccl") on two real devices: skipped on the 1-GPU boxes, the first thing an 8-GPU node runs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MB_BENCH_FORCE_DEVICE",
+                                                            "MB_BENCH_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "nccl" and d["config"]["global_batch"] == 16 and d["gather_ms"] > 0
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MB_BENCH_FORCE_DEVICE", "MB_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and f"--gpus {n}" in (r.stderr + r.stdout) and "GPU(s)" in (r.stderr + r.stdout)

@@ -9,6 +9,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 AB = os.path.join(ROOT, "tools", "_ab")
+TAG = os.environ.get("HT_TAG", "")            # suffix of the library name: several builds with different HT_DEFS side by side
 
 
 def build():
@@ -17,20 +18,20 @@ def build():
     for mode in ([int(a) for a in sys.argv[2:]] or (1, 2, 3, 4)):
         objs, procs = [], []
         for src in B.SOURCES:
-            obj = os.path.join(AB, f"trace{mode}_{src.replace('.hip', '.o')}")
+            obj = os.path.join(AB, f"trace{mode}{TAG}_{src.replace('.hip', '.o')}")
             objs.append(obj)
             procs.append(subprocess.Popen([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f"-DMB_HT_TRACE={mode % 10}", *(["-DMB_BS_NOLOAD=1"] if mode >= 10 else []),
                                            *os.environ.get("HT_DEFS", "").split(), "-c", os.path.join(B.CSRC, src), "-o", obj]))
         assert all(p.wait() == 0 for p in procs)
-        subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", os.path.join(AB, f"libtrace{mode}.so")])
-        print("built", os.path.join(AB, f"libtrace{mode}.so"))
+        subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", os.path.join(AB, f"libtrace{mode}{TAG}.so")])
+        print("built", os.path.join(AB, f"libtrace{mode}{TAG}.so"))
 
 
 def run(mode):
     import numpy as np
     import torch
     from maskbit_amd import _lib
-    _lib.LIB_PATH = os.path.join(AB, f"libtrace{mode}.so")
+    _lib.LIB_PATH = os.path.join(AB, f"libtrace{mode}{TAG}.so")
     lib = _lib.load()
     lib.mb_debug_ht_trace.restype = C.c_int
     lib.mb_debug_ht_trace.argtypes = [C.c_void_p]
@@ -47,15 +48,16 @@ def run(mode):
         res = torch.randn(M, N, device=dev) if epi == 2 else None
         o32 = torch.empty(M, N, device=dev) if epi == 2 else None
         o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
-        if os.environ.get("HT_F4"):                      # with the MX-fp4 weight-correction pass (precise mode): K/256 extra lo K-tiles on the conditional half
+        nlo = int(os.environ.get("HT_MINI", "0"))        # with 1 / 2 MX-fp4 mini-tile operand sets on the conditional half (cfg_pair 2 / 3)
+        sets = []
+        for _ in range(nlo):
             x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8)
-            xsb = torch.full((P * (K // 64) + 256,), 100, device=dev, dtype=torch.uint8)
+            xsb = torch.full(((K // 64) * 64 * 256 + 256,), 100, device=dev, dtype=torch.uint8)
             w4 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); ws = torch.zeros(N, device=dev, dtype=torch.uint8)
             _lib.check(lib.mb_w4_from_f32(W.float().data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), st()))
-            fn = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K,
-                                                     x4.data_ptr(), xsb.data_ptr(), w4.data_ptr(), ws.data_ptr(), st()))
-        else:
-            fn = lambda: _lib.check(lib.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K, None, None, None, None, st()))
+            sets += [x4, xsb, w4, ws]
+        arr = (C.c_void_p * max(1, len(sets)))(*[t.data_ptr() for t in sets])
+        fn = lambda: _lib.check(lib.mb_gemm_mini(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), None, None, P, 1, N, K, nlo, arr, st()))
         G = int(os.environ.get("MASKBIT_AMD_HT_GRID", 256))
         trace = torch.zeros(256, 8, 8, dtype=torch.int64, device=dev)
         for _ in range(3): fn()
