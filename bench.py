@@ -204,9 +204,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU per step (default: the C3 batch, 64)")
     ap.add_argument("--mode", choices=("strict", "diff", "fp16", "wcorr", "max"), default="strict",
-                    help="precision mode of the TIMED region: strict (default; the product default: differential guidance + an MX-fp4 correction pass "
-                         "for the weights' fp16 rounding on every trunk GEMM; meets <= 1e-3 token mismatch with margin), diff (differential guidance "
-                         "alone: faster, AT the bound), single fp16, wcorr (the correction pass in the second half of the trunk only) or max (fp16x2 weights)")
+                    help="precision mode of the TIMED region: strict (default; the product default: differential guidance + MX-fp4 correction mini-tiles "
+                         "for the weights' fp16 rounding on every trunk GEMM + hi/lo head weights: 5.5e-4 token mismatch over three reference runs), diff "
+                         "(differential guidance alone: faster, AT the 1e-3 bound), single fp16, wcorr (the correction in the second half of the trunk "
+                         "only) or max (fp16x2 weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurements: parity replay and the other precision mode")
@@ -359,7 +360,7 @@ def main():
             fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
             traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.*), if present
             traffic_src = None
-            for name in ("r03c_pmc_traffic.json", "r03_pmc_traffic.json"):     # the counter passes of the dominant kernel as the timed mode runs it
+            for name in ("r04_pmc_traffic.json", "r03c_pmc_traffic.json", "r03_pmc_traffic.json"):     # the counter passes of the dominant kernel as the timed mode runs it
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if B == B_PER_GPU and pmc.get("_mode", "").split(" ")[0] == args.mode:
@@ -412,16 +413,18 @@ def main():
             "telemetry": telemetry,
             "precision": {"timed_mode": args.mode,
                           "strict": "the product default: fp16 MFMA, fp32 accumulate, classifier-free guidance in differential form (the unconditional "
-                                    "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u) + an MX-fp4 "
-                                    "correction pass for the fp16 rounding of the weights on the conditional half of every trunk GEMM (LFQBert.cfg_pair = 2)",
-                          "diff": "the differential form without the correction pass (LFQBert.cfg_pair = 1): ~1.17x the default's speed; its token "
-                                  "mismatch over the three reference runs is 1.03e-3, AT the bound (round 2's default)",
+                                    "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u) + MX-fp4 "
+                                    "correction mini-tiles for the fp16 rounding of the weights on the conditional half of every trunk GEMM (and on every row of "
+                                    "the plain forward of the zero-scale steps) + hi/lo head weights (LFQBert.cfg_pair = 2)",
+                          "diff": "the differential form without the correction mini-tiles (LFQBert.cfg_pair = 1): ~1.17x the default's speed; its token "
+                                  "mismatch over the three reference runs is ~1e-3, AT the bound (round 2's default)",
                           "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
             "precision_modes": modes,
             "other_configs": others,
             "ranks_seen": ranks_seen if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
             "gather_ms": gather_ms,       # N > 1: the batch's one all-gather of uint8 images incl. the wait for the slowest rank (max over ranks); part of ms_per_step
-            "kernels_note": f"HIP events on the launch stream inside the timed region; generator kernels sampled on every {PROF_EVERY}th forward",
+            "kernels_note": f"HIP events on the launch stream inside the timed region; generator kernels sampled on every {PROF_EVERY}th guided forward "
+                            f"(names as they are) and every {PROF_EVERY}th plain forward (the zero-scale steps: names + '.plain'), counted separately",
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -65,8 +65,9 @@ typedef struct {
    *     the shared accumulator) and on every row of the plain forward (act_split 0).  Not combined with weight_split.
    * 3 = 2 + the same kind of pass for the fp16 rounding of the conditional LayerNorm OUTPUTS in the guided forward's QKV / FFN-up GEMMs (e2m1 of
    *     their lo halves against e2m1 of the weights): what the 7-bit-per-group codebooks need for margin (tests/diag/error_budget.py).
-   * Pair forwards need seq = 256, hidden 768 / 1024, mlp % 256 == 0, post-norm; modes 2 / 3 also hidden / heads = 64.  Otherwise the engine falls
-   * back (guided: plain forward over [cond | uncond]; plain: act_split). */
+   * Pair forwards need seq = 256, hidden 768 / 1024, mlp % 256 == 0 (post- or pre-norm); modes 2 / 3 also hidden / heads = 64.  Otherwise the engine
+   * falls back (guided: plain forward over [cond | uncond]; plain: act_split) -- the 1024 + 1-token models of 512 x 512 images run that way: 7.6e-4
+   * token mismatch on a full-width reference run with act_split 3 (tests/test_hip_configs.py). */
   int cfg_pair;
 } mb_gen_cfg;
 

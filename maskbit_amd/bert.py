@@ -35,7 +35,8 @@ DEFAULT_WCORR_MASK = 15
 
 
 def pair_capable(seq_len: int, hidden: int, mlp: int, prenorm: bool) -> bool:
-    return seq_len == 256 and hidden in (768, 1024) and mlp % 256 == 0 and not prenorm
+    """Shapes the differential guided forward serves (mb_gen_create: pair_ok); post- and (round 4) pre-norm."""
+    return seq_len == 256 and hidden in (768, 1024) and mlp % 256 == 0
 
 
 def mini_capable(seq_len: int, hidden: int, mlp: int, heads: int) -> bool:

@@ -31,7 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     objs = []
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", *os.environ.get("MASKBIT_AMD_BUILD_DEFS", "").split()]   # (extra -D for A/B builds)
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:

@@ -39,15 +39,19 @@ int fail(int code, const char* fmt, ...) {
 // ---- optional per-kernel device timing with HIP events on the launch stream ------------------
 struct Prof {
   bool on = false;
-  int stride = 1, tick = 0;         // generator forwards are sampled: kernels of every `stride`-th forward are timed
-  bool fwd_live = true;
-  void next_forward() { fwd_live = (tick++ % stride) == stride / 2; }   // (the middle of every stride: with 8, forwards 4, 12, .. -- a 64-step run's unguided forwards are steps 0..2)
+  // Generator forwards are sampled: the kernels of every `stride`-th forward are timed -- counted separately for GUIDED forwards (mb_gen_forward_cfg
+  // and the guided steps of mb_sample: kernel names as they are) and PLAIN ones (mb_gen_forward, the unguided / zero-scale steps: names + ".plain"),
+  // so that a plain forward never lands in a guided kernel's average whatever the step plan and the chunking (round-3 advice).
+  int stride = 1, tick[2] = {0, 0};
+  bool fwd_live = true, fwd_plain = false;
+  void begin_forward(bool plain) { fwd_plain = plain; fwd_live = (tick[plain]++ % stride) == stride / 2; }   // (the middle of every stride)
   struct Rec { hipEvent_t a, b; int kind; };
   std::vector<Rec> recs;
   std::vector<std::string> names;
   std::map<std::string, int> index;
   std::map<int, std::pair<long, double>> acc;   // kind -> (calls, ms)
-  int kind(const char* n) {
+  int kind(const char* n0, bool in_forward) {
+    const std::string n = (in_forward && fwd_plain) ? std::string(n0) + ".plain" : std::string(n0);
     auto it = index.find(n);
     if (it != index.end()) return it->second;
     names.push_back(n);
@@ -69,7 +73,7 @@ struct ProfScope {
   hipStream_t s; bool live; hipEvent_t a, b; int kind;
   ProfScope(const char* name, hipStream_t st, bool in_forward = false) : s(st), live(g_prof.on && (!in_forward || g_prof.fwd_live)) {
     if (!live) return;
-    kind = g_prof.kind(name);
+    kind = g_prof.kind(name, in_forward);
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     (void)hipEventRecord(a, s);
   }
@@ -214,7 +218,6 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     if (!((g->wcorr_mask >> (widx & 3)) & 1)) return;
     ga.nlo = 1; ga.lo[0] = {a4, a4s, g->w4lo[widx], g->w4los[widx]};
   };
-  g_prof.next_forward();
   const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
   // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
   // K = 2d K-tiles, the first d columns pairing x_h16 with W, the second d columns x_lo with the same W
@@ -315,7 +318,6 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   using namespace mb;
   const mb_gen_cfg& c = g->c;
   const int d = c.hidden, f = c.mlp, N = g->N, nb = 2 * B, M = nb * N, P = B * N;
-  g_prof.next_forward();
   int rc = 0;
   // measured (profiles/r03_parity.md): the correction pass in layers >= depth / 2 alone buys about 60 % of the gain on the 12-bit runs for half of
   // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- an option
@@ -352,6 +354,11 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       rc |= pairify_rows(s, g->y_f32, g->x_h16, P, d, f4_for(0));        // y_f32 holds the embedding LayerNorm's fp32 rows here
     }
   }
+  // pre-norm: the first sub-layer normalises the embedding rows again (LayerNorm 1 of layer 0); post-norm: the embedding's own pair operands feed QKV
+  if (c.prenorm && c.depth > 0) {
+    ProfScope p("layernorm", s, true);
+    rc |= layernorm_pair(s, g->y_f32, g->layers[0].ln1g, g->layers[0].ln1b, 1e-12f, g->x_h16, nullptr, P, d, f4_for(0));
+  }
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     const bool wl = wmode && l >= wfrom;
@@ -364,19 +371,26 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
     { ProfScope p("gemm_attn_out", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? 1 : 0, g->att4, g->att4s);
-      if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
+      if (l > 0 && !c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
-    { ProfScope p("layernorm", s, true); rc |= layernorm_pair(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, g->x_h16, g->ln_stats, P, d, f4_for(l)); }
+    // post-norm: LayerNorm 1 follows the attention block; pre-norm: LayerNorm 2 precedes the FFN (same place in the launch order, other parameters;
+    // the stream buffer then holds the raw residual and no GEMM re-derives a LayerNorm from the statistics)
+    { ProfScope p("layernorm", s, true);
+      rc |= layernorm_pair(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, g->x_h16, c.prenorm ? nullptr : g->ln_stats, P, d, f4_for(l)); }
     { ProfScope p("gemm_ffn_up", s, true);
       GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, xlo_mode, g->x4, g->x4s);
       if (wh4) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
       rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
     { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? 1 : 0, g->h4, g->h4s);
-      ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
+      if (!c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     { ProfScope p("layernorm", s, true);
-      if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi (+ lo) rows
+      if (c.prenorm) {            // the next layer's LayerNorm 1 (bert.py:49-59, 106-123), or norm_after_transformer in front of the head
+        if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo);
+        else rc |= layernorm_pair(s, g->y_f32, g->layers[l + 1].ln1g, g->layers[l + 1].ln1b, 1e-12f, g->x_h16, nullptr, P, d, f4_for(l + 1));
+      }
+      else if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi (+ lo) rows
       else rc |= layernorm_pair(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_h16, g->ln_stats, P, d, f4_for(l + 1)); }
   }
   rc |= head_gemms(g, logits, M, s);
@@ -391,6 +405,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
 int gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, int nb, hipStream_t s,
                 float* attn = nullptr) {
   const int chunk = g->chunk_seqs;
+  g_prof.begin_forward(true);
   if (nb <= chunk) return gen_forward_impl(g, tokens, labels, drop, logits, nb, s, attn);
   if (attn) return fail(-3, "attention maps are limited to %d sequences per call", chunk);
   const size_t P = (size_t)g->c.seq * g->c.splits;
@@ -413,7 +428,9 @@ int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, flo
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nc = B - b0 < chunk ? B - b0 : chunk;
     HIP_TRY(hipMemcpyAsync(g->tok_cfg, tokens + (size_t)b0 * P, nc * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(g->tok_cfg + nc * P, tokens + (size_t)b0 * P, nc * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    // (the fused pair embedding reads the conditional tokens only: the twins' copy is needed by the two-kernel path and the plain fallback)
+    if (!(pair && !g->c.embed_tables && g->c.bits <= 24))
+      HIP_TRY(hipMemcpyAsync(g->tok_cfg + nc * P, tokens + (size_t)b0 * P, nc * P * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (!(nc == B && g->cfg_labels_ready == labels && g->cfg_ready_B == B)) {   // (mb_sample marks them ready for the steps of one call)
       HIP_TRY(hipMemcpyAsync(g->lab_cfg, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
       HIP_TRY(hipMemcpyAsync(g->lab_cfg + nc, labels + b0, nc * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
@@ -421,6 +438,7 @@ int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, flo
       HIP_TRY(hipMemsetAsync(g->drop_cfg + nc, 1, nc, s));
     }
     float* out = (nc == B) ? logits : g->logits_tmp;    // chunked: through a buffer of the engine's own, then to the two halves of the caller's
+    if (b0 == 0) g_prof.begin_forward(false);           // one guided forward = all of its chunks
     int rc = pair ? gen_forward_pair_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, out, nc, wmode, s)
                   : gen_forward_impl(g, g->tok_cfg, g->lab_cfg, g->drop_cfg, out, 2 * nc, s);
     if (rc) return rc;
@@ -443,7 +461,7 @@ int mb_set_cu_count(int n) { mb::set_cu_count(n); return 0; }
 int mb_prof_enable(int on) {
   if (!on) g_prof.drain();
   g_prof.on = on != 0;
-  if (on) { g_prof.acc.clear(); g_prof.stride = on; g_prof.tick = 0; }
+  if (on) { g_prof.acc.clear(); g_prof.stride = on; g_prof.tick[0] = g_prof.tick[1] = 0; }
   return 0;
 }
 int mb_prof_read(char* buf, int buflen) {
@@ -642,7 +660,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   g->mini_ok = c.cfg_pair >= 2 && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 128 == 0 && c.hidden / c.heads == 64 && !c.weight_split;
   // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
   // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice)
-  g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && !c.prenorm && g->chunk_seqs >= 2 &&
+  g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && g->chunk_seqs >= 2 &&
                (c.cfg_pair == 1 || g->mini_ok);
   if (g->pair_ok) rc |= galloc(g, &g->att_aux, (M / 2) * d);
   if (g->mini_ok) {

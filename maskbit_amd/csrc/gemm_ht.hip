@@ -44,6 +44,13 @@
 
 namespace mb {
 
+// 16-byte slot swizzle of a 128-byte LDS row (DMA source address and fragment read): slot ^ MB_SWZ(row)
+#ifdef MB_SWZ_ROW
+#define MB_SWZ(r) ((r) & 7)
+#else
+#define MB_SWZ(r) (((r) >> 1) & 7)
+#endif
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 // A fragment pair (two 16-byte LDS reads of one lane) lives in ONE 8-VGPR tuple: the e4m3 MFMA takes it whole, the f16 / fp4 MFMAs its halves
@@ -100,8 +107,13 @@ __device__ long long* g_ht_trace = nullptr;
 // K-tile that follows its landing: 8 fragment reads, 16 scaled MFMAs per wave, same two-barrier rhythm and wave-group stagger as the other phases.
 // What the old lo K-tiles (XP = 5) paid -- a K-tile skeleton of eight barriers and a one-K-tile DMA lead for a quarter of a tile's arithmetic,
 // 1.9-2.6 us each -- shrinks to the fifth phase itself; the staging hides under the fp16 K-tiles, whose L2 -> LDS path has the slack.
-template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass, 6 = MX-fp4 mini-tiles
+// HN = true (round 4; plain sequence tiles with mini-tiles, fp32 + residual epilogue): HALF-COLUMN tiles for small batches.  A tile keeps its 256
+// rows but only 32 of every wave's 64 columns (B half `hb` of the 256-column block, staged in the B0 slot; phases (A0, B1) and (A1, B1) multiply
+// nothing), so an N = 1024 GEMM over 16 sequences runs 128 tiles instead of 64 on 256 CUs (FFN-down 145 -> 9x us).  Every output element sees the
+// same K-tiles and mini-tiles in the same order as in a full tile: bit-identical results, so the choice may depend on the batch size.
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, bool HN = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass, 6 = MX-fp4 mini-tiles
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+  static_assert(!HN || (SEQ && !PAIR && XP == 6 && EPI == EPI_RES_F32), "half-column tiles: plain sequence tiles with mini-tiles, residual epilogue");
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   static_assert(!PAIR || (SEQ && XP != 4), "pair tiles are sequence-aligned (fp16 or fp4 lo pass)");
   constexpr bool MINI = XP == 6;
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     int cls;                                 // PAIR: the conditional class-token row of this tile's sequence pair; odd tiles store it
     int q;                                   // PAIR: which 128-token half of the sequence this tile covers
     int seq;                                 // SEQ: the (conditional) sequence of this tile
+    int hb;                                  // HN: which 32-column half of every wave's 64 columns this tile computes
   };
   int dstA[2], dstB[2];                       // byte offset of the instruction inside its half-tile buffer
 #pragma unroll
@@ -164,7 +177,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int rows_sr = min(8, tiles_m - sr * 8);
     const int rem = L - sr * 8 * tiles_n;
     const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
-    p.m0 = PAIR ? (tm >> 1) * 257 + (tm & 1) * 128 : tm * TILE_ROWS; p.n0 = tn * 256;
+    p.m0 = PAIR ? (tm >> 1) * 257 + (tm & 1) * 128 : tm * TILE_ROWS; p.n0 = (HN ? tn >> 1 : tn) * 256;
+    p.hb = HN ? tn & 1 : 0;
     p.cls = PAIR ? (tm >> 1) * 257 + 256 : 0; p.q = tm & 1;
     p.seq = PAIR ? tm >> 1 : tm;
 #pragma unroll
@@ -172,23 +186,23 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       const int ja = min(wave + 8 * j, A_INSTR - 1);   // surplus slot re-loads the last chunk (uniform vmcnt)
       const int hra = ja * 8 + (lane_o >> 3);
       const int wms = hra / (8 * MT), r = hra - wms * (8 * MT);
-      const int slot_a = (lane_o & 7) ^ ((hra >> 1) & 7);
+      const int slot_a = (lane_o & 7) ^ MB_SWZ(hra);
       const int hrb = (wave + 8 * j) * 8 + (lane_o >> 3);
       const int wns = hrb >> 5, c = hrb & 31;
-      const int slot_b = (lane_o & 7) ^ ((hrb >> 1) & 7);
+      const int slot_b = (lane_o & 7) ^ MB_SWZ(hrb);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int gm = PAIR ? p.m0 + h * a.pair_rows + hra : min(p.m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
         p.offA[h][j] = (uint32_t)gm * (uint32_t)KA + slot_a * 8;
-        const int gn = min(p.n0 + wns * 64 + h * 32 + c, a.N - 1);
+        const int gn = min(p.n0 + wns * 64 + (HN ? p.hb : h) * 32 + c, a.N - 1);
         p.offB[h][j] = (uint32_t)gn * (uint32_t)KW + slot_b * 8;
       }
     }
     // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
-    p.offX = (uint32_t)(PAIR ? p.cls + ((lane_o >> 3) == 1 ? a.pair_rows : 0) : min(p.m0 + 256, a.M - 1)) * (uint32_t)KA + ((lane_o & 7) ^ (((lane_o >> 3) >> 1) & 7)) * 8;
+    p.offX = (uint32_t)(PAIR ? p.cls + ((lane_o >> 3) == 1 ? a.pair_rows : 0) : min(p.m0 + 256, a.M - 1)) * (uint32_t)KA + ((lane_o & 7) ^ MB_SWZ(lane_o >> 3)) * 8;
     if (PERM) {
       const int ra = wave * 8 + (lane_o >> 3);                           // row of instruction j = 0 inside its half-tile (A and B alike)
-      const int qa = (lane_o & 7) ^ ((ra >> 1) & 7);
+      const int qa = (lane_o & 7) ^ MB_SWZ(ra);
       p.d8 = (2 * (qa & 3) + (qa >> 2) - qa) * 8;
     }
   };
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   auto dma_x = [&](const Plan& p, int t) {
     MB_TRACE_DMA(t);
     int dx = 0;
-    if (PERM && t >= nka) { int lo_ = lane; asm volatile("" : "+v"(lo_)); const int qx = (lo_ & 7) ^ (((lo_ >> 3) >> 1) & 7); dx = (2 * (qx & 3) + (qx >> 2) - qx) * 8; }
+    if (PERM && t >= nka) { int lo_ = lane; asm volatile("" : "+v"(lo_)); const int qx = (lo_ & 7) ^ MB_SWZ(lo_ >> 3); dx = (2 * (qx & 3) + (qx >> 2) - qx) * 8; }
     if (SEQ && wave == 7) MB_GLDS16_AUX((t < nka ? a.A : Alo) + (p.offX + dx) + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
   };
   auto dma_a = [&](const Plan& p, int t, int h) {
@@ -220,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
   };
   auto dma_b = [&](const Plan& p, int t, int h) {
+    if (HN && h == 1) return;                          // half-column tiles stage one B half (in the B0 slot)
     MB_TRACE_DMA(t);
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
@@ -231,14 +246,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
   };
   // ---- mini-tiles (XP = 6).  nmk per operand set / row half; mini j: set or half ps = j / nmk, K-elements [128 jj, 128 jj + 128), jj = j % nmk.
-  // One DMA instruction covers 16 rows x 64 B (lane -> row lane >> 2, 16-byte chunk lane & 3, swizzled with (row >> 2) & 3 = (lane >> 4) & 3 so
-  // that the 16 lane rows of a fragment read hit 16 distinct bank groups); the per-lane part of the address is the same for both operands.
+  // One DMA instruction covers 16 rows x 64 B (lane -> row lane >> 2, 16-byte chunk lane & 3, swizzled with (row >> 1) & 3 = (lane >> 3) & 3: the
+  // one of seven candidate layouts of 64-byte rows whose ds_read_b128 fragment reads run at the LDS rate -- tools/micro/lds_b128.hip; the first
+  // choice, (row >> 2) & 3, read at half of it: SQ_LDS_BANK_CONFLICT 4.2 M cycles per FFN-up launch); the per-lane part of the address is the same
+  // for both operands.
   const int nmk = K / 128;
   const int nseq = PAIR ? a.pair_rows / 257 : a.M / 257;
   const bool mini_every = MINI && (!PAIR || a.nlo == 2);       // one mini-tile per fp16 K-tile (else one per two)
   auto mini_lane = [&]() -> uint32_t {
     int lo_ = lane; asm volatile("" : "+v"(lo_));
-    return (uint32_t)((lo_ >> 2) * 2 * K + (((lo_ & 3) ^ ((lo_ >> 4) & 3)) * 16));
+    return (uint32_t)((lo_ >> 2) * 2 * K + (((lo_ & 3) ^ ((lo_ >> 3) & 3)) * 16));
   };
   auto mini_dma_a = [&](const Plan& p, int j) {          // 1 instruction per wave
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
@@ -250,6 +267,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
     const uint8_t* base = a.lo[PAIR ? ps : 0].W4;
     int lo_ = lane; asm volatile("" : "+v"(lo_));
+    if constexpr (HN) {                                  // 128 weight rows: wave w stages rows [16 (w & 1), +16) of half hb of wave column w >> 1
+      MB_GLDS16_AUX(base + ((size_t)((p.n0 >> 4) + (wave >> 1) * 4 + p.hb * 2 + (wave & 1)) * nmk + jj) * 1024 + lo_ * 16, smem + MINI_OFF + MINI_A + wave * 1024, AUX);
+      return;
+    }
 #pragma unroll
     for (int jx = 0; jx < 2; ++jx)
       MB_GLDS16_AUX(base + ((size_t)((p.n0 >> 4) + wave + 8 * jx) * nmk + jj) * 1024 + lo_ * 16, smem + MINI_OFF + MINI_A + (wave + 8 * jx) * 1024, AUX);
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int xadd = (l15 == 0 || (PAIR && l15 == 1)) ? 2 * AH_BYTES + 2 * BH_BYTES : 0;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    foff[ks] = l15 * 128 + (((ks * 4 + g) ^ (l15 >> 1)) * 16);
+    foff[ks] = l15 * 128 + (((ks * 4 + g) ^ MB_SWZ(l15)) * 16);
     // class row: only lane row 0 feeds a result that is kept, so the other 15 lane rows read their usual (conflict-free)
     // A-fragment addresses instead of the X buffer -- 16 lanes on the 8 X rows was a 2-way bank conflict on every read
     xoffe[ks] = (l15 == 0 || (PAIR && l15 == 1)) ? 2 * AH_BYTES + 2 * BH_BYTES + foff[ks] : foff[ks];
@@ -339,6 +360,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   acc[N][(AH) * MH + (I)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                        \
       __builtin_shufflevector(mwb[N], mwb[N], 0, 1, 2, 3, -1, -1, -1, -1), __builtin_shufflevector(mxa[I], mxa[I], 0, 1, 2, 3, -1, -1, -1, -1), \
       acc[N][(AH) * MH + (I)], 4, 4, N, mws, I, mxs);
+#define MB_MINI_MMA_HN(AH)                                                                          \
+  MB_MINI_ONE(AH, 0, 0) MB_MINI_ONE(AH, 1, 0) MB_MINI_ONE(AH, 0, 1) MB_MINI_ONE(AH, 1, 1)           \
+  MB_MINI_ONE(AH, 0, 2) MB_MINI_ONE(AH, 1, 2) MB_MINI_ONE(AH, 0, 3) MB_MINI_ONE(AH, 1, 3)           \
+  _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)      \
+    asm volatile("" : "+v"(acc[n][(AH) * MH + i]));
 #define MB_MINI_MMA(AH)                                                                             \
   MB_MINI_ONE(AH, 0, 0) MB_MINI_ONE(AH, 1, 0) MB_MINI_ONE(AH, 2, 0) MB_MINI_ONE(AH, 3, 0)           \
   MB_MINI_ONE(AH, 0, 1) MB_MINI_ONE(AH, 1, 1) MB_MINI_ONE(AH, 2, 1) MB_MINI_ONE(AH, 3, 1)           \
@@ -466,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           int lo_ = lane; \
           asm volatile("" : "+v"(lo_));                  /* opaque: keeps this arithmetic inside the loop (VGPR budget) */ \
           const int r15 = lo_ & 15, gg = lo_ >> 4, sl = f8t ? 2 * gg + ks : ks * 4 + gg; \
-          fo[ks] = r15 * 128 + ((sl ^ (r15 >> 1)) * 16); \
+          fo[ks] = r15 * 128 + ((sl ^ MB_SWZ(r15)) * 16); \
           xo[ks] = r15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + sl * 16 : fo[ks]; \
         } else { fo[ks] = foff[ks]; xo[ks] = LO ? foff[ks] + xadd : xoffe[ks]; } \
       } \
@@ -495,8 +521,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       } \
       MB_MMA(0, 0) \
       /* ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1 */ \
-      MB_LOAD_B(1) \
-      if (SEQ && wm == 1 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
+      if constexpr (!HN) { MB_LOAD_B(1) } \
+      if (!HN && SEQ && wm == 1 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       /* PAIR: the difference rows (A1) take no part in the lo pass (their scale byte is 0): lo K-tiles neither stage nor multiply them */ \
       /* MINI: the next mini-tile's scale dword and A part go out first (older than everything the phase-3 wait leaves in flight) */ \
       const bool mini_issue = MINI && t >= 1 && (mini_every || !(t & 1)); \
@@ -504,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       if (MINI && mini_issue) { mini_scale_issue(cur, mini_j); MB_MINI_X_DMA(mini_dma_a(cur, mini_j);) } \
       if (n1 && !(PAIR && LO && t + 1 >= nka)) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
-      if (SEQ && wm == 1 && cls_on) { \
+      if (!HN && SEQ && wm == 1 && cls_on) { \
         if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<2>(acce[0], wb[1][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<3>(acce[1], wb[1][1], xe, wsc, xs_cur[4]); } } \
         else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<2, 0>(acce[0], wb[1][0], xe, wsc, xscc); acce[1] = mma_f4<3, 0>(acce[1], wb[1][1], xe, wsc, xscc); } } \
         else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, true); } \
@@ -513,12 +539,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         /* cover this pair here): pad before the register moves that end this block */ \
         if (f8t) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
       } \
-      MB_MMA(0, 1) \
+      if constexpr (!HN) { MB_MMA_DO(0, 1) } MB_MMA_END \
       /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
       if (!(PAIR && f8t)) { MB_LOAD_A(1) } \
       if (MINI && mini_issue) { MB_MINI_X_DMA(mini_dma_b(cur, mini_j);) } \
       if (n2) dma_a(cur, t + 2, 0); \
-      MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 1) } MB_MMA_END \
+      MB_SYNC_L() if (!HN && !(PAIR && f8t)) { MB_MMA_DO(1, 1) } MB_MMA_END \
       /* ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed. */ \
       /* In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output */ \
       /* stores stay in flight until the wait of K-tile 1. */ \
@@ -534,6 +560,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         } else if (MINI) {                               /* the mini-tile's scale dword (requested in phase 1) is older than those: tied through, */ \
           /* ONE asm statement for the three cases (see the block-scale wait above) */ \
           const int wsel = __builtin_amdgcn_readfirstlane(n2 ? (wave == 7 ? 2 : 1) : 0); \
+          if constexpr (HN)                              /* (half-column tiles: A0, (X,) B0 of K-tile t+2 stay in flight: 4 / 5 instructions) */ \
+            asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(5)\n\ts_branch 3f\n" \
+                         "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(4)\n3:" \
+                         : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
+          else \
           asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(7)\n\ts_branch 3f\n" \
                        "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(6)\n3:" \
                        : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
@@ -550,15 +581,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           const int mps = __builtin_amdgcn_readfirstlane(mj >= nmk ? 1 : 0); \
           int lo_ = lane; \
           asm volatile("" : "+v"(lo_)); \
-          const int mfo = (lo_ & 15) * 64 + (((lo_ >> 4) ^ ((lo_ >> 2) & 3)) * 16); \
+          const int mfo = (lo_ & 15) * 64 + (((lo_ >> 4) ^ ((lo_ >> 1) & 3)) * 16); \
           const char* mbuf = smem + MINI_OFF; \
           i32x4 mxa[4], mwb[4]; \
           MB_MINI_X_READ( \
-          _Pragma("unroll") for (int n = 0; n < 4; ++n) mwb[n] = *(const i32x4*)(mbuf + MINI_A + (wn * 64 + n * 16) * 64 + mfo); \
+          _Pragma("unroll") for (int n = 0; n < (HN ? 2 : 4); ++n) mwb[n] = *(const i32x4*)(mbuf + MINI_A + (wn * (HN ? 32 : 64) + n * 16) * 64 + mfo); \
           _Pragma("unroll") for (int i = 0; i < 4; ++i) mxa[i] = *(const i32x4*)(mbuf + (wm * 64 + i * 16) * 64 + mfo); ) \
-          const int mws = (PAIR && mps) ? mwsc1 : mwsc0; \
+          const int mws = HN ? (int)((uint32_t)mwsc0 >> (16 * cur.hb)) : ((PAIR && mps) ? mwsc1 : mwsc0); \
           MB_SYNC_L() \
-          MB_MINI_X_MMA(MB_MINI_MMA(MAH)) \
+          MB_MINI_X_MMA(if constexpr (HN) { MB_MINI_MMA_HN(MAH) } else { MB_MINI_MMA(MAH) }) \
           /* (v_mfma_scale results must not be read by a VALU copy too early, see the class-row blocks above) */ \
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
           MB_MMA_END \
@@ -600,11 +631,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256;
     };
     auto col_of = [&](int r, int nt) {
+      if (HN) return n0 + wn * 64 + cur.hb * 32 + (nt & 1) * 16 + ge * 4;      // (this tile's half of the wave's columns; n-tiles 0, 1 only)
       return r < MT ? n0 + wn * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + ge * 4 : n0 + wn * 64 + wm * 32 + nt * 16 + ge * 4;
     };
     auto row_ok = [&](int r) {
       if (PAIR) return r < MT ? true : (l15e < 2 && tq == 1);
-      return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : l15e == 0;
+      return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : (l15e == 0 && (!HN || wm == 0));
     };
     // ---- next tile: start its first two K-tiles NOW (all LDS is free), so they fly during the epilogue math.
     // The bias of THIS tile is fetched in between by inline-asm loads the compiler does not track: vmcnt retires in
@@ -683,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       const float osc = a.scale ? *a.scale : 1.0f;          // split weights: undo their power-of-two pre-scale
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
-        const int nn = r < MT ? 4 : 2;
+        const int nn = (r < MT && !HN) ? 4 : 2;
 #pragma unroll
         for (int nt = 0; nt < nn; ++nt) {
           f32x4& c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
@@ -798,11 +830,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       // L(0) | add(0) L(1) | S(0) add(1) L(2) | S(1) add(2) L(3) | ... : the wait for L(k + 1) leaves S(k) in flight
       affine(0);
       fetch(0);
+      constexpr int NSWEEP = HN ? 1 : 2;                  // (half-column tiles: one sweep, n-tiles 0 and 1)
 #pragma unroll
-      for (int k = 0; k < 2 * NB; ++k) {
+      for (int k = 0; k < NSWEEP * NB; ++k) {
         asm volatile("" ::: "memory");
         add(k);                                           // (waits for L(k); in place on the accumulators: the load registers are free again)
-        if (k + 1 < 2 * NB) { if ((k + 1) % NB == 0) affine((k + 1) / NB); fetch(k + 1); }
+        if (k + 1 < NSWEEP * NB) { if ((k + 1) % NB == 0) affine((k + 1) / NB); fetch(k + 1); }
         asm volatile("" ::: "memory");
         store(k);
       }
@@ -889,8 +922,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #undef MB_F4_ONE
 #undef MB_MINI_ONE
 #undef MB_MINI_MMA
+#undef MB_MINI_MMA_HN
 }
 
+static const bool g_no_half_tiles = getenv("MASKBIT_AMD_NO_HALF_TILES") && atoi(getenv("MASKBIT_AMD_NO_HALF_TILES")) != 0;   // A/B switch (experiments)
 static int g_cu_override = 0;   // mb_set_cu_count: the CUs a persistent grid is sized for (a stream created with a CU mask sees fewer than the device has)
 void set_cu_count(int n) { g_cu_override = n > 0 ? n : 0; }
 static int num_cu_cached() {
@@ -908,22 +943,22 @@ static int num_cu_cached() {
   return num_cu;
 }
 
-template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false>
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, bool HN = false>
 static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) {
   constexpr int BM = 32 * MT;
   constexpr int LDS = 2 * (BM * 128 + 2 * 128 * 128 + (SEQ ? 1024 : 0)) + (XP == 6 ? 128 * 64 + 256 * 64 : 0);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, HN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     configured = true;
   }
-  const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = a.N / 256;
+  const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * (HN ? 2 : 1);
   static const bool f4_persist = !getenv("MASKBIT_AMD_F4_PERSIST") || atoi(getenv("MASKBIT_AMD_F4_PERSIST")) != 0;   // A/B switch (experiments)
   static const bool res_persist = !getenv("MASKBIT_AMD_RES_PERSIST") || atoi(getenv("MASKBIT_AMD_RES_PERSIST")) != 0;   // A/B switch (experiments)
   if (XP == 5 && !f4_persist) persistent = false;
   if (EPI == EPI_RES_F32 && !res_persist) persistent = false;
   const int grid = (XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
-  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, HN>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
@@ -959,7 +994,12 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
     switch (epi) {
       case EPI_H16: if (a.pair_rows) launch_ht<8, EPI_H16, 6, true, true>(s, a, persistent); else launch_ht<8, EPI_H16, 6, true>(s, a, persistent); break;
       case EPI_GELU_H16: if (a.pair_rows) launch_ht<8, EPI_GELU_H16, 6, true, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 6, true>(s, a, persistent); break;
-      case EPI_RES_F32: if (a.pair_rows) launch_ht<8, EPI_RES_F32, 6, true, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 6, true>(s, a, persistent); break;
+      case EPI_RES_F32:
+        if (a.pair_rows) launch_ht<8, EPI_RES_F32, 6, true, true>(s, a, persistent);
+        // few sequences: half-column tiles when whole tiles would leave half of the CUs idle (bit-identical results: see the kernel)
+        else if ((long)(a.M / 257) * (a.N / 256) * 2 <= num_cu_cached() && !g_no_half_tiles) launch_ht<8, EPI_RES_F32, 6, true, false, true>(s, a, persistent);
+        else launch_ht<8, EPI_RES_F32, 6, true>(s, a, persistent);
+        break;
       default: break;
     }
     return;

@@ -94,12 +94,12 @@ struct GemmArgs {
   int nlo = 0;
 };
 // Byte offset of element (row n, K-element k) of an e2m1 WEIGHT operand of the mini-tile passes.  The operand is stored MINI-TILE-PACKED:
-// [N / 16][K / 128] chunks of 1 KiB = 16 rows x 64 B, the 16-byte pieces of a row swizzled with (row >> 2) & 3 -- the LDS image of one DMA
+// [N / 16][K / 128] chunks of 1 KiB = 16 rows x 64 B, the 16-byte pieces of a row swizzled with (row >> 1) & 3 -- the LDS image of one DMA
 // instruction, so that every instruction of a weight mini-tile reads 1 KiB of CONTIGUOUS memory (8 full 128-byte lines) instead of 16 half lines
 // of a row-major operand (measured: the L2 -> LDS path pays per line, not per byte -- profiles/r04_gemm_minitiles.md).  N % 16 == 0, K % 128 == 0.
 __host__ __device__ inline size_t w4_packed_offset(int n, int k, int K) {
   const int r = n & 15, c = (k & 127) >> 5;
-  return ((size_t)(n >> 4) * (K >> 7) + (k >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + ((k & 31) >> 1);
+  return ((size_t)(n >> 4) * (K >> 7) + (k >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 1) & 3)) << 4) + ((k & 31) >> 1);
 }
 // byte index of the scale of (token row r of sequence seq, 64-column block blk) in the lane-ordered scale arrays of the mini-tile passes
 __host__ __device__ inline size_t fp4_scale_index(int blk, int nseq, int seq, int r) {

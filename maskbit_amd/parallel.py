@@ -19,9 +19,13 @@ of the uint8 block) and no host synchronisation; only ragged batches exchange bl
 """
 from __future__ import annotations
 
+import warnings
 from typing import List, Optional, Tuple
 
 import torch
+
+
+_WARNED_DEFAULT_NOISE = False
 
 
 def shard_range(rank: int, world: int, batch: int) -> Tuple[int, int]:
@@ -71,12 +75,15 @@ def gather_images(local: torch.Tensor, group=None, equal: Optional[bool] = None)
 
 
 @torch.no_grad()
-def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: str = "rank", group=None,
+def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: Optional[str] = None, group=None,
                    num_steps: int = 64, guidance_scale: float = 7.1, guidance_annealing: str = "cosine", scale_pow: float = 3.0,
                    softmax_temperature: float = 1.0, use_sampling_annealing: bool = False, randomize_temperature: float = 8.2,
                    mask_schedule_strategy: str = "arccos") -> torch.Tensor:
     """Sample ``len(global_labels)`` images across the process group; every rank returns all images,
-    uint8 NHWC, identical on every rank (and, with ``noise="batch"``, identical to a 1-GPU run of the same seed; see the module docstring)."""
+    uint8 NHWC, identical on every rank (and, with ``noise="batch"``, identical to a 1-GPU run of the same seed; see the module docstring).
+    ``noise`` left at None means "rank" (every rank draws its own shard's noise from ITS generators): with more than one rank this warns once,
+    because a caller that seeds every rank identically -- what ``noise="batch"``, the default until round 3, wanted -- would then draw the same
+    noise on every rank.  Pass ``noise="rank"`` (and seed the ranks differently) or ``noise="batch"`` explicitly."""
     import torch.distributed as dist
     from .sampling import _ForcedPlan, build_plan, draw_noise, plan_arrays, run_loop, step_chunks
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -89,6 +96,14 @@ def sample_sharded(model, vqgan_model, global_labels: torch.Tensor, *, noise: st
     if guidance_scale != 0.0 and not any(a != 0.0 for a in plan[0]):
         plan = _ForcedPlan(plan)                      # as sample(): the CFG forward runs even when every annealed scale is 0
     dev = model.device
+    if noise is None:
+        noise = "rank"
+        global _WARNED_DEFAULT_NOISE
+        if world > 1 and not _WARNED_DEFAULT_NOISE:
+            _WARNED_DEFAULT_NOISE = True
+            warnings.warn("sample_sharded: noise left at its default ('rank'): every rank draws its own shard's noise from its own generators -- "
+                          "seed the ranks differently (torch.manual_seed(seed + rank)), or pass noise='batch' for the single-device-identical mode",
+                          stacklevel=2)
     if noise not in ("batch", "rank"):
         raise ValueError("noise must be 'batch' or 'rank'")
     nb = B if noise == "batch" else hi - lo           # the batch the noise is drawn for; chunked by steps to bound its memory (sampling.step_chunks)

@@ -123,6 +123,7 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # "trained-like" weights (heavy-tailed, six massive-activation channels: maskbit_amd/synth.py _trained_like) -- what per-row / per-block MX-fp4
     # scales and fp16 activations are sensitive to and Gaussian draws do not show
     "sample_full14_256_s3": (14, 181, 12.0, 4, CFG5_256, False, 4325, 8),
+    "sample_full10_16_nocfg_s3": (10, 182, 12.0, 16, CFG1_16, False, 4330, 0),
     "sample_full12_64_outlier": (12, 190, 12.0, 4, FULL64, False, 4326, 2, "outlier"),
     "sample_full10_16_nocfg_outlier": (10, 191, 12.0, 16, CFG1_16, False, 4327, 0, "outlier"),
     # the two generator variants whose guided forward does not run in differential form on the engine (it falls back to the plain forward over

@@ -106,12 +106,12 @@ def f4_encode_rows(v: torch.Tensor, nseq: int, dev="cuda"):
 
 def w4_decode(w4: torch.Tensor, wsb: torch.Tensor, N: int, K: int) -> torch.Tensor:
     """e2m1 weight operand in the mini-tile-packed layout (mb_kernels.h w4_packed_offset: [N / 16][K / 128] chunks of 16 rows x 64 B, the 16-byte
-    pieces of a row swizzled with (row >> 2) & 3) + its lane-ordered per-row scale bytes (mb_w4_from_f32 / mb_w4lo_from_f32) -> float64 [N, K] on
+    pieces of a row swizzled with (row >> 1) & 3) + its lane-ordered per-row scale bytes (mb_w4_from_f32 / mb_w4lo_from_f32) -> float64 [N, K] on
     the device of w4."""
     n = torch.arange(N, device=wsb.device)
     row = wsb[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)].to(torch.float64)
     nn, kk = torch.meshgrid(torch.arange(N), torch.arange(0, K, 2), indexing="ij")         # byte of elements (k, k + 1)
     r, c = nn & 15, (kk & 127) >> 5
-    off = ((nn >> 4) * (K >> 7) + (kk >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + ((kk & 31) >> 1)
+    off = ((nn >> 4) * (K >> 7) + (kk >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 1) & 3)) << 4) + ((kk & 31) >> 1)
     rowmajor = w4.reshape(-1).cpu()[off.reshape(-1)].reshape(N, K // 2)
     return f4_decode(rowmajor, K).to(w4.device) * (2.0 ** (row - 127)).reshape(N, 1)

@@ -165,6 +165,26 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
         torch.cuda.empty_cache()
 
 
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name,expect,bound", [("sample_full12_64_prenorm", (0, 2), 8e-4), ("sample_full12_64_seq1024", (3, 0), 1e-3)])
+def test_generator_variants_full_width_vs_reference_runs(name, expect, bound):
+    """configs[2]'s sampler (64 steps, CFG 7.1 cosine) on the two generator variants of the reference that differ in how the engine runs the guided
+    forward, against full-width runs of the REAL reference (oracle/make_golden.py RUNS):
+      * use_prenorm=True (bert.py:49-59, 106-123): since round 4 the guided forward runs in differential form here too (the LayerNorm pair kernel in
+        front of each sub-layer, the raw residual in the stream buffer) with the weight-correction mini-tiles -- as independent streams the same
+        mini-tiles measured 1.44e-3 (guidance multiplies the two streams' separate fp16 roundings), hi + lo activation pairs 8.4e-4;
+      * 1024 + 1 tokens (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144): no pair tiles for this sequence length; the guided forward is the
+        plain forward over [cond | uncond] with hi + lo activation pairs (act_split 3), measured 7.6e-4 (single fp16: 1.11e-3)."""
+    import parity_replay as R
+    g = R.load_run(name)
+    gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
+    assert gen.resolved_precision() == expect
+    noise = R.reference_noise(g, gen.device)
+    bad, tot, per, _ = R.teacher_forced(gen, g, noise)
+    print(f"{name} [product default, resolves to {gen.resolved_precision()}]: {bad}/{tot} = {bad / tot:.2e}; per eighth {[sum(per[i:i + 8]) for i in range(0, 64, 8)]}")
+    assert bad / tot <= bound
+
+
 def _full_length_run(bits, num_steps, B, kw, seed):
     """A complete free-running mb_sample of a BASELINE configuration at full size and full length, checked through the size-independent
     properties of the loop (sampling.py:81-131): the run is deterministic; it equals, bit for bit, the step-by-step composition

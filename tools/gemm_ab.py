@@ -1,5 +1,6 @@
 """A/B of two builds of the library on the four trunk pair GEMMs inside one process: tools/_ab/lib_prev.so (a copy of an earlier build) against the
-product library, alternated, 64 sequence pairs.  usage: cp maskbit_amd/libmaskbit_hip.so tools/_ab/lib_prev.so; <change, rebuild>; python tools/gemm_ab.py"""
+product library, alternated, 64 sequence pairs (GEMM_AB_MINI = n: with n MX-fp4 mini-tile operand sets).
+usage: cp maskbit_amd/libmaskbit_hip.so tools/_ab/lib_prev.so; <change, rebuild>; python tools/gemm_ab.py"""
 import ctypes as C
 import os, sys
 import torch
@@ -9,11 +10,13 @@ from maskbit_amd import _lib
 
 
 def main():
-    sig = _lib.SIGNATURES["mb_gemm_pair"]
+    sig = _lib.SIGNATURES["mb_gemm_mini"]
+    nlo = int(os.environ.get("GEMM_AB_MINI", "0"))
     libs = {}
     for name, path in (("previous", os.path.join(ROOT, "tools", "_ab", "lib_prev.so")), ("product", os.path.join(ROOT, "maskbit_amd", "libmaskbit_hip.so"))):
         l = C.CDLL(path)
-        l.mb_gemm_pair.restype, l.mb_gemm_pair.argtypes = sig
+        l.mb_gemm_mini.restype, l.mb_gemm_mini.argtypes = sig
+        l.mb_w4_from_f32.restype, l.mb_w4_from_f32.argtypes = _lib.SIGNATURES["mb_w4_from_f32"]
         libs[name] = l
     dev = torch.device("cuda")
     st = torch.cuda.current_stream().cuda_stream
@@ -30,11 +33,21 @@ def main():
         res = torch.randn(M, N, device=dev) if epi == 2 else None
         outs = {}
         acc = {k: [] for k in libs}
+        sets = {}
+        for k, l in libs.items():                        # each build packs its own e2m1 weight operand (the layout may differ between builds)
+            ts = []
+            for _ in range(nlo):
+                x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8, generator=torch.Generator(device=dev).manual_seed(1))
+                xsb = torch.full(((K // 64) * 64 * 256 + 256,), 100, device=dev, dtype=torch.uint8)
+                w4 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); ws = torch.zeros(N, device=dev, dtype=torch.uint8)
+                assert l.mb_w4_from_f32(W.float().data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), st) == 0
+                ts += [x4, xsb, w4, ws]
+            sets[k] = (ts, (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts]))
         for rnd in range(4):
             for k, l in (list(libs.items()) if rnd % 2 == 0 else list(libs.items())[::-1]):
                 o32 = res.clone() if epi == 2 else None
                 o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
-                fn = lambda: l.mb_gemm_pair(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), P, N, K, None, None, None, None, st)
+                fn = lambda: l.mb_gemm_mini(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), None, None, P, 1, N, K, nlo, sets[k][1], st)
                 assert fn() == 0
                 torch.cuda.synchronize()
                 outs[k] = (o32 if epi == 2 else o16).clone()

@@ -7,10 +7,12 @@ import torch
 from maskbit_amd import parity_replay as R
 
 GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C3_S2, R.RUN_C3_S3],
-          "configs[1] 10-bit / 16 steps / no CFG": [R.RUN_CFG1, R.RUN_CFG1_S2],
+          "configs[1] 10-bit / 16 steps / no CFG": [R.RUN_CFG1, R.RUN_CFG1_S2, R.RUN_CFG1_S3],
           "configs[4] 14-bit / 256 steps / CFG 5.8": [R.RUN_CFG5, R.RUN_CFG5_S2, R.RUN_CFG5_S3],
           "trained-like weights (heavy tails, massive-activation channels): configs[2]": [R.RUN_C3_OUTLIER],
-          "trained-like weights: configs[1]": [R.RUN_CFG1_OUTLIER]}
+          "trained-like weights: configs[1]": [R.RUN_CFG1_OUTLIER],
+          "use_prenorm=True, configs[2]'s sampler (guided forward = plain forward over [cond | uncond])": [R.RUN_C3_PRENORM],
+          "1024 + 1 tokens (512 x 512 models), configs[2]'s sampler (guided forward = plain forward over [cond | uncond])": [R.RUN_C3_SEQ1024]}
 MODES = (("default", -1, -1), ("differential only (cfg_pair = 1)", -1, 1))
 if os.environ.get("PARITY_MODES"):            # e.g. PARITY_MODES="default:-1:-1,fp16:0:0"
     MODES = tuple((t.split(":")[0], int(t.split(":")[1]), int(t.split(":")[2])) for t in os.environ["PARITY_MODES"].split(","))

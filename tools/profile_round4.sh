@@ -1,14 +1,15 @@
 #!/bin/bash
-# Round-2 rocprofv3 evidence on the GPU box (run through gpurun from the repo root):  bash tools/profile_round2.sh <tag>
+# Round-4 rocprofv3 evidence of the product default (guided forward with the weight-correction mini-tiles) on the GPU box (run through gpurun from the repo root):  bash tools/profile_round4.sh <tag>
 #   -> gpurun_out/prof_<tag>/{kt, pmc/<gemm>.<counter>, pmc/dec.<counter>}
 # Kernel-trace statistics of the default bench workload, then separate --pmc passes (never combined with other trace domains) over the
 # trunk GEMM shapes as the guided forward runs them (CFG pair tiles) and over the decoder.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export PAIR_ONE_MINI=1
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-modes > $OUT/bench_under_rocprof.log 2>&1
 for shape in qkv attn_out ffn_up ffn_down; do
