@@ -107,12 +107,15 @@ __device__ long long* g_ht_trace = nullptr;
 // K-tile that follows its landing: 8 fragment reads, 16 scaled MFMAs per wave, same two-barrier rhythm and wave-group stagger as the other phases.
 // What the old lo K-tiles (XP = 5) paid -- a K-tile skeleton of eight barriers and a one-K-tile DMA lead for a quarter of a tile's arithmetic,
 // 1.9-2.6 us each -- shrinks to the fifth phase itself; the staging hides under the fp16 K-tiles, whose L2 -> LDS path has the slack.
-// HN = true (round 4; plain sequence tiles with mini-tiles, fp32 + residual epilogue): HALF-COLUMN tiles for small batches.  A tile keeps its 256
-// rows but only 32 of every wave's 64 columns (B half `hb` of the 256-column block, staged in the B0 slot; phases (A0, B1) and (A1, B1) multiply
-// nothing), so an N = 1024 GEMM over 16 sequences runs 128 tiles instead of 64 on 256 CUs (FFN-down 145 -> 9x us).  Every output element sees the
+// NS = 2 / 4 (round 4; plain sequence tiles with mini-tiles, fp32 + residual epilogue): HALF- / QUARTER-COLUMN tiles for small batches.  A tile keeps
+// its 256 rows but only 64 / NS of every wave's 64 columns (column block `hb` of the 256-column tile, staged in the B0 slot; phases (A0, B1) and
+// (A1, B1) multiply nothing), so an N = 1024 GEMM over 16 sequences runs 128 / 256 tiles instead of 64 on 256 CUs.  Every output element sees the
 // same K-tiles and mini-tiles in the same order as in a full tile: bit-identical results, so the choice may depend on the batch size.
-template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, bool HN = false>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass, 6 = MX-fp4 mini-tiles
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, int NS = 1>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass, 6 = MX-fp4 mini-tiles
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+  constexpr bool HN = NS > 1, QN = NS == 4;
+  constexpr int NTW = 4 / NS;                          // n-tiles of a wave
+  static_assert(NS == 1 || NS == 2 || NS == 4, "column split");
   static_assert(!HN || (SEQ && !PAIR && XP == 6 && EPI == EPI_RES_F32), "half-column tiles: plain sequence tiles with mini-tiles, residual epilogue");
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
   static_assert(!PAIR || (SEQ && XP != 4), "pair tiles are sequence-aligned (fp16 or fp4 lo pass)");
@@ -164,11 +167,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     int cls;                                 // PAIR: the conditional class-token row of this tile's sequence pair; odd tiles store it
     int q;                                   // PAIR: which 128-token half of the sequence this tile covers
     int seq;                                 // SEQ: the (conditional) sequence of this tile
-    int hb;                                  // HN: which 32-column half of every wave's 64 columns this tile computes
+    int hb;                                  // NS > 1: which 64 / NS-column block of every wave's 64 columns this tile computes
   };
   int dstA[2], dstB[2];                       // byte offset of the instruction inside its half-tile buffer
 #pragma unroll
-  for (int j = 0; j < 2; ++j) { dstA[j] = min(wave + 8 * j, A_INSTR - 1) * 1024; dstB[j] = (wave + 8 * j) * 1024; }
+  for (int j = 0; j < 2; ++j) { dstA[j] = min(wave + 8 * j, A_INSTR - 1) * 1024; dstB[j] = (QN ? (wave >> 1) * 4 + (wave & 1) : wave + 8 * j) * 1024; }
   auto make_plan = [&](int vb, Plan& p) {
     int lane_o = lane;                                 // opaque copy: keeps the plan's lane arithmetic from being hoisted
     asm volatile("" : "+v"(lane_o));                   // out of the tile loop and held in VGPRs across the K loop
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int rows_sr = min(8, tiles_m - sr * 8);
     const int rem = L - sr * 8 * tiles_n;
     const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
-    p.m0 = PAIR ? (tm >> 1) * 257 + (tm & 1) * 128 : tm * TILE_ROWS; p.n0 = (HN ? tn >> 1 : tn) * 256;
-    p.hb = HN ? tn & 1 : 0;
+    p.m0 = PAIR ? (tm >> 1) * 257 + (tm & 1) * 128 : tm * TILE_ROWS; p.n0 = (tn / NS) * 256;
+    p.hb = tn % NS;
     p.cls = PAIR ? (tm >> 1) * 257 + 256 : 0; p.q = tm & 1;
     p.seq = PAIR ? tm >> 1 : tm;
 #pragma unroll
@@ -187,14 +190,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       const int hra = ja * 8 + (lane_o >> 3);
       const int wms = hra / (8 * MT), r = hra - wms * (8 * MT);
       const int slot_a = (lane_o & 7) ^ MB_SWZ(hra);
-      const int hrb = (wave + 8 * j) * 8 + (lane_o >> 3);
+      const int hrb = (QN ? (wave >> 1) * 4 + (wave & 1) : wave + 8 * j) * 8 + (lane_o >> 3);   // (quarter-column tiles: 16 of a wave column's 32 slot rows, one instruction per wave)
       const int wns = hrb >> 5, c = hrb & 31;
       const int slot_b = (lane_o & 7) ^ MB_SWZ(hrb);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int gm = PAIR ? p.m0 + h * a.pair_rows + hra : min(p.m0 + wms * (16 * MT) + h * (8 * MT) + r, a.M - 1);
         p.offA[h][j] = (uint32_t)gm * (uint32_t)KA + slot_a * 8;
-        const int gn = min(p.n0 + wns * 64 + (HN ? p.hb : h) * 32 + c, a.N - 1);
+        const int gn = min(p.n0 + wns * 64 + (HN ? p.hb * (64 / NS) : h * 32) + c, a.N - 1);
         p.offB[h][j] = (uint32_t)gn * (uint32_t)KW + slot_b * 8;
       }
     }
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     MB_TRACE_DMA(t);
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < (QN ? 1 : 2); ++j) {
       uint32_t o = (SEQ && LO) ? p.offB[0][0] + ((PERM && t >= nkw) ? p.d8 : 0) : p.offB[h][j];
       if (LO) asm volatile("" : "+v"(o));
       const uint32_t u = (SEQ && LO) ? (uint32_t)(h * 32 + j * 128) * (uint32_t)KW : 0u;
@@ -267,6 +270,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
     const uint8_t* base = a.lo[PAIR ? ps : 0].W4;
     int lo_ = lane; asm volatile("" : "+v"(lo_));
+    if constexpr (QN) {                                  // 64 weight rows: waves 0..3 stage the 16 rows of block hb of wave column w
+      if (wave < 4) MB_GLDS16_AUX(base + ((size_t)((p.n0 >> 4) + wave * 4 + p.hb) * nmk + jj) * 1024 + lo_ * 16, smem + MINI_OFF + MINI_A + wave * 1024, AUX);
+      return;
+    }
     if constexpr (HN) {                                  // 128 weight rows: wave w stages rows [16 (w & 1), +16) of half hb of wave column w >> 1
       MB_GLDS16_AUX(base + ((size_t)((p.n0 >> 4) + (wave >> 1) * 4 + p.hb * 2 + (wave & 1)) * nmk + jj) * 1024 + lo_ * 16, smem + MINI_OFF + MINI_A + wave * 1024, AUX);
       return;
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
       xa[i] = frag_set(xa[i], *(const h16x8*)(par + (H) * AH_BYTES + xbase + i * 16 * 128 + fo[ks]), ks);
 #define MB_LOAD_B(H)                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+  _Pragma("unroll") for (int i = 0; i < (QN ? 1 : 2); ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
       wb[H][i] = frag_set(wb[H][i], *(const h16x8*)(par + wbase + (H) * BH_BYTES + i * 16 * 128 + fo[ks]), ks);
 #define MB_SYNC_L()                                     \
   __builtin_amdgcn_s_barrier();                         \
@@ -360,6 +367,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   acc[N][(AH) * MH + (I)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                        \
       __builtin_shufflevector(mwb[N], mwb[N], 0, 1, 2, 3, -1, -1, -1, -1), __builtin_shufflevector(mxa[I], mxa[I], 0, 1, 2, 3, -1, -1, -1, -1), \
       acc[N][(AH) * MH + (I)], 4, 4, N, mws, I, mxs);
+#define MB_MINI_MMA_QN(AH)                                                                          \
+  MB_MINI_ONE(AH, 0, 0) MB_MINI_ONE(AH, 0, 1) MB_MINI_ONE(AH, 0, 2) MB_MINI_ONE(AH, 0, 3)           \
+  _Pragma("unroll") for (int i = 0; i < MH; ++i) asm volatile("" : "+v"(acc[0][(AH) * MH + i]));
 #define MB_MINI_MMA_HN(AH)                                                                          \
   MB_MINI_ONE(AH, 0, 0) MB_MINI_ONE(AH, 1, 0) MB_MINI_ONE(AH, 0, 1) MB_MINI_ONE(AH, 1, 1)           \
   MB_MINI_ONE(AH, 0, 2) MB_MINI_ONE(AH, 1, 2) MB_MINI_ONE(AH, 0, 3) MB_MINI_ONE(AH, 1, 3)           \
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
         asm volatile("" : "+v"(acc[(BH) * 2 + n][(AH) * MH + i]));                                  \
     } else {                                                                                        \
-      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
+      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < (QN ? 1 : 2); ++n)  \
         acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], false); \
     }                                                                                               \
   }
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<0>(acce[0], wb[0][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<1>(acce[1], wb[0][1], xe, wsc, xs_cur[4]); } } \
         else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<0, 0>(acce[0], wb[0][0], xe, wsc, xscc); acce[1] = mma_f4<1, 0>(acce[1], wb[0][1], xe, wsc, xscc); } } \
         else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, true); } \
-        else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, false); } \
+        else { _Pragma("unroll") for (int n = 0; n < (QN ? 1 : 2); ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, false); } \
         /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
         /* cover this pair here): pad before the register moves that end this block */ \
         if (f8t) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
@@ -560,7 +570,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         } else if (MINI) {                               /* the mini-tile's scale dword (requested in phase 1) is older than those: tied through, */ \
           /* ONE asm statement for the three cases (see the block-scale wait above) */ \
           const int wsel = __builtin_amdgcn_readfirstlane(n2 ? (wave == 7 ? 2 : 1) : 0); \
-          if constexpr (HN)                              /* (half-column tiles: A0, (X,) B0 of K-tile t+2 stay in flight: 4 / 5 instructions) */ \
+          if constexpr (QN)                              /* (quarter-column tiles: A0, (X,) B0 of K-tile t+2 stay in flight: 3 / 4 instructions) */ \
+            asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(4)\n\ts_branch 3f\n" \
+                         "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(3)\n3:" \
+                         : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
+          else if constexpr (HN)                         /* (half-column tiles: 4 / 5 instructions) */ \
             asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(5)\n\ts_branch 3f\n" \
                          "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(4)\n3:" \
                          : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
@@ -585,11 +599,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           const char* mbuf = smem + MINI_OFF; \
           i32x4 mxa[4], mwb[4]; \
           MB_MINI_X_READ( \
-          _Pragma("unroll") for (int n = 0; n < (HN ? 2 : 4); ++n) mwb[n] = *(const i32x4*)(mbuf + MINI_A + (wn * (HN ? 32 : 64) + n * 16) * 64 + mfo); \
+          _Pragma("unroll") for (int n = 0; n < NTW; ++n) mwb[n] = *(const i32x4*)(mbuf + MINI_A + (wn * (64 / NS) + n * 16) * 64 + mfo); \
           _Pragma("unroll") for (int i = 0; i < 4; ++i) mxa[i] = *(const i32x4*)(mbuf + (wm * 64 + i * 16) * 64 + mfo); ) \
-          const int mws = HN ? (int)((uint32_t)mwsc0 >> (16 * cur.hb)) : ((PAIR && mps) ? mwsc1 : mwsc0); \
+          const int mws = HN ? (int)((uint32_t)mwsc0 >> ((32 / NS) * cur.hb)) : ((PAIR && mps) ? mwsc1 : mwsc0); \
           MB_SYNC_L() \
-          MB_MINI_X_MMA(if constexpr (HN) { MB_MINI_MMA_HN(MAH) } else { MB_MINI_MMA(MAH) }) \
+          MB_MINI_X_MMA(if constexpr (QN) { MB_MINI_MMA_QN(MAH) } else if constexpr (HN) { MB_MINI_MMA_HN(MAH) } else { MB_MINI_MMA(MAH) }) \
           /* (v_mfma_scale results must not be read by a VALU copy too early, see the class-row blocks above) */ \
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
           MB_MMA_END \
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256;
     };
     auto col_of = [&](int r, int nt) {
-      if (HN) return n0 + wn * 64 + cur.hb * 32 + (nt & 1) * 16 + ge * 4;      // (this tile's half of the wave's columns; n-tiles 0, 1 only)
+      if (HN) return n0 + wn * 64 + cur.hb * (64 / NS) + (nt & (NTW - 1)) * 16 + ge * 4;      // (this tile's block of the wave's columns)
       return r < MT ? n0 + wn * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + ge * 4 : n0 + wn * 64 + wm * 32 + nt * 16 + ge * 4;
     };
     auto row_ok = [&](int r) {
@@ -715,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       const float osc = a.scale ? *a.scale : 1.0f;          // split weights: undo their power-of-two pre-scale
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
-        const int nn = (r < MT && !HN) ? 4 : 2;
+        const int nn = r < MT ? NTW : (QN ? 1 : 2);
 #pragma unroll
         for (int nt = 0; nt < nn; ++nt) {
           f32x4& c = r < MT ? acc[nt][r < MT ? r : 0] : acce[nt & 1];
@@ -783,6 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       // ~6.5-6.9 TB/s of mixed read + write traffic, profiles/r03_power_and_streams.md section 6.)
       constexpr int NB = MT / RB;                       // batches per sweep
       static_assert(MT % RB == 0, "whole batches");
+      constexpr int NQ = QN ? 1 : 2;                      // n-tiles per sweep (quarter-column tiles: one, 64-byte row segments)
       float4 rv[RB][2];
       float2 sv[RB] = {};
       auto fetch = [&](int k) {                         // batch k: sweep p = k / NB (n-tiles 2p, 2p + 1: one 128-byte line per row), rows (k % NB) * RB ..
@@ -791,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         for (int j = 0; j < RB; ++j) {
           const uint32_t rowc = (uint32_t)min(row_of(r0 + j), a.M - 1);                // clamped: always a legal address
 #pragma unroll
-          for (int q = 0; q < 2; ++q) rv[j][q] = *(const float4*)((const char*)resp + (size_t)((rowc * (uint32_t)a.N + (uint32_t)col_of(r0 + j, 2 * p + q)) * 4u));
+          for (int q = 0; q < NQ; ++q) rv[j][q] = *(const float4*)((const char*)resp + (size_t)((rowc * (uint32_t)a.N + (uint32_t)col_of(r0 + j, 2 * p + q)) * 4u));
           if (lnres) sv[j] = *(const float2*)(a.ln_stats + 2 * (size_t)rowc);
         }
       };
@@ -805,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       auto affine = [&](int p) {
         if (lnres) {
 #pragma unroll
-          for (int q = 0; q < 2; ++q) { gm[q] = *(const f32x4*)(a.ln_g + col_of(0, 2 * p + q)); bt[q] = *(const f32x4*)(a.ln_b + col_of(0, 2 * p + q)); }
+          for (int q = 0; q < NQ; ++q) { gm[q] = *(const f32x4*)(a.ln_g + col_of(0, 2 * p + q)); bt[q] = *(const f32x4*)(a.ln_b + col_of(0, 2 * p + q)); }
         }
       };
       auto add = [&](int k) {
@@ -813,7 +828,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
         for (int j = 0; j < RB; ++j)
 #pragma unroll
-          for (int q = 0; q < 2; ++q) add_one(acc[2 * p + q][r0 + j], rv[j][q], sv[j], gm[q], bt[q]);
+          for (int q = 0; q < NQ; ++q) add_one(acc[2 * p + q][r0 + j], rv[j][q], sv[j], gm[q], bt[q]);
       };
       auto store_one = [&](const f32x4& c, int r, int nt) {
         *(float4*)((char*)out32 + (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)col_of(r, nt)) * 4u)) = make_float4(c[0], c[1], c[2], c[3]);
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         for (int j = 0; j < RB; ++j)
           if (row_ok(r0 + j)) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) store_one(acc[2 * p + q][r0 + j], r0 + j, 2 * p + q);
+            for (int q = 0; q < NQ; ++q) store_one(acc[2 * p + q][r0 + j], r0 + j, 2 * p + q);
           }
       };
       // L(0) | add(0) L(1) | S(0) add(1) L(2) | S(1) add(2) L(3) | ... : the wait for L(k + 1) leaves S(k) in flight
@@ -843,16 +858,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         float4 rr[2]; float2 st = {};
         const uint32_t rowc = (uint32_t)min(row_of(MT), a.M - 1);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           rr[q] = *(const float4*)((const char*)resp + (size_t)((rowc * (uint32_t)a.N + (uint32_t)col_of(MT, q)) * 4u));
           if (lnres) { gm[q] = *(const f32x4*)(a.ln_g + col_of(MT, q)); bt[q] = *(const f32x4*)(a.ln_b + col_of(MT, q)); }
         }
         if (lnres) st = *(const float2*)(a.ln_stats + 2 * (size_t)rowc);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) add_one(acce[q], rr[q], st, gm[q], bt[q]);
+        for (int q = 0; q < NQ; ++q) add_one(acce[q], rr[q], st, gm[q], bt[q]);
         if (row_ok(MT)) {
 #pragma unroll
-          for (int q = 0; q < 2; ++q) store_one(acce[q], MT, q);
+          for (int q = 0; q < NQ; ++q) store_one(acce[q], MT, q);
         }
       }
     } else {
@@ -923,9 +938,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #undef MB_MINI_ONE
 #undef MB_MINI_MMA
 #undef MB_MINI_MMA_HN
+#undef MB_MINI_MMA_QN
 }
 
-static const bool g_no_half_tiles = getenv("MASKBIT_AMD_NO_HALF_TILES") && atoi(getenv("MASKBIT_AMD_NO_HALF_TILES")) != 0;   // A/B switch (experiments)
+static const int g_col_split = getenv("MASKBIT_AMD_COL_SPLIT") ? atoi(getenv("MASKBIT_AMD_COL_SPLIT")) : 4;   // A/B switch (experiments): largest column split of small-batch tiles (1 = whole tiles only)
 static int g_cu_override = 0;   // mb_set_cu_count: the CUs a persistent grid is sized for (a stream created with a CU mask sees fewer than the device has)
 void set_cu_count(int n) { g_cu_override = n > 0 ? n : 0; }
 static int num_cu_cached() {
@@ -943,22 +959,22 @@ static int num_cu_cached() {
   return num_cu;
 }
 
-template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, bool HN = false>
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, int NS = 1>
 static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) {
   constexpr int BM = 32 * MT;
   constexpr int LDS = 2 * (BM * 128 + 2 * 128 * 128 + (SEQ ? 1024 : 0)) + (XP == 6 ? 128 * 64 + 256 * 64 : 0);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, HN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     configured = true;
   }
-  const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * (HN ? 2 : 1);
+  const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * NS;
   static const bool f4_persist = !getenv("MASKBIT_AMD_F4_PERSIST") || atoi(getenv("MASKBIT_AMD_F4_PERSIST")) != 0;   // A/B switch (experiments)
   static const bool res_persist = !getenv("MASKBIT_AMD_RES_PERSIST") || atoi(getenv("MASKBIT_AMD_RES_PERSIST")) != 0;   // A/B switch (experiments)
   if (XP == 5 && !f4_persist) persistent = false;
   if (EPI == EPI_RES_F32 && !res_persist) persistent = false;
   const int grid = (XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
-  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, HN>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, NS>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
@@ -996,8 +1012,9 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
       case EPI_GELU_H16: if (a.pair_rows) launch_ht<8, EPI_GELU_H16, 6, true, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 6, true>(s, a, persistent); break;
       case EPI_RES_F32:
         if (a.pair_rows) launch_ht<8, EPI_RES_F32, 6, true, true>(s, a, persistent);
-        // few sequences: half-column tiles when whole tiles would leave half of the CUs idle (bit-identical results: see the kernel)
-        else if ((long)(a.M / 257) * (a.N / 256) * 2 <= num_cu_cached() && !g_no_half_tiles) launch_ht<8, EPI_RES_F32, 6, true, false, true>(s, a, persistent);
+        // few sequences: quarter- / half-column tiles when whole tiles would leave three quarters / half of the CUs idle (bit-identical results: see the kernel)
+        else if ((long)(a.M / 257) * (a.N / 256) * 4 <= num_cu_cached() && g_col_split >= 4) launch_ht<8, EPI_RES_F32, 6, true, false, 4>(s, a, persistent);
+        else if ((long)(a.M / 257) * (a.N / 256) * 2 <= num_cu_cached() && g_col_split >= 2) launch_ht<8, EPI_RES_F32, 6, true, false, 2>(s, a, persistent);
         else launch_ht<8, EPI_RES_F32, 6, true>(s, a, persistent);
         break;
       default: break;
