@@ -47,8 +47,8 @@ typedef struct {
    * Checkpoint keys then are tok_emb_list.{g}.weight and bias.{g} instead of input_proj.* / prediction_layer.*. */
   int prenorm;
   int embed_tables;
-  /* Activation precision of the trunk GEMMs in the PLAIN forward when the weight-correction mode below does not serve it (explicit modes; the
-   * default resolves to 0 with cfg_pair >= 2): 0 = one fp16 value per element; 1 = fp16 hi + lo pairs for the LayerNorm outputs (QKV and FFN-up
+  /* Activation precision of the trunk GEMMs in the PLAIN forward (explicit modes; with cfg_pair >= 2 the host's default is 1 and only 0 / 1
+   * compose with the weight-correction mini-tiles -- 2 / 3 then run without them): 0 = one fp16 value per element; 1 = fp16 hi + lo pairs for the LayerNorm outputs (QKV and FFN-up
    * sweep their weight twice: hi.W + lo.W in the same fp32 accumulator); 2 = additionally for the attention output and the FFN hidden (all four
    * trunk GEMMs do twice their work); 3 = as 2 with the lo halves stored as e4m3(lo * 2^12) and multiplied with an e4m3 copy of the weights on
    * v_mfma_scale_f32_16x16x128_f8f6f4 (half a sweep; hidden and mlp multiples of 256).  Not combined with weight_split.  (4, the MX-fp4 lo K-tiles of
@@ -62,7 +62,7 @@ typedef struct {
    * 2 = 1 + an MX-fp4 correction of the fp16 rounding of the WEIGHTS of all four trunk GEMMs (the product default): e2m1 of the operand VALUES
    *     with per-(row, 64 columns) scales against e2m1(W - fp16(W)) with per-row scales, as 24 KiB mini-tiles staged under the fp16 K-tiles and
    *     multiplied between them (gemm_ht.hip, XP = 6) -- on the conditional rows of the guided forward (the unconditional outputs inherit it through
-   *     the shared accumulator) and on every row of the plain forward (act_split 0).  Not combined with weight_split.
+   *     the shared accumulator) and on every row of the plain forward (act_split 0 or 1).  Not combined with weight_split.
    * 3 = 2 + the same kind of pass for the fp16 rounding of the conditional LayerNorm OUTPUTS in the guided forward's QKV / FFN-up GEMMs (e2m1 of
    *     their lo halves against e2m1 of the weights): what the 7-bit-per-group codebooks need for margin (tests/diag/error_budget.py).
    * Pair forwards need seq = 256, hidden 768 / 1024, mlp % 256 == 0 (post- or pre-norm); modes 2 / 3 also hidden / heads = 64.  Otherwise the engine

@@ -21,9 +21,9 @@ from . import _lib
 from .base_model import BaseModel, ParamSpec
 
 DEFAULT_WEIGHT_SPLIT = 0
-# Activation precision of the PLAIN forward where the weight-correction mode does not serve it (mb_gen_cfg.act_split): -1 = auto -- 0 when the
-# engine's mode (below) covers the plain forward, otherwise the cheapest hi + lo activation mode the shape allows (3 = e4m3 lo halves where hidden
-# and mlp are multiples of 256, else 2).
+# Activation precision of the PLAIN forward (mb_gen_cfg.act_split): -1 = auto -- 1 (LayerNorm outputs as fp16 hi + lo pairs) next to the engine's
+# weight-correction mode (below) where that covers the plain forward, otherwise the cheapest hi + lo activation mode the shape allows (3 = e4m3 lo
+# halves where hidden and mlp are multiples of 256, else 2).
 DEFAULT_ACT_SPLIT = -1
 # Precision mode of the engine (mb_gen_cfg.cfg_pair): -1 = auto, 0 = independent streams, 1 = classifier-free guidance in differential form alone --
 # the fastest guided forward; its token mismatch against the reference's own 12-bit / 64-step runs is 1.03e-3 over three runs (8.4e-4 / 9.9e-4 /
@@ -139,9 +139,11 @@ class LFQBert(BaseModel):
         """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch": the fp16 rounding of the trunk
         WEIGHTS is ~80 % of the sampled-logit error variance in every configuration (tests/diag/error_budget.py), so wherever the shape allows it
         every trunk GEMM carries the MX-fp4 weight-correction mini-tiles -- guided forwards in differential form (cfg_pair 2; 3 from 7 bits per
-        group on: + the activation-lo pass of the LayerNorm outputs), plain forwards with single fp16 activations (act_split 0).  Measured
-        (profiles/r04_parity.md): 12-bit / 64 steps 4.9e-4 over three reference runs; other shapes fall back to the differential form alone /
-        hi + lo activation pairs."""
+        group on: + the activation-lo pass of the LayerNorm outputs), plain forwards with the LayerNorm outputs as fp16 hi + lo pairs as well
+        (act_split 1: QKV and FFN-up sweep their weight twice; what took configs[1] from 71 / 44 / 67 to 45 / 37 / 56 mismatches of 87 040 on its
+        three reference runs, every run <= 7e-4, at 0.82-0.89 of the plain forward's speed; act_split = 0 with cfg_pair >= 2 is the faster opt-out).
+        Measured (profiles/r04_parity.md): 12-bit / 64 steps 5.5e-4 over three reference runs; other shapes fall back to the differential form
+        alone / hi + lo activation pairs."""
         capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm)
         mini = mini_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.heads) and not self.weight_split
         pair, act = int(self.cfg_pair), int(self.act_split)
@@ -152,7 +154,7 @@ class LFQBert(BaseModel):
         if pair == 1 and not capable:
             pair = 0
         if act < 0:                                                # the plain forward: covered by the weight correction, else hi + lo activation pairs
-            act = 0 if (self.weight_split or pair >= 2) else resolve_act_split(act, self.hidden_dim, self.mlp_dim)
+            act = 0 if self.weight_split else 1 if pair >= 2 else resolve_act_split(act, self.hidden_dim, self.mlp_dim)
         return act, pair
 
     def _engine_destroy(self, h) -> None:

@@ -253,18 +253,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // one of seven candidate layouts of 64-byte rows whose ds_read_b128 fragment reads run at the LDS rate -- tools/micro/lds_b128.hip; the first
   // choice, (row >> 2) & 3, read at half of it: SQ_LDS_BANK_CONFLICT 4.2 M cycles per FFN-up launch); the per-lane part of the address is the same
   // for both operands.
-  const int nmk = K / 128;
+  // (KM: the K extent of the operands = of the corrections; with split activations -- A2 / kw, plain tiles -- the fp16 sweep is twice as long)
+  const int KM = a.kw ? a.kw : K;
+  const int nmk = KM / 128;
   const int nseq = PAIR ? a.pair_rows / 257 : a.M / 257;
-  const bool mini_every = MINI && (!PAIR || a.nlo == 2);       // one mini-tile per fp16 K-tile (else one per two)
+  const bool mini_every = MINI && (PAIR ? a.nlo == 2 : !a.kw);   // one mini-tile per fp16 K-tile (else one per two)
   auto mini_lane = [&]() -> uint32_t {
     int lo_ = lane; asm volatile("" : "+v"(lo_));
-    return (uint32_t)((lo_ >> 2) * 2 * K + (((lo_ & 3) ^ ((lo_ >> 3) & 3)) * 16));
+    return (uint32_t)((lo_ >> 2) * 2 * KM + (((lo_ & 3) ^ ((lo_ >> 3) & 3)) * 16));
   };
   auto mini_dma_a = [&](const Plan& p, int j) {          // 1 instruction per wave
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
     const uint8_t* base = a.lo[PAIR ? ps : 0].A4;
     const uint32_t row0 = PAIR ? p.m0 + wave * 16 : p.m0 + (wave >> 2) * 128 + ps * 64 + (wave & 3) * 16;
-    MB_GLDS16_AUX(base + (size_t)row0 * 2 * K + jj * 64 + mini_lane(), smem + MINI_OFF + wave * 1024, AUX);
+    MB_GLDS16_AUX(base + (size_t)row0 * 2 * KM + jj * 64 + mini_lane(), smem + MINI_OFF + wave * 1024, AUX);
   };
   auto mini_dma_b = [&](const Plan& p, int j) {          // 2 instructions per wave, 1 KiB of contiguous memory each (w4_packed_offset)
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
@@ -980,7 +982,9 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
   if (a.pair_rows && (a.pair_rows % 257 || a.M != 2 * a.pair_rows || a.A8 || a.A2 || (a.ka && a.A4) || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
-  if (a.nlo && (a.nlo > 2 || a.M % 257 || a.K % 128 || a.A8 || a.A4 || a.A2 || a.ka || a.kw || a.out_lo || a.out_lo8 || (!a.pair_rows && a.nlo != 1) ||
+  // (plain tiles may combine the mini-tiles with split activations: A2 / kw, K = 2 kw -- hi + lo LayerNorm outputs AND the weight correction)
+  if (a.nlo && (a.nlo > 2 || a.M % 257 || (a.kw ? a.kw : a.K) % 128 || a.A8 || a.A4 || a.ka || a.out_lo || a.out_lo8 || (!a.pair_rows && a.nlo != 1) ||
+                ((a.A2 || a.kw) && (a.pair_rows || !a.A2 || a.K != 2 * a.kw)) ||
                 !a.lo[0].A4 || !a.lo[0].W4 || !a.lo[0].a_scale || !a.lo[0].w_scale ||
                 (a.nlo == 2 && (!a.lo[1].A4 || !a.lo[1].W4 || !a.lo[1].a_scale || !a.lo[1].w_scale)) || (uint64_t)a.M * a.K * 2 >= (1ull << 32) ||
                 epi == EPI_GELU_F32)) return false;

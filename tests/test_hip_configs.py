@@ -96,19 +96,21 @@ def _vs_reference_run(name, modes):
 @pytest.mark.timeout(900)
 def test_baseline_config1_10bit_16steps_nocfg_vs_reference_runs():
     """BASELINE configs[1] as named -- 10-bit generator, 16 steps, no guidance, batch 16 -- against THREE runs of the real reference (other weights,
-    head gain, noise and labels; 87 040 sampled positions each).  Without guidance the plain forward runs; its product default (round 4: single
-    fp16 activations + the MX-fp4 weight-correction mini-tiles on every trunk GEMM + hi/lo head weights) measures 8.2e-4 / 5.1e-4 / 7.7e-4 =
-    7.0e-4 over all (hi + lo activation pairs with fp16 weights, the default of rounds 2-3: 7.7e-4 / 5.9e-4 on the first two with the same head;
-    single fp16 1.06e-3 / 7.1e-4).  Asserted: the north star's <= 1e-3 on each run, <= 7.5e-4 over all."""
+    head gain, noise and labels; 87 040 sampled positions each).  Without guidance the plain forward runs; its product default (round 4: the
+    LayerNorm outputs as fp16 hi + lo pairs AND the MX-fp4 weight-correction mini-tiles on every trunk GEMM + hi/lo head weights) measures
+    5.2e-4 / 4.3e-4 / 6.4e-4 = 5.3e-4 over all; the weight correction over single fp16 activations (act_split 0, cfg_pair 2: the faster opt-out)
+    8.2e-4 / 5.1e-4 / 7.7e-4 = 7.0e-4; single fp16 1.06e-3 / 7.1e-4.  Asserted: <= 7e-4 on each run and <= 6e-4 over all for the default, the
+    north star's <= 1e-3 on each run for the opt-out."""
     import parity_replay as R
     tb = tt = 0
     for name in (R.RUN_CFG1, R.RUN_CFG1_S2, R.RUN_CFG1_S3):
-        r = _vs_reference_run(name, [("product default", 0, -1, -1), ("single fp16", 0, 0, 0)])
+        r = _vs_reference_run(name, [("product default", 0, -1, -1), ("weight correction, single fp16 activations", 0, 0, 2), ("single fp16", 0, 0, 0)])
         bad, tot = r["product default"]
-        assert tot == 87040 and bad / tot <= 1e-3, name
+        assert tot == 87040 and bad / tot <= 7e-4, name
         tb += bad; tt += tot
+        assert r["weight correction, single fp16 activations"][0] / tot <= 1e-3, name
     print(f"configs[1], three reference runs, product default: {tb}/{tt} = {tb / tt:.2e}")
-    assert tb / tt <= 7.5e-4
+    assert tb / tt <= 6e-4
 
 
 @pytest.mark.timeout(1500)
@@ -166,7 +168,7 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("name,expect,bound", [("sample_full12_64_prenorm", (0, 2), 8e-4), ("sample_full12_64_seq1024", (3, 0), 1e-3)])
+@pytest.mark.parametrize("name,expect,bound", [("sample_full12_64_prenorm", (1, 2), 8e-4), ("sample_full12_64_seq1024", (3, 0), 1e-3)])
 def test_generator_variants_full_width_vs_reference_runs(name, expect, bound):
     """configs[2]'s sampler (64 steps, CFG 7.1 cosine) on the two generator variants of the reference that differ in how the engine runs the guided
     forward, against full-width runs of the REAL reference (oracle/make_golden.py RUNS):
