@@ -180,7 +180,12 @@ def other_configs(dev):
         plan = build_plan(int(kw["num_steps"]), 512, float(kw["guidance_scale"]), kw["guidance_annealing"], float(kw["scale_pow"]), 1.0, False,
                           kw["mask_schedule_strategy"])
         rt = float(kw["randomize_temperature"])
+        # unguided sampling runs the plain forward: also timed with act_split = 0 (the weight correction over single fp16 activations -- the faster
+        # opt-out, 7.0e-4 instead of 5.3e-4 token mismatch over the three reference runs of this configuration, profiles/r04_parity.md)
+        variants = (("", -1), (" [act_split = 0]", 0)) if float(kw["guidance_scale"]) == 0.0 else (("", -1),)
         for B in batches:
+          for vtag, act in variants:
+            gen.act_split = act
             labels = (torch.arange(B) * 37 % 1000).to(dev)
             torch.manual_seed(0)
             reps = 3 if int(kw["num_steps"]) < 100 else 1
@@ -190,8 +195,8 @@ def other_configs(dev):
                     run_chunked(gen, tok, labels, plan, rt, want_steps=False, want_image=False, want_u8=True)
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
-            out[f"{tag}, batch {B}"] = {"images_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B,
-                                        "precision": "LFQBert (act_split, cfg_pair) = %s" % (gen.resolved_precision(),)}
+            out[f"{tag}, batch {B}{vtag}"] = {"images_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B,
+                                              "precision": "LFQBert (act_split, cfg_pair) = %s" % (gen.resolved_precision(),)}
         del gen, tok
         torch.cuda.empty_cache()
     return out
