@@ -774,9 +774,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             const float mul = fp4_scale_mul_nosat(am);
             const uint32_t row = (uint32_t)row_of(i);
             sc4 |= fp4_scale_byte_nosat(am) << (8 * ii);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-              *(uint16_t*)(a.out4 + (size_t)row * 2 * a.N + (col_of(i, nt) >> 1)) = (uint16_t)fp4_pack4(acc[nt][i][0], acc[nt][i][1], acc[nt][i][2], acc[nt][i][3], mul);
+            // a lane's four n-tiles are 2 bytes each (4 columns): as 2-byte stores they cost 13.6 us of a 372 us FFN-up launch (A/B, MB_NO_OUT4_STORE).
+            // Two lane exchanges give every lane 8 CONSECUTIVE bytes of the row's 32-byte block instead: the odd / even lane-row swap of the fp16
+            // stores (n-tiles 2pr <-> 2pr + 1: a lane then holds 8 columns of one n-tile), then the lane halves (g <-> g ^ 2: the neighbouring 8 columns)
+            const uint32_t p0 = fp4_pack4(acc[0][i][0], acc[0][i][1], acc[0][i][2], acc[0][i][3], mul), p1 = fp4_pack4(acc[1][i][0], acc[1][i][1], acc[1][i][2], acc[1][i][3], mul);
+            const uint32_t p2 = fp4_pack4(acc[2][i][0], acc[2][i][1], acc[2][i][2], acc[2][i][3], mul), p3 = fp4_pack4(acc[3][i][0], acc[3][i][1], acc[3][i][2], acc[3][i][3], mul);
+            const auto sw = __builtin_amdgcn_permlane16_swap((p0 & 0xffffu) | (p2 << 16), (p1 & 0xffffu) | (p3 << 16), false, false);
+            const uint32_t q0 = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);      // 32-column group 0: this lane's 4 columns | its neighbour's
+            const uint32_t q1 = __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u);      // 32-column group 1
+            const auto sx = __builtin_amdgcn_permlane32_swap(q0, q1, false, false);    // lanes < 32: group 0 of lanes g, g + 2; lanes >= 32: group 1 of g - 2, g
+#ifdef MB_NO_OUT4_STORE                                     /* experiment (timing only): what the stores of the e2m1 copy cost */
+            if (mul == 12345.0f)
+#endif
+            *(uint2*)(a.out4 + (size_t)row * 2 * a.N + ((n0 + wn * 64) >> 1) + (ge >> 1) * 16 + (ge & 1) * 8) = make_uint2(sx[0], sx[1]);
           }
           const uint32_t gq = PAIR ? (uint32_t)tq * 2 + wm : (uint32_t)wm * 2 + hh;
           if (ge == 0) ((uint32_t*)a.out4_scale)[((blk * nsq + (uint32_t)cur.seq) * 4 + gq) * 16 + l15e] = sc4;

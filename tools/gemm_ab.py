@@ -47,7 +47,10 @@ def main():
             for k, l in (list(libs.items()) if rnd % 2 == 0 else list(libs.items())[::-1]):
                 o32 = res.clone() if epi == 2 else None
                 o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
-                fn = lambda: l.mb_gemm_mini(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), None, None, P, 1, N, K, nlo, sets[k][1], st)
+                h4 = h4s = None
+                if epi == 1 and os.environ.get("GEMM_AB_OUT4"):          # the GELU epilogue's e2m1 copy of the conditional outputs (FFN-down's token operand)
+                    h4 = torch.zeros(P, 2 * N, device=dev, dtype=torch.uint8); h4s = torch.zeros((N // 64) * 64 * 256 + 256, device=dev, dtype=torch.uint8)
+                fn = lambda: l.mb_gemm_mini(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), ptr(h4), ptr(h4s), P, 1, N, K, nlo, sets[k][1], st)
                 assert fn() == 0
                 torch.cuda.synchronize()
                 outs[k] = (o32 if epi == 2 else o16).clone()
