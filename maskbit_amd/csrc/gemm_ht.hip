@@ -468,7 +468,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acce[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // SEQ: class row x this wave row's 2 n-tiles
     // pair tiles: both 128-token halves of a sequence pair stage the class rows, only the second one (q == 1) stores them -- the first skips their MFMAs
+#ifdef MB_NO_CLS                                            /* experiment (timing only): what the class-token rows' MFMAs and fragment reads cost */
+    const bool cls_on = false;
+#else
     const bool cls_on = !PAIR || __builtin_amdgcn_readfirstlane(cur.q) == 1;
+#endif
     h16x16 xa[MH], wb[2][2];      // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
     if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
