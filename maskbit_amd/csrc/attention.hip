@@ -193,8 +193,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         if (kt >= ATT_NKT - 2) s[kt][r] = (kt * 16 + g * 4 + r < N) ? s[kt][r] : -INFINITY;
         mx = fmaxf(mx, s[kt][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = rows_max(mx);
     const float mxs = mx * scale_log2e;
     f32x2 sum2 = {0.f, 0.f};                                  // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): two keys per VALU issue
 #pragma unroll
@@ -207,8 +206,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         sum2 += p;
       }
     float sum = sum2.x + sum2.y;
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = rows_sum(sum);
     float inv = 1.0f / sum;
     asm volatile("" : "+v"(inv));          // every cross-lane op of the softmax has retired before the asm LDS reads start
     f32x4 twin[DH / 16] = {};              // AUX 2: the conditional twin's output rows, requested now, used after the PV loop
@@ -287,8 +285,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(o[nt][r] * inv));
-        am = fmaxf(am, __shfl_xor(am, 16));
-        am = fmaxf(am, __shfl_xor(am, 32));
+        am = rows_max(am);
         const float mul = fp4_scale_mul_nosat(am);
         if (q < 256) {                                                // (class-token rows take no part in the mini-tile passes)
           const size_t row = (size_t)sq * N + q;
@@ -409,8 +406,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
         if (key0 + kt * 16 + g * 4 + r >= N) sblk[kt][r] = -INFINITY;
         mx = fmaxf(mx, sblk[kt][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = rows_max(mx);
     const float m_new = fmaxf(m_run, mx);                   // finite: every block holds at least one real key
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);   // exp2(-inf) = 0 on the first block
     const float mxs = m_new * scale_log2e;
@@ -423,8 +419,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
       for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(sblk[kt][r], scale_log2e, -mxs)); sum += p[r]; }
       pk[kt] = h16x4{(h16)p[0], (h16)p[1], (h16)p[2], (h16)p[3]};
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = rows_sum(sum);
     l_run = l_run * alpha + sum;
     m_run = m_new;
 #pragma unroll

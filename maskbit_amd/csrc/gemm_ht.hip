@@ -773,8 +773,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
               for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(acc[nt][i][e]));
-            am = fmaxf(am, __shfl_xor(am, 16));
-            am = fmaxf(am, __shfl_xor(am, 32));
+            am = rows_max(am);
             const float mul = fp4_scale_mul_nosat(am);
             const uint32_t row = (uint32_t)row_of(i);
             sc4 |= fp4_scale_byte_nosat(am) << (8 * ii);

@@ -55,6 +55,21 @@ __device__ __forceinline__ float wave_max(float v) {
 // (Tried: A-S 7.1.28, erfc(a) = (1 + a1 a + .. + a6 a^6)^-16 -- one quarter-rate instruction per element instead of two.  0.75 % off the FFN-up
 // GEMM, 2-7 positions of token parity lost in every mode (its error, <= 3e-7 nominal, is no longer smooth after the ^16): not kept.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Reductions over the four 16-lane rows of a wave (lanes 16 / 32 apart) on the VALU: v_permlane16_swap / v_permlane32_swap of a value with
+// itself leave (own, partner's) in the two results, in either order -- max and sum are symmetric, so no select.  (__shfl_xor goes through the
+// LDS crossbar: ds_bpermute + its address + a lgkmcnt wait, in the middle of the attention softmax's dependent chain.)
+__device__ __forceinline__ float rows_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   const float a0 = fabsf(x.x), a1 = fabsf(x.y);
   const f32x2 t = {__builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, a0, 1.0f)),
