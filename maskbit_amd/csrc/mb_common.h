@@ -71,6 +71,9 @@ __device__ __forceinline__ float rows_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+#ifdef MB_NO_GELU                                           /* experiment (timing only): what the GELU arithmetic of the FFN-up epilogue costs */
+  return x;
+#endif
   const float a0 = fabsf(x.x), a1 = fabsf(x.y);
   const f32x2 t = {__builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, a0, 1.0f)),
                    __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, a1, 1.0f))};
