@@ -45,6 +45,10 @@ int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb
 int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
 /* LayerNorm that also writes the e2m1 copies of its output rows: values (x4 / x4_scale) and / or fp16 lo halves (xl4 / xl4_scale); M % 257 == 0,
  * d = 768 / 1024; class-token rows (row % 257 == 256) are skipped. */
+/* ... the plain forward's default for QKV / FFN-up (act_split 1 with cfg_pair >= 2): plain sequence tiles over hi + lo activation halves
+ * (A_hi, A_lo [rows, kw]; the fp16 sweep runs twice over W [N, kw]) AND one mini-tile operand set over the kw columns; epi 0 / 1. */
+int mb_gemm_mini_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, void* out_h16, void* out4, void* out4_scale,
+                       int rows, int N, int kw, const void* const* lo, mb_stream stream);
 int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x4, void* x4_scale, void* xl4,
                     void* xl4_scale, int M, int d, mb_stream stream);
 /* Attention of a CFG pair batch (the generator's guided forward, bert.py:84,137 on both streams): qkv [2 pairs N, 3d] fp16 packed in_proj rows, the

@@ -518,6 +518,22 @@ int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
+int mb_gemm_mini_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, void* out_h16, void* out4, void* out4_scale,
+                       int rows, int N, int kw, const void* const* lo /* {A4, a_scale, W4, w_scale} */, mb_stream stream) {
+  if (!A_hi || !A_lo || !W || !bias || !out_h16 || !lo || epi < 0 || epi > 1 || rows <= 0 || rows % 257 || kw <= 0 || kw % 128)
+    return fail(-1, "mb_gemm_mini_split: bad arguments");
+  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, nullptr, nullptr, (h16*)out_h16, rows, N, 2 * kw, 0, 0, nullptr};
+  a.A2 = (const h16*)A_lo; a.kw = kw;
+  a.nlo = 1;
+  a.lo[0] = {(const uint8_t*)lo[0], (const uint8_t*)lo[1], (const uint8_t*)lo[2], (const uint8_t*)lo[3]};
+  a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale;
+  if (!mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_mini_split: shape not supported by the sequence-aligned tiles");
+  ProfScope p("gemm_diag", (hipStream_t)stream);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, 257)) return fail(-3, "mb_gemm_mini_split: shape refused");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
 int mb_attention_pair(const void* qkv, void* out_h16, float* aux, int pairs, int N, int d, int heads, mb_stream stream) {
   if (!qkv || !out_h16 || !aux || pairs <= 0 || N <= 0 || heads <= 0 || d % heads) return fail(-1, "mb_attention_pair: bad arguments");
   ProfScope p("attention", (hipStream_t)stream);

@@ -125,6 +125,52 @@ def test_plain_gemm_with_weight_correction_mini_tiles(epi, nseq, N, K):
         assert float(((dec - ref) ** 2).sum() / (ref ** 2).sum()) < 0.02
 
 
+@pytest.mark.parametrize("epi,nseq,N,K", [(0, 3, 768, 1024), (1, 2, 1024, 1024)])
+def test_plain_gemm_split_activations_with_weight_correction_mini_tiles(epi, nseq, N, K):
+    """The plain forward's default for QKV / FFN-up (act_split 1 composed with cfg_pair >= 2; mb_gemm_mini_split): the fp16 sweep runs over the hi
+    AND the lo halves of the activations (K-tiles doubled) while the mini-tiles -- one per two fp16 K-tiles then, both row halves -- add the weight
+    correction of the K columns: out = (x_hi + x_lo) . W^T + e2m1(x) . e2m1(W32 - W)^T + bias."""
+    import ctypes as C
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(10 * epi + nseq)
+    M = nseq * 257
+    x32 = torch.randn(M, K, device=DEV) * (0.3 + torch.rand(M, K // 64, device=DEV).repeat_interleave(64, 1) * 2)
+    hi = x32.half()
+    lo = (x32 - hi.float()).half()
+    W32, w4lo, wslo, wlo_dec = _weights(N, K, lib, lo=True)
+    W = W32.half()
+    x4, xs, x4_dec = f4_encode_rows(hi.double(), nseq)
+    bias = torch.randn(N, device=DEV) * 0.1
+    out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16)
+    out4 = torch.zeros(M, 2 * N, device=DEV, dtype=torch.uint8) if epi == 1 else None
+    out4s = torch.zeros((N // 64) * nseq * 256 + 256, device=DEV, dtype=torch.uint8) if epi == 1 else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    arr = (C.c_void_p * 4)(x4.data_ptr(), xs.data_ptr(), w4lo.data_ptr(), wslo.data_ptr())
+    _lib.check(lib.mb_gemm_mini_split(epi, hi.data_ptr(), lo.data_ptr(), W.data_ptr(), bias.data_ptr(), out16.data_ptr(), ptr(out4), ptr(out4s), M, N, K, arr,
+                                      torch.cuda.current_stream().cuda_stream), "mb_gemm_mini_split")
+    torch.cuda.synchronize()
+    want = (hi.double() + lo.double()) @ W.double().t() + x4_dec @ wlo_dec.t() + bias.double()
+    if epi == 1:
+        want = torch.nn.functional.gelu(want)
+    got = out16.double()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    assert float(err.max()) < 2e-3 * max(1.0, float(want.abs().max())), (float(err.max()), int(err.argmax()) // N, int(err.argmax()) % N)
+    # against the fp32 operands: closer than either half measure (hi + lo activations with fp16 weights; single fp16 activations with the correction)
+    true = x32.double() @ W32.double().t() + bias.double()
+    if epi == 1:
+        true = torch.nn.functional.gelu(true)
+    keep = (torch.arange(M, device=DEV) % 257) < 256
+    rms = lambda t: float((t - true)[keep].pow(2).mean().sqrt())
+    f = (lambda t: torch.nn.functional.gelu(t)) if epi == 1 else (lambda t: t)
+    e_both = rms(got)
+    e_act = rms(f((hi.double() + lo.double()) @ W.double().t() + bias.double()).half().double())
+    e_w = rms(f(hi.double() @ W.double().t() + x4_dec @ wlo_dec.t() + bias.double()).half().double())
+    print(f"rms error vs fp32 operands: hi + lo activations alone {e_act:.3e}, weight correction alone {e_w:.3e}, both {e_both:.3e}")
+    assert e_both <= 1.02 * min(e_act, e_w)
+
+
 @pytest.mark.parametrize("d,nseq", [(1024, 3), (768, 2)])
 def test_layernorm_writes_e2m1_values_and_lo_halves(d, nseq):
     """mb_layernorm_f4 (the LayerNorm kernels' producer path): e2m1 of the normalised rows and of their fp16 lo halves, one scale per 64 columns
