@@ -64,6 +64,14 @@ __device__ __forceinline__ float rows_max(float v) {
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
+// Maximum over the 16 lanes of a lane row on the VALU's DPP path (quad swaps, then the half-row and row mirrors: max is symmetric) -- four
+// v_max with a DPP operand instead of four ds_bpermute round trips.
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, false)));    // quad_perm [1, 0, 3, 2]
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, false)));    // quad_perm [2, 3, 0, 1]
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, false)));   // row_half_mirror
+  return fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xF, 0xF, false))); // row_mirror
+}
 __device__ __forceinline__ float rows_sum(float v) {
   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = __uint_as_float(a[0]) + __uint_as_float(a[1]);

@@ -19,8 +19,7 @@ __device__ __forceinline__ void fp4_row_store(const float4* v, int lane, uint8_t
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     float am = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+    am = row16_max(am);
     if ((lane & 15) == 0) scales[fp4_scale_index(q * 4 + (lane >> 4), nseq, seq, tok)] = (uint8_t)fp4_scale_byte_nosat(am);
     *(uint16_t*)(x4row + q * 128 + lane * 2) = (uint16_t)fp4_pack4(v[q].x, v[q].y, v[q].z, v[q].w, fp4_scale_mul_nosat(am));
   }
