@@ -129,18 +129,19 @@ def build_models(dev):
     return gen.eval().requires_grad_(False).to(dev), tok.eval().requires_grad_(False).to(dev)
 
 
-def measured_parity(gen, run=None):
+def measured_parity(gen, run=None, batch=B_PER_GPU):
     """Teacher-forced token mismatch of the engine's CURRENT precision mode against a full-size 64-step run of the real reference: by default
     tests/golden/sample_full12_64.npz (made by oracle/make_golden.py full64 with the bench's own weights; 84 284 sampled positions); `run` names
-    another recorded run (`gen` must then carry that run's weights)."""
+    another recorded run (`gen` must then carry that run's weights).  Round 5: measured AT THE TIMED BATCH SIZE -- the fixture's 4 (8) samples ride as
+    rows 0 .. 63 (spread) of a 64-sample guided forward whose other rows hold random codes in the same mask state, i.e. through the same 2 048-tile
+    persistent GEMM walks, pair attention grid and LayerNorm launches the timed region runs (parity_replay.teacher_forced(batch = 64))."""
     from maskbit_amd import parity_replay as R
-    if run is None:
-        bad, tot, _, _ = R.teacher_forced(gen)
-    else:
-        g = R.load_run(run)
-        bad, tot, _, _ = R.teacher_forced(gen, g, R.reference_noise(g, gen.device))
-    return {"token_mismatch": bad / tot, "mismatches": bad, "positions": tot,
-            "against": f"the reference's own sample() run, CPU fp32 (tests/golden/{run or 'sample_full12_64'}.npz), teacher-forced per step"}
+    g = R.load_run(run) if run is not None else R.load_full64()
+    bad, tot, _, _ = R.teacher_forced(gen, g, R.reference_noise(g, gen.device), batch=batch)
+    return {"token_mismatch": bad / tot, "mismatches": bad, "positions": tot, "batch": max(batch, int(g["steps"].shape[1])),
+            "fixture_samples": int(g["steps"].shape[1]),
+            "against": f"the reference's own sample() run, CPU fp32 (tests/golden/{run or 'sample_full12_64'}.npz), teacher-forced per step, the fixture's "
+                       f"samples embedded in a batch of {max(batch, int(g['steps'].shape[1]))}"}
 
 
 def other_runs_parity(dev, mode_settings):

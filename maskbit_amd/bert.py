@@ -41,7 +41,7 @@ def pair_capable(seq_len: int, hidden: int, mlp: int, prenorm: bool) -> bool:
 
 def mini_capable(seq_len: int, hidden: int, mlp: int, heads: int) -> bool:
     """Shapes the MX-fp4 mini-tile passes serve (mb_gen_create: mini_ok)."""
-    return seq_len == 256 and hidden in (768, 1024) and mlp % 128 == 0 and hidden // heads == 64
+    return seq_len == 256 and hidden in (768, 1024) and mlp % 256 == 0 and hidden // heads == 64
 
 
 def resolve_act_split(act_split: int, hidden: int, mlp: int) -> int:

@@ -209,8 +209,9 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   // cfg_pair >= 2 outside a guided forward (plain forward(), sampling without guidance, the zero-scale steps of a guided run): the fp16 rounding of
   // the WEIGHTS is 80 % of the sampled-logit error variance there (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
   // activation pairs, 0.0045 with the weight correction alone), so all four trunk GEMMs carry the MX-fp4 weight-correction mini-tiles on every row
-  // act_split 1 composes: the LayerNorm outputs then ALSO enter QKV / FFN-up as fp16 hi + lo pairs (the fp16 sweep of those two GEMMs doubles) -- the
-  // emulator's 63 -> 41 mismatches on configs[1]; an opt-in (0.7 of the plain forward's speed), not the default.  act_split 2 / 3: hi + lo pairs alone.
+  // act_split 1 composes, and is what LFQBert.resolved_precision() picks by default next to cfg_pair >= 2: the LayerNorm outputs then ALSO enter
+  // QKV / FFN-up as fp16 hi + lo pairs (the fp16 sweep of those two GEMMs doubles) -- the emulator's 63 -> 41 mismatches on configs[1], measured
+  // 5.3e-4 against 7.0e-4 over its three reference runs at 0.82-0.89 of the speed; act_split 0 is the faster opt-out.  act_split 2 / 3: hi + lo pairs alone.
   const bool wm = g->mini_ok && c.cfg_pair >= 2 && c.act_split <= 1 && !c.weight_split;
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
   Fp4Rows f4x;
@@ -310,8 +311,9 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   if (attn_rc) return fail(-3, "attention maps: head dim %d / %d tokens not supported", d / c.heads, N);
-  if (gemm_rc) return fail(-3, "act_split = %d: a trunk GEMM of this forward (%d sequences x %d tokens, hidden %d, mlp %d) is outside the "
-                               "half-tile kernel's shapes", c.act_split, nb, N, d, f);
+  if (gemm_rc) return fail(-3, "a trunk GEMM of this forward (%d sequences x %d tokens, hidden %d, mlp %d; act_split %d, cfg_pair %d%s) is outside the "
+                               "half-tile kernel's shapes: its lo pass / correction mini-tiles cannot run", nb, N, d, f, c.act_split, c.cfg_pair,
+                               wm ? ", weight-correction mini-tiles" : "");
   return 0;
 }
 
@@ -679,7 +681,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   }
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   // MX-fp4 mini-tile passes (cfg_pair 2 / 3): 257-token sequences, vector LayerNorm widths, heads of 64 (the attention kernels' e2m1 output), whole mini-tiles
-  g->mini_ok = c.cfg_pair >= 2 && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 128 == 0 && c.hidden / c.heads == 64 && !c.weight_split;
+  g->mini_ok = c.cfg_pair >= 2 && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && c.hidden / c.heads == 64 && !c.weight_split;   // (FFN-up's N = mlp: whole 256-column tiles)
   // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
   // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice)
   g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && g->chunk_seqs >= 2 &&

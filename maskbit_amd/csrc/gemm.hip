@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
 
   // ---- epilogue: lane holds out[m][n..n+3], m = ..+(lane&15), n = ..+(lane>>4)*4
   const float sc = a.scale ? *a.scale : 1.0f;
-  float satm = 0.f;                                  // fp16 epilogues: largest |value| this lane stores (GemmArgs.sat)
+  bool satb = false;                                 // fp16 epilogues: this lane stores a value outside fp16's range, or a NaN (GemmArgs.sat)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + (lane & 15);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
         v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y;
       }
       if (EPI == EPI_H16 || EPI == EPI_GELU_H16) {
-        satm = fmaxf(satm, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+        satb |= !(fabsf(v0) <= MB_H16_MAX) | !(fabsf(v1) <= MB_H16_MAX) | !(fabsf(v2) <= MB_H16_MAX) | !(fabsf(v3) <= MB_H16_MAX);   // (fmaxf would drop a NaN)
         h16x4 o = {to_h(v0), to_h(v1), to_h(v2), to_h(v3)};
         *(h16x4*)(a.out_h16 + orow * a.N + n) = o;
         if (a.out_lo)
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
       }
     }
   }
-  if ((EPI == EPI_H16 || EPI == EPI_GELU_H16) && a.sat && !(satm <= MB_H16_MAX)) atomicAdd(a.sat, 1u);
+  if ((EPI == EPI_H16 || EPI == EPI_GELU_H16) && a.sat && satb) atomicAdd(a.sat, 1u);
 }
 
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
@@ -161,7 +161,7 @@ int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
     gemm_ht(s, epi, a, variant);
     return 0;
   }
-  if (a.A8 || a.A4 || a.pair_rows) return -1;
+  if (a.A8 || a.A4 || a.pair_rows || a.nlo) return -1;   // (mini-tile passes exist in the half-tile kernel only: never dropped silently)
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles), block(256);
   switch (epi) {

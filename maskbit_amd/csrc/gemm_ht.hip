@@ -886,7 +886,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         }
       }
     } else {
-      float satm = 0.f;                                  // fp16 epilogues: largest |value| this lane stores (saturation census, GemmArgs.sat)
+      float satm = 0.f;                                  // fp16 epilogues: largest |value| this lane stores (saturation census, GemmArgs.sat);
+      bool satnan = false;                               // ... and whether one of them is a NaN (fmaxf returns the other operand)
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
         const bool ok = row_ok(r);
@@ -896,8 +897,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           for (int pr = 0; pr < nn / 2; ++pr) {
             const f32x4 ca = r < MT ? acc[2 * pr][r < MT ? r : 0] : acce[0];
             const f32x4 cb = r < MT ? acc[2 * pr + 1][r < MT ? r : 0] : acce[1];
-            if (a.sat && ok) satm = fmaxf(fmaxf(satm, fmaxf(fmaxf(fabsf(ca[0]), fabsf(ca[1])), fmaxf(fabsf(ca[2]), fabsf(ca[3])))),
-                                          fmaxf(fmaxf(fabsf(cb[0]), fabsf(cb[1])), fmaxf(fabsf(cb[2]), fabsf(cb[3]))));
+            if (a.sat && ok) {
+              satm = fmaxf(fmaxf(satm, fmaxf(fmaxf(fabsf(ca[0]), fabsf(ca[1])), fmaxf(fabsf(ca[2]), fabsf(ca[3])))),
+                           fmaxf(fmaxf(fabsf(cb[0]), fabsf(cb[1])), fmaxf(fabsf(cb[2]), fabsf(cb[3]))));
+              const float sm = (ca[0] + ca[1]) + (ca[2] + ca[3]) + (cb[0] + cb[1]) + (cb[2] + cb[3]);   // NaN if any of the eight is (or +inf next to -inf)
+              satnan |= sm != sm;
+            }
             const h16x2 ta0 = {to_h(ca[0]), to_h(ca[1])}, ta1 = {to_h(ca[2]), to_h(ca[3])};
             const h16x2 tb0 = {to_h(cb[0]), to_h(cb[1])}, tb1 = {to_h(cb[2]), to_h(cb[3])};
             // swap: lane rows with odd g of the first operand <-> even g of the second (16-lane rows)
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             }
         }
       }
-      if ((EPI == EPI_H16 || EPI == EPI_GELU_H16) && a.sat && !(satm <= MB_H16_MAX)) atomicAdd(a.sat, 1u);   // (NaN counts too)
+      if ((EPI == EPI_H16 || EPI == EPI_GELU_H16) && a.sat && (satnan || !(satm <= MB_H16_MAX))) atomicAdd(a.sat, 1u);   // (a NaN counts too)
     }
     if (has_next) __builtin_amdgcn_s_barrier();        // everyone's share of the next tile's K-tiles 0 and 1 has landed (each wave waited above)
     MB_TRACE(4);

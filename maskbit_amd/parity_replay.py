@@ -8,7 +8,8 @@ tokens and pixels from the fixture.  Used by ``tests/test_hip_full64.py`` / ``te
 shim), by the tools and by ``bench.py`` (which reports the measured token mismatch of the mode it times).
 
   teacher_forced(): every step restarts from the reference's masked-token state; mismatches are counted over the positions
-                    sampled at that step (84 284 in the run) -- the north star's "bit-token mismatch vs reference".
+                    sampled at that step (84 284 in the run) -- the north star's "bit-token mismatch vs reference".  With batch = 64 the
+                    fixture's samples ride inside a batch of the size bench.py times.
   free_running():   one ``mb_sample`` call over all 64 steps with the same noise; reports how far the trajectories drift.
 """
 from __future__ import annotations
@@ -115,9 +116,23 @@ def build_models(device, with_tokenizer: bool = True, name: str = "sample_full12
     return gen, tok
 
 
+def _embed_rows(B: int, batch: int) -> torch.Tensor:
+    """Rows of a `batch`-sample batch that carry the fixture's B samples: spread over the batch (first, last and in between), so that they ride in
+    different pair tiles, CU rounds and XCD chunks of the persistent GEMM grids than they do at batch B."""
+    if batch == B:
+        return torch.arange(B)
+    rows = torch.linspace(0, batch - 1, B).round().long()
+    assert rows.unique().numel() == B
+    return rows
+
+
 @torch.no_grad()
-def teacher_forced(gen, g=None, noise=None):
-    """-> (mismatches, sampled positions, per-step mismatch counts, re-mask differences)."""
+def teacher_forced(gen, g=None, noise=None, batch: int = 0):
+    """-> (mismatches, sampled positions, per-step mismatch counts, re-mask differences).
+    batch > B (round 5): the fixture's B samples ride as rows of a `batch`-sample forward -- the size bench.py TIMES (64 pairs: 2 048 pair tiles walked
+    persistently in 8 rounds by 256 workgroups) -- the other rows holding random codes in the same mask state under random labels; the sampling step
+    then runs on the fixture's rows alone, with the fixture's noise.  The counts must equal the batch = B replay's exactly: a sequence pair's logits do
+    not depend on its batch neighbours (tests/test_hip_timed_path.py asserts the bits)."""
     from maskbit_amd import _lib
     lib = _lib.load()
     g = g or load_full64()
@@ -125,18 +140,32 @@ def teacher_forced(gen, g=None, noise=None):
     q, c = noise if noise is not None else reference_noise(g, dev)
     scale, temp, mask_len = plan_of(g)
     S, B = g["steps"].shape[0], g["steps"].shape[1]
+    NB = max(int(batch), B)
+    rows = _embed_rows(B, NB).to(dev)
     y = g["labels"].to(dev)
+    if NB > B:
+        fill = torch.Generator().manual_seed(g["seed"] + 99)
+        y_all = torch.randint(0, 1000, (NB,), generator=fill).to(dev)
+        y_all[rows] = y
     per_step, remask = [], 0
     total = 0
     for i in range(S):
         tin_cpu = tokens_in(g, i)
         tin = tin_cpu.to(dev).contiguous()
-        if float(g["kw"]["guidance_scale"]) != 0.0 and scale[i] != 0.0:
-            lg = gen.forward_cfg(tin, y, scale[i])                   # the guided forward of the loop (cond | label-dropped); as in mb_sample, the steps whose
-                                                                     # annealed scale is exactly 0 run the conditional forward alone (c + 0 (c - u) == c)
-            lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
+        if NB > B:
+            src = tin_cpu[torch.arange(NB) % B]                      # filler rows: a fixture row's mask state, random codes where it is decoded
+            rnd = torch.randint(0, g["C"], src.shape, generator=fill)
+            tall = torch.where(src == g["C"], src, rnd).to(dev)
+            tall[rows] = tin
+            tall = tall.contiguous()
         else:
-            lc, lu = gen(tin, y, torch.zeros(B, dtype=torch.bool, device=dev)), None
+            tall, y_all = tin, y
+        if float(g["kw"]["guidance_scale"]) != 0.0 and scale[i] != 0.0:
+            lg = gen.forward_cfg(tall, y_all, scale[i])              # the guided forward of the loop (cond | label-dropped); as in mb_sample, the steps whose
+                                                                     # annealed scale is exactly 0 run the conditional forward alone (c + 0 (c - u) == c)
+            lc, lu = lg[:NB][rows].contiguous(), lg[NB:][rows].contiguous()
+        else:
+            lc, lu = gen(tall, y_all, torch.zeros(NB, dtype=torch.bool, device=dev))[rows].contiguous(), None
         tout, pred = torch.empty_like(tin), torch.empty_like(tin)
         _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr() if lu is not None else None, scale[i], temp[i], q[i].data_ptr(), c[i].data_ptr(),
                                       mask_len[i], tin.data_ptr(), tout.data_ptr(), pred.data_ptr(), B, g["steps"].shape[2], 2, g["C"],

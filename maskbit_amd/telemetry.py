@@ -46,10 +46,16 @@ def _read_int(path: str) -> Optional[int]:
         return None
 
 
-def _smi_sample() -> Tuple[Optional[float], Optional[float]]:
+def _smi_sample(device_index: int = 0) -> Tuple[Optional[float], Optional[float]]:
+    """One rocm-smi reading of THIS device (`-d index`; the entry keyed `card<index>` when several come back) -- never another card's."""
     try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
-        card = next(iter(json.loads(out).values()))
+        out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+        cards = json.loads(out)
+        card = cards.get(f"card{device_index}")
+        if card is None:
+            if len(cards) != 1:
+                return None, None                                  # several cards and none is named as ours: report nothing rather than GPU 0's
+            card = next(iter(cards.values()))
         sclk = next((v for k, v in card.items() if "sclk" in k.lower()), None)
         pw = next((v for k, v in card.items() if "power" in k.lower() and "(w)" in k.lower()), None)
         mhz = float("".join(ch for ch in str(sclk) if ch.isdigit() or ch == ".")) if sclk is not None else None
@@ -74,8 +80,9 @@ class ClockSampler:
                 bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}.0"
         except Exception:      # noqa: BLE001
             pass
+        self.device_index = device_index
         self.hwmon = _hwmon_dir(bdf)
-        self.source = f"hwmon ({self.hwmon})" if self.hwmon else "rocm-smi"
+        self.source = f"hwmon ({self.hwmon})" if self.hwmon else f"rocm-smi -d {device_index}"
         if not self.hwmon:
             self.period = max(self.period, 1.0)
 
@@ -86,7 +93,7 @@ class ClockSampler:
             if uw is None:
                 uw = _read_int(os.path.join(self.hwmon, "power1_input"))
             return (hz / 1e6 if hz else None, uw / 1e6 if uw else None)
-        return _smi_sample()
+        return _smi_sample(self.device_index)
 
     def _run(self):
         while not self._stop.is_set():
