@@ -322,7 +322,6 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
 // fp16(x_c) and the unconditional rows the DIFFERENCE fp16(x_u - x_c); the pair GEMM (gemm_ht.hip, PAIR) adds the two products for the
 // unconditional outputs.  The fp32 residual stream, qkv and the logits hold ordinary values for both streams.  wmode: MX-fp4 correction
 // pass for the fp16 rounding of the QKV / FFN-up weights (conditional rows; the unconditional outputs inherit it through acc_c).
-bool emu128() { static const bool on = getenv("MASKBIT_AMD_EMU128") && atoi(getenv("MASKBIT_AMD_EMU128")) != 0; return on; }   // experiment (requant128_rows)
 int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, int B, bool wmode, hipStream_t s) {
   using namespace mb;
   const mb_gen_cfg& c = g->c;
@@ -362,7 +361,6 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       embed_ln(s, e);
       rc |= pairify_rows(s, g->y_f32, g->x_h16, P, d, f4_for(0));        // y_f32 holds the embedding LayerNorm's fp32 rows here
     }
-    if (emu128() && f4_for(0).x4) requant128_rows(s, g->x_h16, g->x4, g->x4s, P, d, B);
   }
   // pre-norm: the first sub-layer normalises the embedding rows again (LayerNorm 1 of layer 0); post-norm: the embedding's own pair operands feed QKV
   if (c.prenorm && c.depth > 0) {
@@ -379,7 +377,6 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
     const bool wo4 = wl && (g->wcorr_mask & 2), wh4 = wl && (g->wcorr_mask & 8);
     { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
-    if (emu128() && wo4) requant128_rows(s, g->att, g->att4, g->att4s, P, d, B);
     { ProfScope p("gemm_attn_out", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? 1 : 0, g->att4, g->att4s);
       if (l > 0 && !c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
@@ -388,12 +385,10 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     // the stream buffer then holds the raw residual and no GEMM re-derives a LayerNorm from the statistics)
     { ProfScope p("layernorm", s, true);
       rc |= layernorm_pair(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, g->x_h16, c.prenorm ? nullptr : g->ln_stats, P, d, f4_for(l)); }
-    if (emu128() && f4_for(l).x4) requant128_rows(s, g->x_h16, g->x4, g->x4s, P, d, B);
     { ProfScope p("gemm_ffn_up", s, true);
       GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, xlo_mode, g->x4, g->x4s);
       if (wh4) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
       rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
-    if (emu128() && wh4) requant128_rows(s, g->h, g->h4, g->h4s, P, f, B);
     { ProfScope p("gemm_ffn_down", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? 1 : 0, g->h4, g->h4s);
       if (!c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b; }
@@ -405,7 +400,6 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       }
       else if (l + 1 == c.depth) layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, g->x_lo);   // feeds the head: plain hi (+ lo) rows
       else rc |= layernorm_pair(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, g->x_h16, g->ln_stats, P, d, f4_for(l + 1)); }
-    if (emu128() && l + 1 < c.depth && f4_for(l + 1).x4) requant128_rows(s, g->x_h16, g->x4, g->x4s, P, d, B);
   }
   rc |= head_gemms(g, logits, M, s);
   hipError_t e = hipGetLastError();

@@ -132,7 +132,6 @@ void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const flo
 // x_h16[r] = fp16(x_c), x_h16[r + P] = fp16(x_u - x_c), both rows' {mean, rstd}; optional f4: e2m1 copies of the CONDITIONAL rows.
 int layernorm_pair(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps, h16* x_h16, float* stats, int P, int d,
                    const Fp4Rows& f4 = Fp4Rows{});
-void requant128_rows(hipStream_t s, const h16* x, uint8_t* x4, uint8_t* x4s, int rows, int width, int nseq);   // experiment (norm_embed.hip)
 int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, const Fp4Rows& f4 = Fp4Rows{});
 
 // ---- bit-token embed + class token + pos-emb + first LayerNorm (bert.py:440-454, 482-496) -------

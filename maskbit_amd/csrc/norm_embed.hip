@@ -384,27 +384,4 @@ void transpose_f32(hipStream_t s, const float* src, float* dst, int rows, int co
   hipLaunchKernelGGL(transpose_f32_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, src, dst, rows, cols);
 }
 
-// EXPERIMENT (round 5; MASKBIT_AMD_EMU128=1, engine.hip): re-derive an e2m1 token operand of the mini-tile passes from the fp16 rows the GEMM itself
-// reads, with ONE power-of-two scale per (row, 128 columns) -- the larger of the two 64-column blocks' scales, stored in both blocks' slots.  What a
-// GEMM that converts its resident fp16 fragments in registers (v_cvt_scalef32_pk_fp4_f16, two K-tiles = 128 K-elements per scaled MFMA) would
-// multiply; run behind the real producers to price that form in token mismatches before the kernel is built.
-__global__ __launch_bounds__(256) void requant128_kernel(const h16* __restrict__ x, uint8_t* __restrict__ x4, uint8_t* __restrict__ x4s, int rows, int width, int nseq) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int seq = row / 257, tok = row - seq * 257;
-  if (tok == 256) return;
-  for (int q = 0; q < width / 256; ++q) {
-    const h16x4 hv = *(const h16x4*)(x + (size_t)row * width + q * 256 + lane * 4);
-    const float4 v = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
-    float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    am = row16_max(am);
-    am = fmaxf(am, __shfl_xor(am, 16));                            // the 128-column block = lane groups (0, 1) / (2, 3)
-    if ((lane & 15) == 0) x4s[fp4_scale_index(q * 4 + (lane >> 4), nseq, seq, tok)] = (uint8_t)fp4_scale_byte_nosat(am);
-    *(uint16_t*)(x4 + (size_t)row * 2 * width + q * 128 + lane * 2) = (uint16_t)fp4_pack4(v.x, v.y, v.z, v.w, fp4_scale_mul_nosat(am));
-  }
-}
-void requant128_rows(hipStream_t s, const h16* x, uint8_t* x4, uint8_t* x4s, int rows, int width, int nseq) {
-  hipLaunchKernelGGL(requant128_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, x4, x4s, rows, width, nseq);
-}
-
 }  // namespace mb
