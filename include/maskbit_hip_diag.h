@@ -39,6 +39,10 @@ int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const
  * optional): e2m1 of the (conditional) outputs + their lane-ordered scales. */
 int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
                  void* out4_scale, int rows, int pair, int N, int K, int nlo, const void* const* lo, mb_stream stream);
+/* ... the pair form for sequences of seq_rows rows incl. the class token (0 = 257; 1 025 = the 512 x 512 models: eight 128-token pair tiles per sequence
+ * pair, (seq_rows - 1) / 64 token groups in the lane-ordered scale arrays). */
+int mb_gemm_mini_seq(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
+                     void* out4_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream);
 /* e2m1 operands of the mini-tile passes: of the fp16 weight values (per-row scales minimising the row's quantisation error) and of the weight's fp16
  * rounding error W - fp16(W); row stride 2K bytes (first K / 2 used), scale bytes in the kernel's lane order; N % 64 == 0. */
 int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);

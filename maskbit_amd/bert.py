@@ -36,12 +36,12 @@ DEFAULT_WCORR_MASK = 15
 
 def pair_capable(seq_len: int, hidden: int, mlp: int, prenorm: bool) -> bool:
     """Shapes the differential guided forward serves (mb_gen_create: pair_ok); post- and (round 4) pre-norm."""
-    return seq_len == 256 and hidden in (768, 1024) and mlp % 256 == 0
+    return seq_len in (256, 1024) and hidden in (768, 1024) and mlp % 256 == 0
 
 
 def mini_capable(seq_len: int, hidden: int, mlp: int, heads: int) -> bool:
     """Shapes the MX-fp4 mini-tile passes serve (mb_gen_create: mini_ok)."""
-    return seq_len == 256 and hidden in (768, 1024) and mlp % 256 == 0 and hidden // heads == 64
+    return seq_len in (256, 1024) and hidden in (768, 1024) and mlp % 256 == 0 and hidden // heads == 64
 
 
 def resolve_act_split(act_split: int, hidden: int, mlp: int) -> int:

@@ -326,9 +326,14 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 // column, and the output accumulators are rescaled by exp2((m_old - m_new) * c) when a block raises the maximum
 // (Milakov-Gimelshein / FlashAttention-style streaming softmax).  K/V blocks are double-buffered through LDS by LDS-DMA.
 constexpr int ATTL_KB = 128;             // keys per block
-template <int DH>
+// PAIRM (round 5: the differential guided forward of the 1024 + 1-token models): the workgroup runs its 64 queries against the conditional sequence,
+// keeps the normalised fp32 output tile (16 VGPRs), then against the label-dropped twin `sq_off` sequences further down and stores
+// fp16(o_u - o_c) there -- the pair form of attention_kernel<DH, 4>.  out4 / out4s (optional, DH = 64): e2m1 of the conditional outputs + one scale
+// byte per (row, head), lane-ordered with (N - 1) / 64 token groups per sequence, for the out-proj pair GEMM's weight-correction mini-tiles.
+template <int DH, bool PAIRM = false>
 __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
-                                                               int N, int d, int heads, int nchunk, float scale_log2e) {
+                                                               int N, int d, int heads, int nchunk, float scale_log2e, int sq_off = 0,
+                                                               uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0) {
   constexpr int ROW = DH * 2, SL = DH / 8, KS = DH / 32, NT = DH / 16, RPI = 64 / SL;
   constexpr int BLK_BYTES = ATTL_KB * ROW;                 // one operand block
   constexpr int NINST = ATTL_KB / RPI;                     // DMA instructions per operand block (16 or 8)
@@ -338,12 +343,17 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int chunk = bid % nchunk; bid /= nchunk;
-  const int sq = bid / heads, h = bid - sq * heads;
+  const int sq0 = bid / heads, h = bid - sq0 * heads;
   const size_t rs = (size_t)3 * d;
-  const h16* base = qkv + (size_t)sq * N * rs + h * DH;
   auto kswz = [](int row) { return SL == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
   auto vswz = [](int row) { return SL == 8 ? (((row >> 1) & 3) << 1) : (((row >> 1) & 1) << 1); };
   const int nblk = (N + ATTL_KB - 1) / ATTL_KB;
+  f32x4 oc[NT];                                            // PAIRM: the conditional pass's output tile
+#pragma unroll 1
+  for (int pass = 0; pass < (PAIRM ? 2 : 1); ++pass) {
+  const int sq = sq0 + pass * sq_off;
+  const h16* base = qkv + (size_t)sq * N * rs + h * DH;
+  if (PAIRM && pass > 0) __syncthreads();                  // (the last block's buffer is free: the loop below ends with a barrier; kept for clarity)
   auto stage = [&](int b, int buf) {                       // rows >= N re-read row N-1 (masked below)
     char* Kb = smem + buf * 2 * BLK_BYTES;
     char* Vb = Kb + BLK_BYTES;
@@ -450,12 +460,32 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
     __syncthreads();                                          // everyone is done with this buffer before it is refilled
   }
   const int q = qt * 16 + l15;
-  if (q < N) {
-    const float inv = 1.0f / l_run;
-    const size_t ooff = ((size_t)sq * N + q) * d + h * DH;
+  const float inv = 1.0f / l_run;
+  if constexpr (PAIRM && DH == 64) {
+    if (out4s && pass == 0) {                              // block (row, head) = this lane's 16 values x its 4 lane groups (cf. attention_kernel)
+      float am = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(o[nt][r] * inv));
+      am = rows_max(am);
+      const float mul = fp4_scale_mul_nosat(am);
+      if (q < N - 1) {                                     // (class-token rows take no part in the mini-tile passes)
+        const size_t row = (size_t)sq * N + q;
+        if (g == 0) out4s[fp4_scale_index(h, out4_nseq, sq, q, (N - 1) >> 6)] = (uint8_t)fp4_scale_byte_nosat(am);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          *(uint16_t*)(out4 + row * 2 * d + (h * DH + nt * 16 + g * 4) / 2) = (uint16_t)fp4_pack4(o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv, mul);
+      }
+    }
+  }
+  if (q < N || PAIRM) {
+    const size_t ooff = ((size_t)sq * N + min(q, N - 1)) * d + h * DH;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const f32x4 v = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+      f32x4 v = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+      if constexpr (PAIRM) { if (pass == 0) oc[nt] = v; else v = v - oc[nt]; }
+      if (q >= N) continue;
       const h16x4 hi = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
       *(h16x4*)(out + ooff + nt * 16 + g * 4) = hi;
       if (out_lo)
@@ -464,6 +494,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
       if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4h(v[0], v[1], v[2], v[3], hi);
     }
   }
+  }                                      // pass
 }
 
 // ---- return_attn=True (bert.py:119,137: need_weights with the default average_attn_weights): the head-averaged softmax
@@ -576,8 +607,16 @@ void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width) {
 
 int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads, uint8_t* out4, uint8_t* out4s) {
   const int dh = d / heads;
-  if (N > ATT_NP || (dh != 64 && dh != 32)) return -1;
+  if (dh != 64 && dh != 32) return -1;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  if (N > ATT_NP) {                                           // the 1024 + 1-token models: streaming kernel, both streams of a pair in one workgroup
+    if (out4 && (dh != 64 || (N - 1) % 64)) return -1;
+    const int nchunk = ((N + 15) / 16 + 3) / 4;
+    dim3 grid(P * heads * nchunk), block(256);
+    if (dh == 64) hipLaunchKernelGGL((attention_long_kernel<64, true>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, nchunk, scale_log2e, P, out4, out4s, P);
+    else hipLaunchKernelGGL((attention_long_kernel<32, true>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, nchunk, scale_log2e, P);
+    return 0;
+  }
   dim3 grid(P * heads), block(64 * ATT_NW);
   // A/B switch, read once per process: 4 (default) = one launch / 2 = two launches through the fp32 aux rows
   static const int pair_mode = getenv("MASKBIT_AMD_ATT_PAIR") ? atoi(getenv("MASKBIT_AMD_ATT_PAIR")) : 4;

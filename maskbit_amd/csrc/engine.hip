@@ -212,7 +212,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   // act_split 1 composes, and is what LFQBert.resolved_precision() picks by default next to cfg_pair >= 2: the LayerNorm outputs then ALSO enter
   // QKV / FFN-up as fp16 hi + lo pairs (the fp16 sweep of those two GEMMs doubles) -- the emulator's 63 -> 41 mismatches on configs[1], measured
   // 5.3e-4 against 7.0e-4 over its three reference runs at 0.82-0.89 of the speed; act_split 0 is the faster opt-out.  act_split 2 / 3: hi + lo pairs alone.
-  const bool wm = g->mini_ok && c.cfg_pair >= 2 && c.act_split <= 1 && !c.weight_split;
+  const bool wm = g->mini_ok && c.seq == 256 && c.cfg_pair >= 2 && c.act_split <= 1 && !c.weight_split;   // (plain sequence tiles are 256 + 1 rows: the 1024 + 1-token models run their plain forward with act_split alone)
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
   Fp4Rows f4x;
   if (wm && (g->wcorr_mask & 5)) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; }
@@ -334,7 +334,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   const bool alo = wmode && c.cfg_pair == 3;             // + activation-lo mini-tiles of the LayerNorm outputs (QKV / FFN-up)
   auto f4_for = [&](int consumer_layer) {                // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
-    if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) { f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; if (alo) { f.xl4 = g->xl4; f.xl4s = g->xl4s; } }
+    if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) { f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; f.seq_rows = N; if (alo) { f.xl4 = g->xl4; f.xl4s = g->xl4s; } }
     return f;
   };
   // lo: 0 = fp16 only, 1 = weight-correction mini-tiles (a4 / a4s = e2m1 of the conditional operand values), 2 = + the activation-lo set (x only)
@@ -342,6 +342,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
                    const uint8_t* a4 = nullptr, const uint8_t* a4s = nullptr) {
     GemmArgs ga{A, W, bias, res, res, out16, M, Nout, g->split ? 2 * K : K, 0, g->split ? K : 0, g->sc(widx)};   // fp16x2 weights: A swept twice
     ga.pair_rows = P;
+    ga.seq_rows = N;
     if (epi != EPI_RES_F32) ga.sat = g->sat;
     if (lo && !((g->wcorr_mask >> (widx & 3)) & 1)) lo = 0;
     if (lo) {
@@ -507,13 +508,17 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
 }
 int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
                  void* out4_scale, int rows, int pair, int N, int K, int nlo, const void* const* lo /* nlo x {A4, a_scale, W4, w_scale} */, mb_stream stream) {
-  if (!A || !W || !bias || epi < 0 || epi > 2 || rows <= 0 || K <= 0 || K % 64 || nlo < 0 || nlo > 2 || (nlo && !lo)) return fail(-1, "mb_gemm_mini: bad arguments");
+  return mb_gemm_mini_seq(epi, A, W, bias, residual, out_f32, out_h16, out4, out4_scale, rows, pair, 0, N, K, nlo, lo, stream);
+}
+int mb_gemm_mini_seq(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
+                     void* out4_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream) {
+  if (!A || !W || !bias || epi < 0 || epi > 2 || rows <= 0 || K <= 0 || K % 64 || nlo < 0 || nlo > 2 || (nlo && !lo) || (seq_rows && !pair)) return fail(-1, "mb_gemm_mini: bad arguments");
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, pair ? 2 * rows : rows, N, K, 0, 0, nullptr};
-  if (pair) a.pair_rows = rows;
+  if (pair) { a.pair_rows = rows; a.seq_rows = seq_rows; }
   a.nlo = nlo;
   for (int i = 0; i < nlo; ++i) a.lo[i] = {(const uint8_t*)lo[4 * i], (const uint8_t*)lo[4 * i + 1], (const uint8_t*)lo[4 * i + 2], (const uint8_t*)lo[4 * i + 3]};
   a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale;
-  if (a.M % 257 || !mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_mini: shape not supported by the sequence-aligned tiles");
+  if ((!seq_rows && a.M % 257) || !mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_mini: shape not supported by the sequence-aligned tiles");
   ProfScope p("gemm_diag", (hipStream_t)stream);
   if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, 257)) return fail(-3, "mb_gemm_mini: shape refused");
   hipError_t e = hipGetLastError();
@@ -681,15 +686,16 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   }
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
   // MX-fp4 mini-tile passes (cfg_pair 2 / 3): 257-token sequences, vector LayerNorm widths, heads of 64 (the attention kernels' e2m1 output), whole mini-tiles
-  g->mini_ok = c.cfg_pair >= 2 && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && c.hidden / c.heads == 64 && !c.weight_split;   // (FFN-up's N = mlp: whole 256-column tiles)
+  g->mini_ok = c.cfg_pair >= 2 && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && c.hidden / c.heads == 64 && !c.weight_split;   // (FFN-up's N = mlp: whole 256-column tiles)
   // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
   // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice)
-  g->pair_ok = c.cfg_pair && c.seq == 256 && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && g->chunk_seqs >= 2 &&
+  // (round 5: also the 1024 + 1-token models of 512 x 512 images -- a pair tile is 128 tokens of a sequence pair whatever the sequence length)
+  g->pair_ok = c.cfg_pair && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && g->chunk_seqs >= 2 &&
                (c.cfg_pair == 1 || g->mini_ok);
   if (g->pair_ok) rc |= galloc(g, &g->att_aux, (M / 2) * d);
   if (g->mini_ok) {
     // e2m1 operands: row stride of the fp16 sibling (2 * width bytes, first width / 2 used); scale bytes in lane order: [width / 64][sequences][256]
-    const size_t ns = (size_t)g->chunk_seqs * 256;
+    const size_t ns = (size_t)g->chunk_seqs * c.seq;
     rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->att4, M * 2 * d); rc |= galloc(g, &g->att4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->h4, M * 2 * f); rc |= galloc(g, &g->h4s, (f / 64) * ns + 256);

@@ -155,6 +155,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // receives chunk 2g+ks, the 32 bytes lane group g feeds to the K = 128 MFMA), so the fragment reads are the fp16 ones -- reading
   // chunks 2g+ks in place was a 2-way LDS bank conflict on every read (PMC: 10.2 M conflict cycles of 40.9 M active, fp16 tiles: 0)
   constexpr bool PERM = F8 && SEQ;
+  // pair tiles: SQ rows per sequence (class token last), TPS = (SQ - 1) / 128 tiles per sequence pair (2 or 8: a power of two), 2 TPS groups of 64 tokens
+  const int SQ = a.seq_rows ? a.seq_rows : 257;
+  const int tps_sh = PAIR ? 31 - __builtin_clz((unsigned)((SQ - 1) >> 7)) : 1;
+  const int TPS = 1 << tps_sh;
   const h16* const Alo = F8 ? (const h16*)a.A8 : (F4 ? (const h16*)a.A4 : (a.A2 ? a.A2 : a.A));
   const h16* const Wlo = F8 ? (const h16*)a.W8 : (F4 ? (const h16*)a.W4 : a.W);
   const int ntiles = tiles_m * tiles_n;
@@ -180,10 +184,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int rows_sr = min(8, tiles_m - sr * 8);
     const int rem = L - sr * 8 * tiles_n;
     const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
-    p.m0 = PAIR ? (tm >> 1) * 257 + (tm & 1) * 128 : tm * TILE_ROWS; p.n0 = (tn / NS) * 256;
+    p.m0 = PAIR ? (tm >> tps_sh) * SQ + (tm & (TPS - 1)) * 128 : tm * TILE_ROWS; p.n0 = (tn / NS) * 256;
     p.hb = tn % NS;
-    p.cls = PAIR ? (tm >> 1) * 257 + 256 : 0; p.q = tm & 1;
-    p.seq = PAIR ? tm >> 1 : tm;
+    p.cls = PAIR ? (tm >> tps_sh) * SQ + SQ - 1 : 0; p.q = tm & (TPS - 1);
+    p.seq = PAIR ? tm >> tps_sh : tm;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ja = min(wave + 8 * j, A_INSTR - 1);   // surplus slot re-loads the last chunk (uniform vmcnt)
@@ -256,7 +260,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // (KM: the K extent of the operands = of the corrections; with split activations -- A2 / kw, plain tiles -- the fp16 sweep is twice as long)
   const int KM = a.kw ? a.kw : K;
   const int nmk = KM / 128;
-  const int nseq = PAIR ? a.pair_rows / 257 : a.M / 257;
+  const int nseq = PAIR ? a.pair_rows / SQ : a.M / 257;
+  const int grp_bytes = PAIR ? TPS * 128 : 256;          // scale bytes per (64-column block, sequence): 64 per 64-token group
   const bool mini_every = MINI && (PAIR ? a.nlo == 2 : !a.kw);   // one mini-tile per fp16 K-tile (else one per two)
   auto mini_lane = [&]() -> uint32_t {
     int lo_ = lane; asm volatile("" : "+v"(lo_));
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
     const int gq = PAIR ? p.q * 2 + wm : wm * 2 + ps;
     int lo_ = lane; asm volatile("" : "+v"(lo_));
-    return ((uint32_t)(2 * jj + (lo_ >> 5)) * nseq + p.seq) * 256 + gq * 64 + (lo_ & 15) * 4;
+    return ((uint32_t)(2 * jj + (lo_ >> 5)) * nseq + p.seq) * grp_bytes + gq * 64 + (lo_ & 15) * 4;
   };
   int mwsc0 = 0, mwsc1 = 0, mxs = 0;                    // MINI: weight scale dwords of the (two) operand sets, the current mini's token scale dword
   auto mini_scale_issue = [&](const Plan& p, int j) {    // inline asm: counted by the K loop's own vmcnt wait, which the register is tied through
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #ifdef MB_NO_CLS                                            /* experiment (timing only): what the class-token rows' MFMAs and fragment reads cost */
     const bool cls_on = false;
 #else
-    const bool cls_on = !PAIR || __builtin_amdgcn_readfirstlane(cur.q) == 1;
+    const bool cls_on = !PAIR || __builtin_amdgcn_readfirstlane(cur.q) == TPS - 1;
 #endif
     h16x16 xa[MH], wb[2][2];      // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       return r < MT ? n0 + wn * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + ge * 4 : n0 + wn * 64 + wm * 32 + nt * 16 + ge * 4;
     };
     auto row_ok = [&](int r) {
-      if (PAIR) return r < MT ? true : (l15e < 2 && tq == 1);
+      if (PAIR) return r < MT ? true : (l15e < 2 && tq == TPS - 1);
       return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : (l15e == 0 && (!HN || wm == 0));
     };
     // ---- next tile: start its first two K-tiles NOW (all LDS is free), so they fly during the epilogue math.
@@ -761,7 +766,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         // block (4 n-tiles x 4 lane groups x 4 columns), and the four m-tiles of a lane in one 64-row group are one dword of the lane-ordered scale
         // array (GemmArgs.lo); class-token rows are skipped (they take no part in those passes)
         const uint32_t blk = (uint32_t)(n0 >> 6) + wn;
-        const uint32_t nsq = PAIR ? (uint32_t)a.pair_rows / 257 : (uint32_t)a.M / 257;
+        const uint32_t nsq = PAIR ? (uint32_t)a.pair_rows / (uint32_t)SQ : (uint32_t)a.M / 257;
+        const uint32_t ngrp = PAIR ? (uint32_t)TPS * 2 : 4u;
 #pragma unroll
         for (int hh = 0; hh < (PAIR ? 1 : 2); ++hh) {
           uint32_t sc4 = 0;
@@ -792,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             *(uint2*)(a.out4 + (size_t)row * 2 * a.N + ((n0 + wn * 64) >> 1) + (ge >> 1) * 16 + (ge & 1) * 8) = make_uint2(sx[0], sx[1]);
           }
           const uint32_t gq = PAIR ? (uint32_t)tq * 2 + wm : (uint32_t)wm * 2 + hh;
-          if (ge == 0) ((uint32_t*)a.out4_scale)[((blk * nsq + (uint32_t)cur.seq) * 4 + gq) * 16 + l15e] = sc4;
+          if (ge == 0) ((uint32_t*)a.out4_scale)[((blk * nsq + (uint32_t)cur.seq) * ngrp + gq) * 16 + l15e] = sc4;
         }
       }
     }
@@ -988,7 +994,8 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
     (void)hipFuncSetAttribute((const void*)gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     configured = true;
   }
-  const int tiles_m = PAIR ? (a.pair_rows / 257) * 2 : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * NS;
+  const int sq_rows = a.seq_rows ? a.seq_rows : 257;
+  const int tiles_m = PAIR ? (a.pair_rows / sq_rows) * ((sq_rows - 1) / 128) : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * NS;
   static const bool f4_persist = !getenv("MASKBIT_AMD_F4_PERSIST") || atoi(getenv("MASKBIT_AMD_F4_PERSIST")) != 0;   // A/B switch (experiments)
   static const bool res_persist = !getenv("MASKBIT_AMD_RES_PERSIST") || atoi(getenv("MASKBIT_AMD_RES_PERSIST")) != 0;   // A/B switch (experiments)
   if (XP == 5 && !f4_persist) persistent = false;
@@ -999,9 +1006,11 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
-  if (a.pair_rows && (a.pair_rows % 257 || a.M != 2 * a.pair_rows || a.A8 || a.A2 || (a.ka && a.A4) || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
+  const int sqr = a.seq_rows ? a.seq_rows : 257;
+  if (a.seq_rows && (!a.pair_rows || (sqr - 1) % 128 || ((sqr - 1) / 128 & ((sqr - 1) / 128 - 1)))) return false;   // pair tiles only; 128-token tiles, a power of two per sequence
+  if (a.pair_rows && (a.pair_rows % sqr || a.M != 2 * a.pair_rows || a.A8 || a.A2 || (a.ka && a.A4) || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
   // (plain tiles may combine the mini-tiles with split activations: A2 / kw, K = 2 kw -- hi + lo LayerNorm outputs AND the weight correction)
-  if (a.nlo && (a.nlo > 2 || a.M % 257 || (a.kw ? a.kw : a.K) % 128 || a.A8 || a.A4 || a.ka || a.out_lo || a.out_lo8 || (!a.pair_rows && a.nlo != 1) ||
+  if (a.nlo && (a.nlo > 2 || (a.pair_rows ? a.pair_rows % sqr : a.M % 257) || (a.kw ? a.kw : a.K) % 128 || a.A8 || a.A4 || a.ka || a.out_lo || a.out_lo8 || (!a.pair_rows && a.nlo != 1) ||
                 ((a.A2 || a.kw) && (a.pair_rows || !a.A2 || a.K != 2 * a.kw)) ||
                 !a.lo[0].A4 || !a.lo[0].W4 || !a.lo[0].a_scale || !a.lo[0].w_scale ||
                 (a.nlo == 2 && (!a.lo[1].A4 || !a.lo[1].W4 || !a.lo[1].a_scale || !a.lo[1].w_scale)) || (uint64_t)a.M * a.K * 2 >= (1ull << 32) ||

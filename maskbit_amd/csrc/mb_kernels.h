@@ -70,6 +70,9 @@ struct GemmArgs {
   // rows: out_c = f(A_c . W), out_u = f(A_c . W + A_delta . W) -- with the GELU epilogue the unconditional rows receive gelu(u) - gelu(c),
   // i.e. the next GEMM's difference operand.  See gemm_ht.hip and DESIGN.md "Precision".
   int pair_rows = 0;
+  // pair tiles: rows per sequence incl. the class token (0 = 257).  A pair tile is 128 tokens of one sequence pair, so any (seq_rows - 1) % 128 == 0
+  // is served: 257 (256 x 256 images) and 1 025 (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144); the LAST tile of a pair stores the class rows.
+  int seq_rows = 0;
   // pair tiles + fp4 pass: a_scale is a_scale[row][kw / 64] (one E8M0 byte per 64 K-elements of a conditional row).  GELU epilogue (pair tiles):
   // out4 / out4_scale (optional) receive e2m1 of the conditional OUTPUT values (row stride 2N bytes) and their block bytes out4_scale[row][N / 64],
   // the token operand of the next GEMM's weight-correction pass; class-token rows are left untouched (their bytes stay 0: no correction).
@@ -102,8 +105,9 @@ __host__ __device__ inline size_t w4_packed_offset(int n, int k, int K) {
   return ((size_t)(n >> 4) * (K >> 7) + (k >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 1) & 3)) << 4) + ((k & 31) >> 1);
 }
 // byte index of the scale of (token row r of sequence seq, 64-column block blk) in the lane-ordered scale arrays of the mini-tile passes
-__host__ __device__ inline size_t fp4_scale_index(int blk, int nseq, int seq, int r) {
-  return (((size_t)blk * nseq + seq) * 4 + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3);
+// (groups = 64-token groups per sequence: 4 for the 256-token models, 16 for the 1024-token ones of 512 x 512 images)
+__host__ __device__ inline size_t fp4_scale_index(int blk, int nseq, int seq, int r, int groups = 4) {
+  return (((size_t)blk * nseq + seq) * groups + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3);
 }
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   // 0, or -1: lo-pass request outside the half-tile kernel's shapes
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
@@ -121,7 +125,7 @@ void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K,
 // e2m1 copies written by the row-wise producers for the trunk GEMMs' mini-tile passes (GemmArgs.lo): the rows' VALUES (x4, with the
 // lane-ordered per-(row, 64 columns) scale bytes x4s) and / or their fp16 LO HALVES x - fp16(x) (xl4 / xl4s); rows are tokens of nseq sequences of
 // 257 (row stride 2d bytes, first d / 2 used; class-token rows are skipped).  hidden = 768 / 1024 only.
-struct Fp4Rows { uint8_t* x4 = nullptr; uint8_t* x4s = nullptr; uint8_t* xl4 = nullptr; uint8_t* xl4s = nullptr; int nseq = 0; };
+struct Fp4Rows { uint8_t* x4 = nullptr; uint8_t* x4s = nullptr; uint8_t* xl4 = nullptr; uint8_t* xl4s = nullptr; int nseq = 0; int seq_rows = 257; };   // seq_rows: tokens per sequence incl. the class token
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,

@@ -15,26 +15,26 @@ constexpr int MAXS = 32;  // scalar fallback path: d <= 64 * MAXS = 2048
 // power-of-two scale per 64 columns -- 16 lanes of one q -- chosen from the block's largest element without saturation (3 < max <= 6), its E8M0
 // byte stored in the lane-ordered scale array.  A massive-activation channel then costs the resolution of its own 64-column block, not of the row.
 template <int NV>
-__device__ __forceinline__ void fp4_row_store(const float4* v, int lane, uint8_t* x4row, uint8_t* scales, int nseq, int seq, int tok) {
+__device__ __forceinline__ void fp4_row_store(const float4* v, int lane, uint8_t* x4row, uint8_t* scales, int nseq, int seq, int tok, int groups) {
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     float am = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
     am = row16_max(am);
-    if ((lane & 15) == 0) scales[fp4_scale_index(q * 4 + (lane >> 4), nseq, seq, tok)] = (uint8_t)fp4_scale_byte_nosat(am);
+    if ((lane & 15) == 0) scales[fp4_scale_index(q * 4 + (lane >> 4), nseq, seq, tok, groups)] = (uint8_t)fp4_scale_byte_nosat(am);
     *(uint16_t*)(x4row + q * 128 + lane * 2) = (uint16_t)fp4_pack4(v[q].x, v[q].y, v[q].z, v[q].w, fp4_scale_mul_nosat(am));
   }
 }
 // values (f4.x4) and / or fp16 lo halves (f4.xl4) of row `row` (token row % 257 of sequence row / 257; class-token rows take no part)
 template <int NV>
 __device__ __forceinline__ void fp4_rows_out(const Fp4Rows& f4, float4* v, int lane, int row, int d) {
-  const int seq = row / 257, tok = row - seq * 257;
-  if (tok == 256) return;
-  if (f4.x4) fp4_row_store<NV>(v, lane, f4.x4 + (size_t)row * 2 * d, f4.x4s, f4.nseq, seq, tok);
+  const int seq = row / f4.seq_rows, tok = row - seq * f4.seq_rows, groups = (f4.seq_rows - 1) >> 6;
+  if (tok == f4.seq_rows - 1) return;
+  if (f4.x4) fp4_row_store<NV>(v, lane, f4.x4 + (size_t)row * 2 * d, f4.x4s, f4.nseq, seq, tok, groups);
   if (f4.xl4) {
 #pragma unroll
     for (int q = 0; q < NV; ++q)
       v[q] = make_float4(v[q].x - (float)to_h(v[q].x), v[q].y - (float)to_h(v[q].y), v[q].z - (float)to_h(v[q].z), v[q].w - (float)to_h(v[q].w));
-    fp4_row_store<NV>(v, lane, f4.xl4 + (size_t)row * 2 * d, f4.xl4s, f4.nseq, seq, tok);
+    fp4_row_store<NV>(v, lane, f4.xl4 + (size_t)row * 2 * d, f4.xl4s, f4.nseq, seq, tok, groups);
   }
 }
 

@@ -37,14 +37,18 @@ def token_mismatch(a: torch.Tensor, b: torch.Tensor, where=None) -> float:
     return float(ne.float().mean())
 
 
-def gemm_mini(lib, epi, A, W, bias, res, out32, out16, rows, pair, N, K, lo_sets=(), out4=None, out4s=None):
-    """mb_gemm_mini (include/maskbit_hip_diag.h): a sequence-aligned (pair) GEMM with len(lo_sets) MX-fp4 mini-tile passes; a set = (A4, a_scale, W4,
-    w_scale) tensors."""
+def gemm_mini(lib, epi, A, W, bias, res, out32, out16, rows, pair, N, K, lo_sets=(), out4=None, out4s=None, seq_rows=0):
+    """mb_gemm_mini / mb_gemm_mini_seq (include/maskbit_hip_diag.h): a sequence-aligned (pair) GEMM with len(lo_sets) MX-fp4 mini-tile passes; a set =
+    (A4, a_scale, W4, w_scale) tensors; seq_rows: rows per sequence of a pair GEMM (0 = 257)."""
     import ctypes as C
     from maskbit_amd import _lib
     ptr = lambda t: t.data_ptr() if t is not None else None
     flat = [t.data_ptr() for s in lo_sets for t in s]
     arr = (C.c_void_p * max(1, len(flat)))(*flat)
+    if seq_rows:
+        _lib.check(lib.mb_gemm_mini_seq(epi, ptr(A), ptr(W), ptr(bias), ptr(res), ptr(out32), ptr(out16), ptr(out4), ptr(out4s), rows, int(pair), seq_rows, N, K,
+                                        len(lo_sets), arr, torch.cuda.current_stream().cuda_stream), "mb_gemm_mini_seq")
+        return
     _lib.check(lib.mb_gemm_mini(epi, ptr(A), ptr(W), ptr(bias), ptr(res), ptr(out32), ptr(out16), ptr(out4), ptr(out4s), rows, int(pair), N, K,
                                 len(lo_sets), arr, torch.cuda.current_stream().cuda_stream), "mb_gemm_mini")
 
@@ -73,17 +77,19 @@ def f4_block_exponent(amax: torch.Tensor) -> torch.Tensor:
     return (e + 126) + (m > 0.75).to(torch.int32)
 
 
-def f4_scale_index(blk, nseq, seq, r):
-    """mb_kernels.h fp4_scale_index: byte index of (64-column block blk, token r of sequence seq) in a lane-ordered scale array."""
-    return ((blk * nseq + seq) * 4 + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3)
+def f4_scale_index(blk, nseq, seq, r, groups=4):
+    """mb_kernels.h fp4_scale_index: byte index of (64-column block blk, token r of sequence seq) in a lane-ordered scale array (groups = 64-token
+    groups per sequence: 4, or 16 for the 1024-token models)."""
+    return ((blk * nseq + seq) * groups + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3)
 
 
-def f4_encode_rows(v: torch.Tensor, nseq: int, dev="cuda"):
-    """What the engine's producers write for rows of values v [nseq * 257, K] (float64, CPU or GPU): (x4 uint8 [R, 2K] with garbage in the class-token
+def f4_encode_rows(v: torch.Tensor, nseq: int, dev="cuda", seq_rows: int = 257):
+    """What the engine's producers write for rows of values v [nseq * seq_rows, K] (float64, CPU or GPU): (x4 uint8 [R, 2K] with garbage in the class-token
     rows and the padding, lane-ordered scale bytes, the decoded float64 operand [R, K] with zeros in the class-token rows)."""
     v = v.double().cpu()
     R, K = v.shape
-    assert R == nseq * 257 and K % 64 == 0
+    assert R == nseq * seq_rows and K % 64 == 0
+    ntok, groups = seq_rows - 1, (seq_rows - 1) // 64
     blocks = v.reshape(R, K // 64, 64)
     amax = blocks.abs().amax(-1)
     E = f4_block_exponent(amax.clamp(min=1e-30))
@@ -92,12 +98,12 @@ def f4_encode_rows(v: torch.Tensor, nseq: int, dev="cuda"):
     x4 = torch.randint(0, 256, (R, 2 * K), dtype=torch.uint8)
     x4[:, : K // 2] = (codes[:, 0::2] | (codes[:, 1::2] << 4)).to(torch.uint8)
     dec = (_F4V[codes].reshape(R, K // 64, 64) * (2.0 ** (sbyte.double() - 127)).unsqueeze(-1)).reshape(R, K)
-    scales = torch.randint(0, 256, ((K // 64) * nseq * 256 + 256,), dtype=torch.uint8)
+    scales = torch.randint(0, 256, ((K // 64) * nseq * ntok + 256,), dtype=torch.uint8)
     rows = torch.arange(R)
-    seq, tok = rows // 257, rows % 257
-    keep = tok < 256
+    seq, tok = rows // seq_rows, rows % seq_rows
+    keep = tok < ntok
     for b in range(K // 64):
-        idx = f4_scale_index(b, nseq, seq[keep], tok[keep])
+        idx = f4_scale_index(b, nseq, seq[keep], tok[keep], groups)
         scales[idx] = sbyte[keep, b].to(torch.uint8)
     dec[~keep] = 0.0
     x4[~keep] = torch.randint(0, 256, (int((~keep).sum()), 2 * K), dtype=torch.uint8)      # class-token rows: garbage, must not matter

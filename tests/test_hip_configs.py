@@ -168,15 +168,16 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("name,expect,bound", [("sample_full12_64_prenorm", (1, 2), 8e-4), ("sample_full12_64_seq1024", (3, 0), 1e-3)])
+@pytest.mark.parametrize("name,expect,bound", [("sample_full12_64_prenorm", (1, 2), 8e-4), ("sample_full12_64_seq1024", (1, 2), 7e-4)])
 def test_generator_variants_full_width_vs_reference_runs(name, expect, bound):
     """configs[2]'s sampler (64 steps, CFG 7.1 cosine) on the two generator variants of the reference that differ in how the engine runs the guided
     forward, against full-width runs of the REAL reference (oracle/make_golden.py RUNS):
       * use_prenorm=True (bert.py:49-59, 106-123): since round 4 the guided forward runs in differential form here too (the LayerNorm pair kernel in
         front of each sub-layer, the raw residual in the stream buffer) with the weight-correction mini-tiles -- as independent streams the same
         mini-tiles measured 1.44e-3 (guidance multiplies the two streams' separate fp16 roundings), hi + lo activation pairs 8.4e-4;
-      * 1024 + 1 tokens (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144): no pair tiles for this sequence length; the guided forward is the
-        plain forward over [cond | uncond] with hi + lo activation pairs (act_split 3), measured 7.6e-4 (single fp16: 1.11e-3)."""
+      * 1024 + 1 tokens (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144): since round 5 the differential form with the weight-correction
+        mini-tiles here too (eight 128-token pair tiles per sequence pair, the streaming attention kernel in pair form); rounds 3-4 ran the plain forward
+        over [cond | uncond] with hi + lo activation pairs (act_split 3) and measured 7.6e-4 (single fp16: 1.11e-3)."""
     import parity_replay as R
     g = R.load_run(name)
     gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
