@@ -146,14 +146,14 @@ def measured_parity(gen, run=None, batch=B_PER_GPU):
 
 def other_runs_parity(dev, mode_settings):
     """The same measurement on the OTHER full-size 12-bit runs of the reference (other generator weights, head gain, noise seed and labels:
-    tests/golden/sample_full12_64_s2.npz, 84 284 positions, and _s3.npz, batch 8, 168 568 positions) for each (weight_split, act_split, cfg_pair)
+    tests/golden/sample_full12_64_s2.npz, 84 284 positions, and _s3.npz, batch 8, 168 568 positions) for each LFQBert.precision
     in `mode_settings` -> {mode: {run: parity, "pooled_with_first_run": ...}} (the first run's count is added by the caller's own measurement)."""
     from maskbit_amd import parity_replay as R
     out = {m: {} for m in mode_settings}
     for run in (R.RUN_C3_S2, R.RUN_C3_S3):
         gen, _ = R.build_models(dev, with_tokenizer=False, name=run)
-        for name, (ws, asplit, pair) in mode_settings.items():
-            gen.weight_split, gen.act_split, gen.cfg_pair = ws, asplit, pair
+        for name, prec in mode_settings.items():
+            gen.precision = prec
             out[name][run] = measured_parity(gen, run)
         del gen
         torch.cuda.empty_cache()
@@ -181,12 +181,10 @@ def other_configs(dev):
         plan = build_plan(int(kw["num_steps"]), 512, float(kw["guidance_scale"]), kw["guidance_annealing"], float(kw["scale_pow"]), 1.0, False,
                           kw["mask_schedule_strategy"])
         rt = float(kw["randomize_temperature"])
-        # unguided sampling runs the plain forward: also timed with act_split = 0 (the weight correction over single fp16 activations -- the faster
-        # opt-out, 7.0e-4 instead of 5.3e-4 token mismatch over the three reference runs of this configuration, profiles/r04_parity.md)
-        variants = (("", -1), (" [act_split = 0]", 0)) if float(kw["guidance_scale"]) == 0.0 else (("", -1),)
+        # (round 4 also timed an opt-out for unguided sampling -- the weight correction over single fp16 activations, 7.0e-4 instead of 5.3e-4 token
+        # mismatch at 1.15-1.2x the speed; removed with the one-knob precision of round 5: the default carries the margin)
         for B in batches:
-          for vtag, act in variants:
-            gen.act_split = act
+          for vtag in ("",):
             labels = (torch.arange(B) * 37 % 1000).to(dev)
             torch.manual_seed(0)
             reps = 3 if int(kw["num_steps"]) < 100 else 1
@@ -197,8 +195,46 @@ def other_configs(dev):
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
             out[f"{tag}, batch {B}{vtag}"] = {"images_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B,
-                                              "precision": "LFQBert (act_split, cfg_pair) = %s" % (gen.resolved_precision(),)}
+                                              "precision": "LFQBert.precision = %d" % gen.resolved_precision()}
         del gen, tok
+        torch.cuda.empty_cache()
+    out.update(variant_configs(dev))
+    return out
+
+
+def variant_configs(dev):
+    """The generator variants of SURVEY.md section 8(f) through the same sample() path with configs[2]'s sampler (64 steps, CFG 7.1 cosine, arccos),
+    decode to uint8 included, one timed batch each after a warm-up batch: use_prenorm=True (bert.py:49-59,106-123), the embedding-table `Bert` class
+    (bert.py:184-340), and the 1024 + 1-token generator of the 512 x 512 models (scripts/eval_maskbit.py:125,139-144) at batch 16 with a 32 x 32-latent
+    decode to 512 x 512.  All three run the differential guided forward with the weight-correction mini-tiles (resolved precision in the entry)."""
+    from maskbit_amd import Bert, ConvVQModel, LFQBert, synth
+    from maskbit_amd.sampling import build_plan, run_chunked
+    out = {}
+    tok = ConvVQModel(tok_config())
+    tok.load_state_dict(synth.make_tokenizer_weights(synth.TokCfg(token_size=12), seed=TOK_SEED), strict=False)
+    tok = tok.eval().requires_grad_(False).to(dev)
+    for tag, cls, kw, gcfg, B in (
+            ("variant: use_prenorm=True, 12-bit/64 steps/CFG 7.1", LFQBert, dict(use_prenorm=True), synth.GenCfg(bits=12, splits=2, prenorm=True), 64),
+            ("variant: Bert (embedding tables, tied head), 12-bit/64 steps/CFG 7.1", Bert, dict(), synth.GenCfg(bits=12, splits=2, kind="bert"), 64),
+            ("variant: 1024 + 1 tokens (512 x 512 models), 12-bit/64 steps/CFG 7.1", LFQBert, dict(img_size=512), synth.GenCfg(bits=12, splits=2, seq=1024), 16)):
+        try:
+            gen = cls(**dict(GEN, **kw))
+            gen.load_state_dict(synth.make_generator_weights(gcfg, seed=GEN_SEED + 1, head_gain=HEAD_GAIN), strict=True)
+            gen = gen.eval().requires_grad_(False).to(dev)
+            plan = build_plan(NUM_STEPS, 2 * gen.seq_len, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
+                              SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])
+            labels = (torch.arange(B) * 37 % 1000).to(dev)
+            torch.manual_seed(0)
+            for timed in (False, True):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                _, u8, _, _ = run_chunked(gen, tok, labels, plan, SAMPLER["randomize_temperature"], want_steps=False, want_image=False, want_u8=True)
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[f"{tag}, batch {B}"] = {"images_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B, "image": list(u8.shape[1:3]),
+                                        "precision": "LFQBert.precision = %d" % gen.resolved_precision()}
+            del gen
+        except Exception as e:                              # noqa: BLE001  (context only)
+            out[f"{tag}, batch {B}"] = {"error": repr(e)}
         torch.cuda.empty_cache()
     return out
 
@@ -209,11 +245,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU per step (default: the C3 batch, 64)")
-    ap.add_argument("--mode", choices=("strict", "diff", "fp16", "wcorr", "max"), default="strict",
-                    help="precision mode of the TIMED region: strict (default; the product default: differential guidance + MX-fp4 correction mini-tiles "
-                         "for the weights' fp16 rounding on every trunk GEMM + hi/lo head weights: 5.5e-4 token mismatch over three reference runs), diff "
-                         "(differential guidance alone: faster, AT the 1e-3 bound), single fp16, wcorr (the correction in the second half of the trunk "
-                         "only) or max (fp16x2 weights)")
+    ap.add_argument("--mode", choices=("strict", "diff", "fp16"), default="strict",
+                    help="precision mode of the TIMED region (LFQBert.precision): strict (default; the product default: differential guidance + MX-fp4 "
+                         "correction mini-tiles for the weights' fp16 rounding on every trunk GEMM + hi/lo head weights: 5.5e-4 token mismatch over three "
+                         "reference runs), diff (differential guidance alone: faster, AT the 1e-3 bound) or single fp16 (independent streams: 1.4e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurements: parity replay and the other precision mode")
@@ -256,9 +291,8 @@ def main():
 
     B = args.batch
     gen, tok = build_models(dev)
-    MODES = {"strict": (0, -1, -1), "diff": (0, -1, 1), "fp16": (0, 0, 0), "wcorr": (0, -1, 2), "max": (1, -1, -1)}   # LFQBert (weight_split, act_split, cfg_pair); (0, -1, -1) = the product default
-    gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
-    gen.wcorr_from = gen.depth // 2 if args.mode == "wcorr" else 0
+    MODES = {"strict": -1, "diff": 1, "fp16": 0}          # LFQBert.precision; -1 = the product default (resolves to 2 for this generator)
+    gen.precision = MODES[args.mode]
     torch.manual_seed(1234 + rank)
     plan = build_plan(NUM_STEPS, 512, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
                       SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])
@@ -318,8 +352,7 @@ def main():
         # the two faster modes below the default (differential guidance without the weight-correction pass; single fp16 with independent streams),
         # one untimed-region batch each -- the first with the kernel timers on, so that the line also carries the dominant GEMM without the pass
         for other in [m for m in ("diff", "fp16", "strict") if m != args.mode][:2]:
-            gen.weight_split, gen.act_split, gen.cfg_pair = MODES[other]
-            gen.wcorr_from = 0
+            gen.precision = MODES[other]
             one_batch(10_000); torch.cuda.synchronize()
             if other == "diff" and not args.no_prof:
                 _lib.prof_enable(True, every=PROF_EVERY)
@@ -335,14 +368,12 @@ def main():
                 c_, ms_ = pr["gemm_ffn_up"]
                 modes[other]["ffn_up_avg_launch_us"] = ms_ / c_ * 1e3
                 modes[other]["ffn_up_frac_of_peak"] = 2.0 * (2 * B * 257) * 4096 * 1024 / (ms_ / c_ * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
-        gen.weight_split, gen.act_split, gen.cfg_pair = MODES[args.mode]
-        gen.wcorr_from = gen.depth // 2 if args.mode == "wcorr" else 0
-        if args.mode != "wcorr":
-            try:                                                # the other full-size reference runs (context only: never costs the headline line)
-                for name, par in other_runs_parity(dev, {m: MODES[m] for m in modes}).items():
-                    modes[name]["parity_other_runs"] = par
-            except Exception as e:                              # noqa: BLE001
-                modes["parity_other_runs_error"] = repr(e)
+        gen.precision = MODES[args.mode]
+        try:                                                    # the other full-size reference runs (context only: never costs the headline line)
+            for name, par in other_runs_parity(dev, {m: MODES[m] for m in modes}).items():
+                modes[name]["parity_other_runs"] = par
+        except Exception as e:                                  # noqa: BLE001
+            modes["parity_other_runs_error"] = repr(e)
     others = None
     if world == 1 and not args.no_modes and B == B_PER_GPU:
         try:
@@ -364,22 +395,22 @@ def main():
             achieved = gemm_flops[dom] / (ms / calls * 1e-3) / 1e12
             fam_flops = sum(gemm_flops[k] * prof[k][0] for k in gemm_flops if k in prof)
             fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
-            traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.*), if present
-            traffic_src = None
-            for name in ("r04_pmc_traffic.json", "r03c_pmc_traffic.json", "r03_pmc_traffic.json"):     # the counter passes of the dominant kernel as the timed mode runs it
+            # `traffic` (HBM bytes per launch from the PMC counters) cannot be measured inside a timing run -- counters need their own rocprofv3 --pmc
+            # passes -- so it is null here; the last committed counter pass of the same kernel in the same mode is quoted beside it as a REFERENCE.
+            traffic_ref = None
+            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if B == B_PER_GPU and pmc.get("_mode", "").split(" ")[0] == args.mode:
-                        traffic = pmc[dom.replace("gemm_", "")]["hbm_bytes_corrected"]
-                        traffic_src = name
+                        traffic_ref = {"bytes_per_launch": pmc[dom.replace("gemm_", "")]["hbm_bytes_corrected"], "source": f"profiles/{name}",
+                                       "what": "2*FETCH_SIZE + WRITE_SIZE of a committed rocprofv3 --pmc pass of this kernel: NOT measured in this run"}
                         break
                 except Exception:
                     pass
             roofline = {"bound": "mfma", "kernel": f"gemm_ht_kernel ({dom}: M={M}, N={4096 if dom == 'gemm_ffn_up' else (3072 if dom == 'gemm_qkv' else 1024)}, "
                                                    f"K={4096 if dom == 'gemm_ffn_down' else 1024})",
                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                        "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE+WRITE_SIZE) from a committed rocprofv3 --pmc pass of this kernel, profiles/{traffic_src}: "
-                                        "NOT measured in this run",
+                        "traffic": None, "traffic_reference": traffic_ref,
                         "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
                         "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
                         # executed sequence-forwards per image: two per guided step, one where the annealed scale is exactly 0 (the loop skips the
@@ -421,10 +452,10 @@ def main():
                           "strict": "the product default: fp16 MFMA, fp32 accumulate, classifier-free guidance in differential form (the unconditional "
                                     "stream's GEMM operands carried as fp16(x_u - x_c) next to fp16(x_c): operand rounding cancels in c - u) + MX-fp4 "
                                     "correction mini-tiles for the fp16 rounding of the weights on the conditional half of every trunk GEMM (and on every row of "
-                                    "the plain forward of the zero-scale steps) + hi/lo head weights (LFQBert.cfg_pair = 2)",
-                          "diff": "the differential form without the correction mini-tiles (LFQBert.cfg_pair = 1): ~1.17x the default's speed; its token "
+                                    "the plain forward of the zero-scale steps) + hi/lo head weights (LFQBert.precision = 2)",
+                          "diff": "the differential form without the correction mini-tiles (LFQBert.precision = 1): ~1.17x the default's speed; its token "
                                   "mismatch over the three reference runs is ~1e-3, AT the bound (round 2's default)",
-                          "fp16": "single fp16 operands, independent streams (LFQBert.act_split = 0, cfg_pair = 0)"},
+                          "fp16": "single fp16 operands, independent streams (LFQBert.precision = 0)"},
             "precision_modes": modes,
             "other_configs": others,
             "ranks_seen": ranks_seen if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,

@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define MB_ABI_VERSION 6
+#define MB_ABI_VERSION 7
+enum { MB_PREC_FP16 = 0, MB_PREC_DIFF = 1, MB_PREC_WCORR = 2, MB_PREC_ALO = 3 };
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
 typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
@@ -36,39 +37,23 @@ typedef struct {
   int mlp;     /* mlp_dim (multiple of 64)         */
   int seq;     /* (img_size/input_stride)^2 = 256  */
   int nclass;  /* 1000; row nclass = "dropped"     */
-  /* Weight precision of the trunk/head GEMMs (no counterpart in the reference, which is fp32):
-   * 0 = one fp16 value per weight; 1 = "fp16x2": hi + lo fp16 halves of the power-of-two pre-scaled
-   * weight, both multiplied on the MFMA and summed in the fp32 accumulator (weight rounding error
-   * 2^-22 instead of 2^-11; twice the GEMM work).  See DESIGN.md, "Precision". */
-  int weight_split;
   /* Generator variants of modeling/bert.py: prenorm = use_prenorm (LayerNorm before each sub-layer, raw residual,
    * norm_after_transformer; bert.py:49-59,106-123,498-499); embed_tables = the `Bert` class (bert.py:184-340): per-group
    * nn.Embedding(C+1, hidden) inputs summed, output head tied to those tables plus a per-position bias [seq, C].
    * Checkpoint keys then are tok_emb_list.{g}.weight and bias.{g} instead of input_proj.* / prediction_layer.*. */
   int prenorm;
   int embed_tables;
-  /* Activation precision of the trunk GEMMs in the PLAIN forward (explicit modes; with cfg_pair >= 2 the host's default is 1 and only 0 / 1
-   * compose with the weight-correction mini-tiles -- 2 / 3 then run without them): 0 = one fp16 value per element; 1 = fp16 hi + lo pairs for the LayerNorm outputs (QKV and FFN-up
-   * sweep their weight twice: hi.W + lo.W in the same fp32 accumulator); 2 = additionally for the attention output and the FFN hidden (all four
-   * trunk GEMMs do twice their work); 3 = as 2 with the lo halves stored as e4m3(lo * 2^12) and multiplied with an e4m3 copy of the weights on
-   * v_mfma_scale_f32_16x16x128_f8f6f4 (half a sweep; hidden and mlp multiples of 256).  Not combined with weight_split.  (4, the MX-fp4 lo K-tiles of
-   * rounds 2-3, is retired: cfg_pair 2 / 3.) */
-  int act_split;
-  /* Precision mode of the engine (DESIGN.md "Precision").
-   * 0 = independent streams: the guided forward is the plain forward over [cond | uncond].
-   * 1 = classifier-free guidance in DIFFERENTIAL form (mb_gen_forward_cfg / mb_sample): the unconditional stream's GEMM operands are carried as
-   *     fp16(x_u - x_c) next to fp16(x_c), so the operand rounding of x_c is common to both streams and cancels in (c - u), the term the guidance
-   *     scale multiplies -- at no extra GEMM work (weight_split = 1 composes: the pair GEMMs sweep twice).
-   * 2 = 1 + an MX-fp4 correction of the fp16 rounding of the WEIGHTS of all four trunk GEMMs (the product default): e2m1 of the operand VALUES
-   *     with per-(row, 64 columns) scales against e2m1(W - fp16(W)) with per-row scales, as 24 KiB mini-tiles staged under the fp16 K-tiles and
-   *     multiplied between them (gemm_ht.hip, XP = 6) -- on the conditional rows of the guided forward (the unconditional outputs inherit it through
-   *     the shared accumulator) and on every row of the plain forward (act_split 0 or 1).  Not combined with weight_split.
-   * 3 = 2 + the same kind of pass for the fp16 rounding of the conditional LayerNorm OUTPUTS in the guided forward's QKV / FFN-up GEMMs (e2m1 of
-   *     their lo halves against e2m1 of the weights): what the 7-bit-per-group codebooks need for margin (tests/diag/error_budget.py).
-   * Pair forwards need seq = 256, hidden 768 / 1024, mlp % 256 == 0 (post- or pre-norm); modes 2 / 3 also hidden / heads = 64.  Otherwise the engine
-   * falls back (guided: plain forward over [cond | uncond]; plain: act_split) -- the 1024 + 1-token models of 512 x 512 images run that way: 7.6e-4
-   * token mismatch on a full-width reference run with act_split 3 (tests/test_hip_configs.py). */
-  int cfg_pair;
+  /* Precision mode of the engine -- ONE knob (no counterpart in the reference, which is fp32; DESIGN.md "Precision").  fp16 operands, fp32 accumulation
+   * everywhere; the two head GEMMs always multiply hi + lo inputs by hi + lo weights.
+   *   MB_PREC_FP16  0  single fp16 operands, guided forward = plain forward over [cond | uncond] (1.4e-3 token mismatch on configs[2]: a baseline).
+   *   MB_PREC_DIFF  1  classifier-free guidance in DIFFERENTIAL form: the unconditional stream's GEMM operands are fp16(x_u - x_c), so the rounding of
+   *                    x_c cancels in (c - u); plain forwards carry the LayerNorm outputs as fp16 hi + lo pairs (~1.0e-3: AT the bound).
+   *   MB_PREC_WCORR 2  + MX-fp4 mini-tile correction of the fp16 rounding of all four trunk WEIGHTS (gemm_ht.hip XP = 6), guided and plain (5.5e-4).
+   *   MB_PREC_ALO   3  + the same kind of pass for the rounding of the conditional LayerNorm outputs in QKV / FFN-up of the guided forward (what the
+   *                    7-bit-per-group codebooks need: 5.5e-4 on the 14-bit / 256-step runs).
+   * Modes 1-3 need seq in {256, 1024}, hidden in {768, 1024}, mlp % 256 == 0 (2 / 3 also hidden / heads = 64); other shapes run mode 0 with hi + lo
+   * LayerNorm outputs.  The host's default is 2, or 3 from 7 bits per group on (LFQBert.resolved_precision). */
+  int precision;
 } mb_gen_cfg;
 
 /* ConvDecoder configuration (modeling/modules/autoencoder.py:358-397, configs/tokenizer yaml files). */
@@ -110,19 +95,16 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out);
 void mb_gen_destroy(mb_gen* g);
 /* One call per checkpoint entry (key names of SURVEY.md 8b / BaseModel.load_pretrained,
  * modeling/modules/base_model.py:87-141).  `data` is a device fp32 tensor in the checkpoint's
- * own layout; GEMM weights are repacked to fp16 here (plus the e2m1 / e4m3 operands of the correction passes; the two head weights as fp16
+ * own layout; GEMM weights are repacked to fp16 here (plus the e2m1 operands of the correction passes; the two head weights as fp16
  * hi + lo planes).  Unknown names return -2. */
 int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* shape, int ndim, mb_stream stream);
-/* cfg_pair >= 2 only: the correction passes run in trunk layers >= from_layer (default 0 = every layer; depth = none; guided forward) and on the
- * GEMMs of gemm_mask (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down; default 15; both forwards). */
-int mb_gen_set_wcorr(mb_gen* g, int from_layer, int gemm_mask);
 /* tokens int64 [nb,seq,m] (value C = masked), labels int64 [nb], drop uint8 [nb] (1 => label
  * replaced by nclass, bert.py:482-484; may be NULL) -> logits fp32 [nb,seq,m,C]. */
 int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop,
                    float* logits, int nb, mb_stream stream);
 /* The guided forward of sample() (sampling.py:83-88): tokens int64 [B,seq,m], labels int64 [B] -> logits fp32 [2B,seq,m,C], rows [0,B) the
- * conditional and [B,2B) the label-dropped forward of the same tokens.  With cfg.cfg_pair the two streams run in differential form
- * (see mb_gen_cfg.cfg_pair).  `scale` is reserved (ignored: the precision of the forward does not depend on the guidance scale); pass the
+ * conditional and [B,2B) the label-dropped forward of the same tokens.  With cfg.precision >= 1 the two streams run in differential form
+ * (see mb_gen_cfg.precision).  `scale` is reserved (ignored: the precision of the forward does not depend on the guidance scale); pass the
  * step's scale or any number. */
 int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, mb_stream stream);
 /* The same forward with `return_attn=True` (bert.py:461, 505-508; nn.MultiheadAttention need_weights with head averaging,

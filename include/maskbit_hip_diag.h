@@ -16,22 +16,17 @@ extern "C" {
  * half-tile kernel with 192 / 256-row tiles, 257 its sequence-aligned tiles (M % 257 == 0). */
 int mb_gemm(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32,
             void* out_h16, int M, int N, int K, int period, int variant, mb_stream stream);
-/* Split-weight ("fp16x2") diagnostics: repack W[N,K] fp32 -> dst[N,2K] fp16 (hi | lo) + *scale_out (`tmp`: 4 bytes of device scratch), and the GEMM
- * over such a weight (K = 2 * ka, A is [M, ka]); ln_stats != NULL: the residual is LayerNorm(residual rows) re-derived from {mean, rstd}[M]. */
-int mb_split_weights(const float* W, int N, int K, void* dst_h16, float* scale_out, void* tmp, mb_stream stream);
+/* mb_gemm with the LayerNorm-residual epilogue: ln_stats != NULL: the residual that is added is LayerNorm(residual rows) re-derived from
+ * {mean, rstd}[M] (epi 2 only). */
 int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
-               int M, int N, int K, int ka, const float* scale, const float* ln_stats, const float* ln_g, const float* ln_b, int period, int variant,
-               mb_stream stream);
+               int M, int N, int K, const float* ln_stats, const float* ln_g, const float* ln_b, int period, int variant, mb_stream stream);
 /* LayerNorm over rows (modeling/bert.py:69-70,137-139): any of x_f32 / x_h16 / x_lo (fp16 lo halves) / stats ({mean, rstd} per row) may be NULL. */
 int mb_layernorm(const float* y, const float* gamma, const float* beta, float eps, float* x_f32, void* x_h16, void* x_lo, float* stats,
                  int M, int d, mb_stream stream);
-/* Split-activation GEMMs (mb_gen_cfg.act_split): out = (A_hi + A_lo) . W^T + bias with fp16 lo halves (act_split 1 / 2), or with e4m3 lo halves
- * A8 = e4m3(lo * 2^12) against W8 = e4m3(W * 2^(*w8_exp)) (act_split 3; row strides of the fp16 siblings, kw % 128 == 0). */
+/* Split-activation GEMM (the plain forward's LayerNorm outputs as fp16 hi + lo pairs): out = (A_hi + A_lo) . W^T + bias, both [M, kw]. */
 int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual,
                       float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
-int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const void* W8, const int* w8_exp, const float* bias,
-                 const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream);
-/* "CFG pair" GEMM (mb_gen_cfg.cfg_pair): rows [0, pair_rows) of A / out are conditional, [pair_rows, 2 pair_rows) their unconditional twins whose
+/* "CFG pair" GEMM (mb_gen_cfg.precision >= 1): rows [0, pair_rows) of A / out are conditional, [pair_rows, 2 pair_rows) their unconditional twins whose
  * A rows hold the difference operand; out_c = f(A_c.W), out_u = f(A_c.W + A_delta.W) (GELU epilogue: the u rows receive gelu(u) - gelu(c)).
  * mb_gemm_mini: a sequence-aligned GEMM (rows % 257 == 0; pair != 0: a pair GEMM over `rows` conditional rows) with nlo MX-fp4 mini-tile passes:
  * lo = nlo x {A4, a_scale, W4, w_scale} device pointers (operand layouts: mb_kernels.h GemmArgs.lo; the token scales in lane order,
@@ -49,7 +44,7 @@ int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb
 int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
 /* LayerNorm that also writes the e2m1 copies of its output rows: values (x4 / x4_scale) and / or fp16 lo halves (xl4 / xl4_scale); M % 257 == 0,
  * d = 768 / 1024; class-token rows (row % 257 == 256) are skipped. */
-/* ... the plain forward's default for QKV / FFN-up (act_split 1 with cfg_pair >= 2): plain sequence tiles over hi + lo activation halves
+/* ... the plain forward's default for QKV / FFN-up (precision >= 2): plain sequence tiles over hi + lo activation halves
  * (A_hi, A_lo [rows, kw]; the fp16 sweep runs twice over W [N, kw]) AND one mini-tile operand set over the kw columns; epi 0 / 1. */
 int mb_gemm_mini_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, void* out_h16, void* out4, void* out4_scale,
                        int rows, int N, int kw, const void* const* lo, mb_stream stream);
@@ -57,9 +52,13 @@ int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float
                     void* xl4_scale, int M, int d, mb_stream stream);
 /* Attention of a CFG pair batch (the generator's guided forward, bert.py:84,137 on both streams): qkv [2 pairs N, 3d] fp16 packed in_proj rows, the
  * conditional sequences first, their unconditional twins `pairs` sequences later.  out rows of conditional sequences = softmax(QK^T/sqrt(dh))V in
- * fp16; rows of unconditional sequences = fp16(o_u - o_c), the difference operand of the out-proj pair GEMM.  aux [pairs N, d] fp32: scratch of the
- * two-launch form (MASKBIT_AMD_ATT_PAIR=2); the default form keeps the conditional rows in registers and leaves it untouched. */
-int mb_attention_pair(const void* qkv, void* out_h16, float* aux, int pairs, int N, int d, int heads, mb_stream stream);
+ * fp16; rows of unconditional sequences = fp16(o_u - o_c), the difference operand of the out-proj pair GEMM (the conditional output tiles stay in
+ * registers in between).  N <= 288: one head's K / V in LDS; longer sequences: the streaming kernel. */
+int mb_attention_pair(const void* qkv, void* out_h16, int pairs, int N, int d, int heads, mb_stream stream);
+/* Study knob of the weight-correction passes (precision >= 2): they run in trunk layers >= from_layer (default 0 = every layer; depth = none; guided
+ * forward) and on the GEMMs of gemm_mask (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down; default 15; both forwards).  No subset keeps the default's
+ * parity margin (profiles/r04_gemm_minitiles.md section 4): the product never calls this. */
+int mb_gen_set_wcorr(mb_gen* g, int from_layer, int gemm_mask);
 /* Persistent kernels launch one workgroup per CU.  On a stream created with a CU mask (hipExtStreamCreateWithCUMask) fewer CUs serve the launch:
  * n = the CUs the following launches should size their grids for, 0 = the device's count (default).  Process-wide, not thread-safe. */
 int mb_set_cu_count(int n);

@@ -20,17 +20,14 @@ import torch
 from . import _lib
 from .base_model import BaseModel, ParamSpec
 
-DEFAULT_WEIGHT_SPLIT = 0
-# Activation precision of the PLAIN forward (mb_gen_cfg.act_split): -1 = auto -- 1 (LayerNorm outputs as fp16 hi + lo pairs) next to the engine's
-# weight-correction mode (below) where that covers the plain forward, otherwise the cheapest hi + lo activation mode the shape allows (3 = e4m3 lo
-# halves where hidden and mlp are multiples of 256, else 2).
-DEFAULT_ACT_SPLIT = -1
-# Precision mode of the engine (mb_gen_cfg.cfg_pair): -1 = auto, 0 = independent streams, 1 = classifier-free guidance in differential form alone --
-# the fastest guided forward; its token mismatch against the reference's own 12-bit / 64-step runs is 1.03e-3 over three runs (8.4e-4 / 9.9e-4 /
-# 1.14e-3): AT the 1e-3 bound, not under it --, 2 = + the MX-fp4 weight-correction mini-tiles on every trunk GEMM, in the guided AND the plain forward
-# (the default below 7 bits per group), 3 = + the activation-lo mini-tiles for the LayerNorm outputs in the guided forward (the default from 7 bits
-# per group on: the 14-bit / 256-step configuration sits at the bound without it; tests/diag/error_budget.py, profiles/r04_parity.md).
-DEFAULT_CFG_PAIR = -1
+# Precision mode of the engine (mb_gen_cfg.precision, include/maskbit_hip.h) -- one knob:
+#   PREC_FP16  0  single fp16 operands, the guided forward as independent streams (1.4e-3 token mismatch on configs[2]: a baseline, not a product mode)
+#   PREC_DIFF  1  classifier-free guidance in differential form; plain forwards with the LayerNorm outputs as fp16 hi + lo pairs (~1.0e-3: AT the bound)
+#   PREC_WCORR 2  + MX-fp4 weight-correction mini-tiles on every trunk GEMM, guided and plain (5.5e-4 over three reference runs of configs[2]; 5.3e-4 on configs[1])
+#   PREC_ALO   3  + activation-lo mini-tiles for the LayerNorm outputs of the guided forward (5.5e-4 on the 14-bit / 256-step runs)
+# -1 = auto: 2, or 3 from 7 bits per group on, degraded to what the shape allows (resolved_precision()).
+PREC_AUTO, PREC_FP16, PREC_DIFF, PREC_WCORR, PREC_ALO = -1, 0, 1, 2, 3
+DEFAULT_PRECISION = PREC_AUTO
 DEFAULT_WCORR_MASK = 15
 
 
@@ -42,12 +39,6 @@ def pair_capable(seq_len: int, hidden: int, mlp: int, prenorm: bool) -> bool:
 def mini_capable(seq_len: int, hidden: int, mlp: int, heads: int) -> bool:
     """Shapes the MX-fp4 mini-tile passes serve (mb_gen_create: mini_ok)."""
     return seq_len in (256, 1024) and hidden in (768, 1024) and mlp % 256 == 0 and hidden // heads == 64
-
-
-def resolve_act_split(act_split: int, hidden: int, mlp: int) -> int:
-    if act_split >= 0:
-        return act_split
-    return 3 if (hidden % 256 == 0 and mlp % 256 == 0) else 2
 
 
 def _generator_specs(d: int, f: int, depth: int, seq: int, bits: int, nclass: int, out: int, prenorm: bool = False,
@@ -100,16 +91,10 @@ class LFQBert(BaseModel):
         self.dropout = dropout            # inference only: dropout is the identity in eval mode
         self.use_prenorm = bool(use_prenorm)
         self.embed_tables = bool(getattr(self, "_EMBED_TABLES", False))
-        # GEMM weight precision of the device engine (not a reference argument): 0 = fp16, 1 = fp16 hi+lo pairs ("fp16x2",
-        # twice the GEMM work, weight rounding 2^-22).  Default from MASKBIT_AMD_WEIGHT_SPLIT; may be changed before a call.
-        self.weight_split = int(os.environ.get("MASKBIT_AMD_WEIGHT_SPLIT", str(DEFAULT_WEIGHT_SPLIT)))
-        # Activation precision of the plain forward's trunk GEMMs where the engine's weight-correction mode does not serve it: 0 = single fp16;
-        # 1 = fp16 hi+lo pairs for the LayerNorm outputs; 2 = also for the attention output and the FFN hidden (all four trunk GEMMs do twice the
-        # work); 3 = as 2 with the lo halves and a weight copy in 8 bits (half a sweep).  -1 (DEFAULT): see DEFAULT_ACT_SPLIT.
-        # Default from MASKBIT_AMD_ACT_SPLIT; may be changed before a call (the engine is rebuilt).
-        self.act_split = int(os.environ.get("MASKBIT_AMD_ACT_SPLIT", str(DEFAULT_ACT_SPLIT)))
-        self.cfg_pair = int(os.environ.get("MASKBIT_AMD_CFG_PAIR", str(DEFAULT_CFG_PAIR)))
-        # cfg_pair 2 only: first trunk layer that carries the weight-correction pass (0 = all, the default; depth // 2 = the second half of the trunk:
+        # Precision mode of the device engine (not a reference argument; see PREC_* above).  Default from MASKBIT_AMD_PRECISION; may be changed before a
+        # call (the engine is rebuilt and the checkpoint repacked).
+        self.precision = int(os.environ.get("MASKBIT_AMD_PRECISION", str(DEFAULT_PRECISION)))
+        # study knobs (mb_gen_set_wcorr, include/maskbit_hip_diag.h): first trunk layer that carries the weight-correction pass (0 = all, the default; depth // 2 = the second half of the trunk:
         # half the cost, 7.6e-4 instead of 4.8e-4 over the three 12-bit / 64-step runs, no use on the 14-bit ones -- profiles/r03_parity.md)
         self.wcorr_from = int(os.environ.get("MASKBIT_AMD_WFROM", "0"))
         # ... and which GEMMs of a layer carry them: 1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down (15 = all, the default)
@@ -126,36 +111,30 @@ class LFQBert(BaseModel):
 
     # ---- engine hooks ---------------------------------------------------------------------
     def _engine_create(self, capacity: int):
-        act, pair = self.resolved_precision()
         cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass,
-                          int(self.weight_split), int(self.use_prenorm), int(self.embed_tables), act, pair)
-        self._engine_split = (int(self.weight_split), int(self.act_split), int(self.cfg_pair))
+                          int(self.use_prenorm), int(self.embed_tables), self.resolved_precision())
+        self._engine_split = int(self.precision)
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
         self._engine_wfrom = None
         return h
 
-    def resolved_precision(self):
-        """(act_split, cfg_pair) handed to the engine.  The defaults (-1, -1) mean "meet the <= 1e-3 token mismatch": the fp16 rounding of the trunk
-        WEIGHTS is ~80 % of the sampled-logit error variance in every configuration (tests/diag/error_budget.py), so wherever the shape allows it
-        every trunk GEMM carries the MX-fp4 weight-correction mini-tiles -- guided forwards in differential form (cfg_pair 2; 3 from 7 bits per
-        group on: + the activation-lo pass of the LayerNorm outputs), plain forwards with the LayerNorm outputs as fp16 hi + lo pairs as well
-        (act_split 1: QKV and FFN-up sweep their weight twice; what took configs[1] from 71 / 44 / 67 to 45 / 37 / 56 mismatches of 87 040 on its
-        three reference runs, every run <= 7e-4, at 0.82-0.89 of the plain forward's speed; act_split = 0 with cfg_pair >= 2 is the faster opt-out).
-        Measured (profiles/r04_parity.md): 12-bit / 64 steps 5.5e-4 over three reference runs; other shapes fall back to the differential form
-        alone / hi + lo activation pairs."""
+    def resolved_precision(self) -> int:
+        """The precision mode handed to the engine.  The default (-1) means "meet the <= 1e-3 token mismatch with margin": the fp16 rounding of the trunk
+        WEIGHTS is ~80 % of the sampled-logit error variance in every configuration (tests/diag/error_budget.py), so wherever the shape allows it every
+        trunk GEMM carries the MX-fp4 weight-correction mini-tiles (PREC_WCORR; PREC_ALO from 7 bits per group on) -- guided forwards in differential form,
+        plain forwards with the LayerNorm outputs as fp16 hi + lo pairs as well.  Measured (profiles/r04_parity.md, r05): 12-bit / 64 steps 5.5e-4 over
+        three reference runs, 10-bit / 16 steps / no guidance 5.3e-4, 14-bit / 256 steps 5.5e-4, the 1024 + 1-token models 5.6e-4.  Shapes the mini-tile
+        kernels do not serve fall back to the differential form alone, shapes the pair tiles do not serve to independent streams (with hi + lo LayerNorm
+        outputs: the engine keeps those for every requested precision >= 1)."""
         capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm)
-        mini = mini_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.heads) and not self.weight_split
-        pair, act = int(self.cfg_pair), int(self.act_split)
-        if pair < 0:
-            pair = 3 if self.bits // self.splits >= 7 else 2
-        if pair >= 2 and not mini:
-            pair = 1                                               # no mini-tile passes for this shape (or fp16x2 weights, which do not need them)
-        if pair == 1 and not capable:
-            pair = 0
-        if act < 0:                                                # the plain forward: covered by the weight correction, else hi + lo activation pairs
-            act = 0 if self.weight_split else 1 if pair >= 2 else resolve_act_split(act, self.hidden_dim, self.mlp_dim)
-        return act, pair
+        mini = mini_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.heads)
+        prec = int(self.precision)
+        if prec < 0:
+            prec = PREC_ALO if self.bits // self.splits >= 7 else PREC_WCORR
+        if prec >= PREC_WCORR and not (capable and mini):
+            prec = PREC_DIFF
+        return prec
 
     def _engine_destroy(self, h) -> None:
         _lib.load().mb_gen_destroy(h)
@@ -166,7 +145,7 @@ class LFQBert(BaseModel):
 
     def engine(self, min_seqs: int):
         """Device engine able to hold ``min_seqs`` sequences (CFG needs 2 x batch)."""
-        if self._engine is not None and self._engine_split != (int(self.weight_split), int(self.act_split), int(self.cfg_pair)):
+        if self._engine is not None and self._engine_split != int(self.precision):
             self._drop_engine()                                    # precision mode changed: rebuild and repack
         have = self._engine_key[1] if self._engine_key else 0
         h = self._ensure_engine(max(min_seqs, have, 16))
@@ -232,7 +211,7 @@ class LFQBert(BaseModel):
     @torch.no_grad()
     def forward_cfg(self, img_tokens: torch.Tensor, class_labels: torch.Tensor, scale: float = -1.0) -> torch.Tensor:
         """The guided forward of sample() (sampling.py:83-88) in one call: logits [2b, seq, m, C], rows [0, b) = model(tokens, labels, ~drop),
-        rows [b, 2b) = the label-dropped forward of the same tokens.  On the engine the two streams run in differential form (cfg_pair);
+        rows [b, 2b) = the label-dropped forward of the same tokens.  On the engine the two streams run in differential form (precision >= 1);
         ``scale`` is the guidance scale the caller will combine them with (precision plan hint; negative = unknown)."""
         dev = self._require_cuda("forward_cfg")
         if img_tokens.dim() != 3 or img_tokens.shape[1] != self.seq_len or img_tokens.shape[2] != self.splits:

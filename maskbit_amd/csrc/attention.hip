@@ -42,21 +42,21 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // score MFMAs, the softmax, the PV MFMAs, the stores.
 #ifdef MB_ATT_TRACE
 __device__ long long* g_att_trace = nullptr;
-#define MB_ATRACE(k) do { if (g_att_trace && tid == 0 && (k) < 32) g_att_trace[((size_t)blockIdx.x + ((AUX == 2 || (AUX == 4 && pass == 1)) ? gridDim.x : 0)) * 32 + (k)] = wall_clock64(); } while (0)
+#define MB_ATRACE(k) do { if (g_att_trace && tid == 0 && (k) < 32) g_att_trace[((size_t)blockIdx.x + ((AUX == 4 && pass == 1) ? gridDim.x : 0)) * 32 + (k)] = wall_clock64(); } while (0)
 #else
 #define MB_ATRACE(k) do { } while (0)
 #endif
 
-// AUX (CFG pair attention, mb_kernels.h attention_pair): 1 = also store the fp32 output rows to aux (conditional sequences), 2 = subtract the
-// conditional twin's fp32 rows (aux) and store the DIFFERENCE as the fp16 output (unconditional sequences, sq_off = P).
-// AUX = 4 (the default pair form): one workgroup handles the conditional sequence of a (pair, head) and then its unconditional twin, the conditional
-// output tiles parked in registers in between: no aux traffic, one launch, two workgroups per CU as before.  (Tried and dropped: both streams side by
-// side in one 8-wave workgroup with an LDS mailbox -- 160 KiB of LDS, one workgroup per CU, no faster than the two launches.)
+// AUX = 4 (CFG pair attention, mb_kernels.h attention_pair): one workgroup handles the conditional sequence of a (pair, head) and then its
+// unconditional twin, the conditional output tiles parked in registers in between, and stores fp16(o_u - o_c) for the twin: no extra traffic, one
+// launch, two workgroups per CU as before.  (Rounds 2-3 also had a two-launch form through fp32 rows in memory -- 119 against 88 us -- removed in
+// round 5; tried and dropped earlier: both streams side by side in one 8-wave workgroup with an LDS mailbox, no faster.)  AUX = 5: the plain forward
+// with the e2m1 copy of its outputs.
 template <int DH, int AUX = 0>
-__global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
-                                                          int N, int d, int heads, float scale_log2e, float* __restrict__ aux = nullptr, int sq_off = 0,
+__global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out,
+                                                          int N, int d, int heads, float scale_log2e, int sq_off = 0,
                                                           uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0) {
-  // out4 / out4s (AUX 1 / 4: conditional sequences; AUX 5: the plain forward, every sequence; optional): e2m1 of the output VALUES (row stride 2d
+  // out4 / out4s (AUX 4: conditional sequences; AUX 5: the plain forward, every sequence; optional): e2m1 of the output VALUES (row stride 2d
   // bytes) with one E8M0 scale byte per (row, head) in the lane-ordered layout of the GEMM's mini-tile passes (GemmArgs.lo; out4_nseq sequences),
   // DH = 64, N = 257 -- the token operand of the out-proj GEMM's weight-correction pass
   constexpr int ROW = DH * 2;            // bytes per K / V row
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
   const int sq0 = blockIdx.x / heads, h = blockIdx.x - sq0 * heads;
   const size_t rs = (size_t)3 * d;                                   // qkv row stride (elements)
   // AUX = 4: the workgroup handles the conditional sequence and then its unconditional twin (two passes over the same code); the conditional
-  // output tiles stay in registers (oc) for the subtraction -- no aux traffic, one launch, and still two 72 KiB workgroups per CU
+  // output tiles stay in registers (oc) for the subtraction -- one launch, and still two 72 KiB workgroups per CU
   constexpr int NPASS = AUX == 4 ? 2 : 1;
   // (the tiles of a wave's first ATT_MAXQT - 1 rounds; the <= 2 waves that own a tile in the last round -- N = 257: the class-token tile -- park it in
   // a 4 KiB LDS slab each instead: with it in registers the kernel spilled 4 VGPRs, and a kernel with scratch costs more per launch than it saved)
@@ -209,13 +209,6 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
     sum = rows_sum(sum);
     float inv = 1.0f / sum;
     asm volatile("" : "+v"(inv));          // every cross-lane op of the softmax has retired before the asm LDS reads start
-    f32x4 twin[DH / 16] = {};              // AUX 2: the conditional twin's output rows, requested now, used after the PV loop
-    if constexpr (AUX == 2) {
-      const int qq = min(qt * 16 + l15, N - 1);
-#pragma unroll
-      for (int nt = 0; nt < DH / 16; ++nt) twin[nt] = *(const f32x4*)(aux + ((size_t)sq0 * N + qq) * d + h * DH + nt * 16 + g * 4);
-    }
-
     MB_ATRACE(4 + 4 * i);
     // ---- O^T = V^T P^T ; V^T fragments by transpose reads, one k-block ahead
     f32x4 o[NT];
@@ -278,7 +271,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
     MB_ATRACE(5 + 4 * i);
     // ---- o[nt][r] = O[q = l15][dh = nt*16 + g*4 + r]
     const int q = qt * 16 + l15;
-    if constexpr ((AUX == 1 || AUX == 4 || AUX == 5) && DH == 64) {
+    if constexpr ((AUX == 4 || AUX == 5) && DH == 64) {
       if (out4 && (AUX != 4 || pass == 0)) {                          // block (row, head) = this lane's 16 values x its 4 lane groups
         float am = 0.f;
 #pragma unroll
@@ -301,18 +294,12 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         f32x4 v = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
-        if constexpr (AUX == 1) *(f32x4*)(aux + ((size_t)sq0 * N + q) * d + h * DH + nt * 16 + g * 4) = v;
-        if constexpr (AUX == 2) v = v - twin[nt];
         if constexpr (AUX == 4) {
           if (i < ATT_MAXQT - 1) { f32x4& r = oc[i < ATT_MAXQT - 1 ? i : 0][nt]; if (pass == 0) r = v; else v = v - r; }
           else { f32x4* slot = (f32x4*)oc_last + ((qt - ATT_NW * (ATT_MAXQT - 1)) * NT + nt) * 64 + lane; if (pass == 0) *slot = v; else v = v - *slot; }
         }
         const h16x4 hi = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
         *(h16x4*)(out + ooff + nt * 16 + g * 4) = hi;
-        if (out_lo)                                             // split activations: the fp16 lo halves v - fp16(v)
-          *(h16x4*)(out_lo + ooff + nt * 16 + g * 4) =
-              h16x4{to_h(v[0] - (float)hi[0]), to_h(v[1] - (float)hi[1]), to_h(v[2] - (float)hi[2]), to_h(v[3] - (float)hi[3])};
-        if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4h(v[0], v[1], v[2], v[3], hi);
       }
     }
     MB_ATRACE(6 + 4 * i);
@@ -331,7 +318,7 @@ constexpr int ATTL_KB = 128;             // keys per block
 // fp16(o_u - o_c) there -- the pair form of attention_kernel<DH, 4>.  out4 / out4s (optional, DH = 64): e2m1 of the conditional outputs + one scale
 // byte per (row, head), lane-ordered with (N - 1) / 64 token groups per sequence, for the out-proj pair GEMM's weight-correction mini-tiles.
 template <int DH, bool PAIRM = false>
-__global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, h16* __restrict__ out_lo, uint8_t* __restrict__ out_lo8,
+__global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __restrict__ qkv, h16* __restrict__ out,
                                                                int N, int d, int heads, int nchunk, float scale_log2e, int sq_off = 0,
                                                                uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0) {
   constexpr int ROW = DH * 2, SL = DH / 8, KS = DH / 32, NT = DH / 16, RPI = 64 / SL;
@@ -488,10 +475,6 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
       if (q >= N) continue;
       const h16x4 hi = {to_h(v[0]), to_h(v[1]), to_h(v[2]), to_h(v[3])};
       *(h16x4*)(out + ooff + nt * 16 + g * 4) = hi;
-      if (out_lo)
-        *(h16x4*)(out_lo + ooff + nt * 16 + g * 4) =
-            h16x4{to_h(v[0] - (float)hi[0]), to_h(v[1] - (float)hi[1]), to_h(v[2] - (float)hi[2]), to_h(v[3] - (float)hi[3])};
-      if (out_lo8) *(uint32_t*)(out_lo8 + ((size_t)sq * N + q) * 2 * d + h * DH + nt * 16 + g * 4) = lo8_pack4h(v[0], v[1], v[2], v[3], hi);
     }
   }
   }                                      // pass
@@ -560,52 +543,24 @@ int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, in
   return 0;
 }
 
-void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo, uint8_t* out_lo8, uint8_t* out4, uint8_t* out4s) {
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, uint8_t* out4, uint8_t* out4s) {
   const int dh = d / heads;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   if (N > ATT_NP) {                                           // longer than one head's K/V fits in LDS: streaming kernel
     const int nchunk = (N + 63) / 64;
     dim3 grid(nb * heads * nchunk), block(256);
-    if (dh == 64) hipLaunchKernelGGL(attention_long_kernel<64>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, nchunk, scale_log2e);
-    else hipLaunchKernelGGL(attention_long_kernel<32>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, nchunk, scale_log2e);
+    if (dh == 64) hipLaunchKernelGGL(attention_long_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e);
+    else hipLaunchKernelGGL(attention_long_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e);
     return;
   }
   dim3 grid(nb * heads), block(64 * ATT_NW);
   if (out4 && dh == 64 && N == 257)        // plain forward with the weight-correction mini-tiles: also the e2m1 copy of the outputs
-    hipLaunchKernelGGL((attention_kernel<64, 5>), grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e, (float*)nullptr, 0, out4, out4s, nb);
-  else if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
-  else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, out_lo, out_lo8, N, d, heads, scale_log2e);
+    hipLaunchKernelGGL((attention_kernel<64, 5>), grid, block, 0, s, qkv, out, N, d, heads, scale_log2e, 0, out4, out4s, nb);
+  else if (dh == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, scale_log2e);
+  else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, scale_log2e);
 }
 
-// ---- diagnostic (BASELINE configs[4] "fp8 MFMA attention", measured and rejected -- profiles/r02_fp8_attention.md): round the Q, K, V rows the
-// attention kernel is about to read to OCP e4m3 with one power-of-two scale per (token, head, operand), in place.  The values an fp8 MFMA would
-// multiply are exactly these (products of e4m3 values are exact in the fp32 accumulator on either MFMA), so running the fp16 attention kernel on
-// them measures the token parity an e4m3 Q/K/V attention would have, with the most favourable (dynamic, per-row) scaling.
-__global__ __launch_bounds__(256) void qkv_e4m3_round_kernel(h16* __restrict__ qkv, int rows, int width) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  h16* r = qkv + (size_t)row * width;
-  for (int c0 = 0; c0 < width; c0 += 256) {                     // 256 columns = 4 head slices of 64; a head slice = 16 lanes x 4 columns
-    const h16x4 v = *(const h16x4*)(r + c0 + lane * 4);
-    float f[4] = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    float am = fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3])));
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
-    int ex = 0;
-    if (am > 0.f) (void)frexpf(am, &ex);                       // am = m * 2^ex, m in [0.5, 1) -> am * 2^(8 - ex) in [128, 256) (e4m3 max 448)
-    const float up = ldexpf(1.0f, 8 - ex), dn = ldexpf(1.0f, ex - 8);
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * up, f[1] * up, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * up, f[3] * up, w, true);
-    *(h16x4*)(r + c0 + lane * 4) = h16x4{(h16)(__builtin_amdgcn_cvt_f32_fp8(w, 0) * dn), (h16)(__builtin_amdgcn_cvt_f32_fp8(w, 1) * dn),
-                                          (h16)(__builtin_amdgcn_cvt_f32_fp8(w, 2) * dn), (h16)(__builtin_amdgcn_cvt_f32_fp8(w, 3) * dn)};
-  }
-}
-void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width) {
-  hipLaunchKernelGGL(qkv_e4m3_round_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, qkv, rows, width);
-}
-
-int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads, uint8_t* out4, uint8_t* out4s) {
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d, int heads, uint8_t* out4, uint8_t* out4s) {
   const int dh = d / heads;
   if (dh != 64 && dh != 32) return -1;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
@@ -613,27 +568,15 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, i
     if (out4 && (dh != 64 || (N - 1) % 64)) return -1;
     const int nchunk = ((N + 15) / 16 + 3) / 4;
     dim3 grid(P * heads * nchunk), block(256);
-    if (dh == 64) hipLaunchKernelGGL((attention_long_kernel<64, true>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, nchunk, scale_log2e, P, out4, out4s, P);
-    else hipLaunchKernelGGL((attention_long_kernel<32, true>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, nchunk, scale_log2e, P);
+    if (dh == 64) hipLaunchKernelGGL((attention_long_kernel<64, true>), grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e, P, out4, out4s, P);
+    else hipLaunchKernelGGL((attention_long_kernel<32, true>), grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e, P);
     return 0;
   }
   dim3 grid(P * heads), block(64 * ATT_NW);
-  // A/B switch, read once per process: 4 (default) = one launch / 2 = two launches through the fp32 aux rows
-  static const int pair_mode = getenv("MASKBIT_AMD_ATT_PAIR") ? atoi(getenv("MASKBIT_AMD_ATT_PAIR")) : 4;
-  if (out4 && (dh != 64 || N != 257)) return -1;         // the fp4 output exists for head dimension 64 and 257-token sequences
-  if (pair_mode == 4) {                    // one workgroup per (pair, head): conditional pass, then the twin; conditional outputs parked in registers
-    // 88 us against 119 us for the two launches (B = 64 pairs): a third of the traffic was the fp32 aux round trip
-    if (dh == 64) hipLaunchKernelGGL((attention_kernel<64, 4>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P, out4, out4s, P);
-    else hipLaunchKernelGGL((attention_kernel<32, 4>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, (float*)nullptr, P);
-    return 0;
-  }
-  if (dh == 64) {
-    hipLaunchKernelGGL((attention_kernel<64, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0, out4, out4s, P);
-    hipLaunchKernelGGL((attention_kernel<64, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
-  } else {
-    hipLaunchKernelGGL((attention_kernel<32, 1>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, 0);
-    hipLaunchKernelGGL((attention_kernel<32, 2>), grid, block, 0, s, qkv, out, (h16*)nullptr, (uint8_t*)nullptr, N, d, heads, scale_log2e, aux, P);
-  }
+  if ((out4 || out4s) && (dh != 64 || N != 257)) return -1;   // the fp4 output exists for head dimension 64 and 257-token sequences
+  // one workgroup per (pair, head): conditional pass, then the twin; conditional outputs parked in registers
+  if (dh == 64) hipLaunchKernelGGL((attention_kernel<64, 4>), grid, block, 0, s, qkv, out, N, d, heads, scale_log2e, P, out4, out4s, P);
+  else hipLaunchKernelGGL((attention_kernel<32, 4>), grid, block, 0, s, qkv, out, N, d, heads, scale_log2e, P);
   return 0;
 }
 
@@ -644,6 +587,6 @@ extern "C" int mb_debug_att_trace(long long* p) { return (int)hipMemcpyToSymbol(
 #endif
 #if defined(MB_ATT_TRACE) || defined(MB_ATT_VARIANT)      // experimental builds of this file alone (tools/att_trace.py)
 extern "C" int mb_debug_attention_pair(const void* qkv, void* out, float* aux, int P, int N, int d, int heads, void* stream) {
-  return mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out, aux, P, N, d, heads, nullptr, nullptr);
+  return mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out, P, N, d, heads, nullptr, nullptr);
 }
 #endif

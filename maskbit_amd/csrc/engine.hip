@@ -109,28 +109,18 @@ struct mb_gen {
   float *bl = nullptr, *lnhg = nullptr, *lnhb = nullptr, *bp = nullptr;
   float *lnag = nullptr, *lnab = nullptr;              // norm_after_transformer (pre-norm variant)
   float *tables = nullptr, *bias_pos = nullptr;       // Bert: embedding tables [m][C+1][d]; output bias [seq][m*C]
-  // split weights (cfg.weight_split): one output scale per GEMM weight [4*layer + {qkv, o, 1, 2}], then wl, wp
-  int split = 0;
-  float* wscale = nullptr;
-  unsigned* split_tmp = nullptr;
-  const float* sc(int idx) const { return split ? wscale + idx : nullptr; }
+  unsigned* split_tmp = nullptr;                        // scratch of the head weights' hi / lo split
   // workspace
   float *y_f32 = nullptr, *ln_stats = nullptr;       // fp32 residual stream (pre-LayerNorm rows) and {mean, rstd} per row
-  h16 *x_h16 = nullptr, *x_lo = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;   // x_lo: lo halves of x_h16 (cfg.act_split)
-  h16 *att_lo = nullptr, *h_lo = nullptr;                                                // cfg.act_split == 2: lo halves of att and h
-  // cfg.act_split == 3: the lo halves as e4m3 (row stride 2 * width bytes) + e4m3 copies of the four trunk weights per layer
-  uint8_t *x8 = nullptr, *att8 = nullptr, *h8 = nullptr;
-  std::vector<uint8_t*> w8;                                                              // [4 * layer + {qkv, o, 1, 2}]
-  // cfg.cfg_pair: differential CFG forward.  pair_ok = the shape allows it; aux = the conditional attention output in fp32 (attention_pair).
-  // cfg_pair >= 2 ("W mode", mini_ok = the shape allows it): every trunk GEMM carries the MX-fp4 weight-correction mini-tiles (gemm_ht.hip,
-  // XP = 6) -- in the guided forward on the conditional rows, in the plain forward on every row: x4 / att4 / h4 hold e2m1 of the LayerNorm outputs,
-  // attention outputs and FFN hiddens (values; x4s / att4s / h4s their lane-ordered block scales), w4lo / w4los e2m1 of the weights' fp16 rounding
-  // errors.  cfg_pair == 3 additionally corrects the fp16 rounding of the LayerNorm OUTPUTS in the guided forward's QKV / FFN-up GEMMs: xl4 / xl4s =
-  // e2m1 of their lo halves, w4 / w4s = e2m1 of the (fp16) weights qkv / net.0.
+  h16 *x_h16 = nullptr, *x_lo = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr;   // x_lo: lo halves of x_h16 (head GEMMs; precision >= 1: QKV / FFN-up of plain forwards)
+  // precision >= 1: differential CFG forward (pair_ok = the shape allows it).  precision >= 2 (mini_ok = the shape allows it): every trunk GEMM carries the
+  // MX-fp4 weight-correction mini-tiles (gemm_ht.hip, XP = 6) -- in the guided forward on the conditional rows, in the plain forward (257-token sequences)
+  // on every row: x4 / att4 / h4 hold e2m1 of the LayerNorm outputs, attention outputs and FFN hiddens (values; x4s / att4s / h4s their lane-ordered
+  // block scales), w4lo / w4los e2m1 of the weights' fp16 rounding errors.  precision 3 additionally corrects the fp16 rounding of the LayerNorm OUTPUTS
+  // in the guided forward's QKV / FFN-up GEMMs: xl4 / xl4s = e2m1 of their lo halves, w4 / w4s = e2m1 of the (fp16) weights qkv / net.0.
   bool pair_ok = false, mini_ok = false;
   uint8_t *x4 = nullptr, *x4s = nullptr, *xl4 = nullptr, *xl4s = nullptr;
   std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {qkv, -, 1, -}]
-  float* att_aux = nullptr;
   float* logits_tmp = nullptr;                          // guided forwards over more pairs than one pass holds
   // The two head GEMMs run hi + lo inputs against hi + lo WEIGHTS in every mode (GemmArgs.W2: three sweeps): their rounding reaches the logits
   // un-averaged -- fp16 head weights alone were a quarter of the sampled-logit error variance left after the trunk's weight correction
@@ -141,11 +131,10 @@ struct mb_gen {
   unsigned* sat = nullptr;                              // lanes of the QKV / FFN-up epilogues that clamped a fp16 store (mb_gen_saturation_count)
   std::vector<uint8_t*> w4lo, w4los;                                                     // [4 * layer + {qkv, o, 1, 2}]
   uint8_t *att4 = nullptr, *att4s = nullptr, *h4 = nullptr, *h4s = nullptr;              // e2m1 of the conditional attention outputs / FFN hiddens + block scales
-  int* w8_exp = nullptr;                                                                 // their power-of-two scales, same indexing
   // loop state for mb_sample
   // the run mb_sample is in the middle of (step chunks): samples, total steps, guidance flag, the step the next chunk must begin with (-1: no run)
   int loop_B = 0, loop_steps = 0, loop_guided = 0, loop_next = -1;
-  int wcorr_from = 0;                                   // cfg_pair >= 2: first trunk layer that carries the correction passes (mb_gen_set_wcorr)
+  int wcorr_from = 0;                                   // precision >= 2: first trunk layer that carries the correction passes (mb_gen_set_wcorr)
   int wcorr_mask = 15;                                  // ... and which GEMMs of a layer: 1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down
   const int64_t* cfg_labels_ready = nullptr;            // gen_forward_cfg: lab_cfg / drop_cfg already hold [labels | labels] / [0 | 1] for this many pairs
   int cfg_ready_B = 0;
@@ -165,12 +154,6 @@ int galloc(mb_gen* g, T** p, size_t n) {
   return rc;
 }
 
-// MASKBIT_AMD_ATTN_F8=1 (diagnostic, profiles/r02_fp8_attention.md): Q/K/V rounded to e4m3 before the attention kernel reads them
-bool attn_f8_diag() {
-  static const bool on = getenv("MASKBIT_AMD_ATTN_F8") && atoi(getenv("MASKBIT_AMD_ATTN_F8")) != 0;
-  return on;
-}
-
 // The head (bert.py:411-417, 500-503): last_layer.0 + GELU, LayerNorm, prediction layer, on the hi + lo rows the trunk's last LayerNorm left in
 // x_h16 / x_lo -- hi + lo inputs against hi + lo weights in every mode (mb_gen::wl_lo)
 int head_gemms(mb_gen* g, float* logits, int M, hipStream_t s) {
@@ -179,13 +162,13 @@ int head_gemms(mb_gen* g, float* logits, int M, hipStream_t s) {
   const int d = c.hidden;
   int rc = 0;
   { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 3 * d, 0, 0, g->head_scale};
+    GemmArgs ga{g->x_h16, g->wl, g->bl, nullptr, g->y_f32, nullptr, M, d, 3 * d, 0, g->head_scale};
     ga.A2 = g->x_lo; ga.kw = d; ga.W2 = g->wl_lo;
     rc |= gemm_tn(s, EPI_GELU_F32, ga); }
   { ProfScope p("layernorm", s, true);
     layernorm_rows(s, g->y_f32, g->lnhg, g->lnhb, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }
   { ProfScope p("gemm_head", s, true);
-    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, (g->wp_lo ? 3 : 2) * d, g->N, 0,
+    GemmArgs ga{g->x_h16, g->wp, c.embed_tables ? g->bias_pos : g->bp, nullptr, logits, nullptr, M, c.splits * g->C, (g->wp_lo ? 3 : 2) * d, g->N,
                 g->wp_lo ? g->head_scale + 1 : nullptr};
     ga.A2 = g->x_lo; ga.kw = d; ga.W2 = g->wp_lo;
     ga.bias_per_pos = c.embed_tables;
@@ -203,121 +186,79 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     return attn ? attention_probs(s, g->qkv, attn + (size_t)l * nb * N * N, nb, N, d, c.heads) : 0;
   };
   int attn_rc = 0, gemm_rc = 0;
-  h16* const xlo_trunk = (c.act_split == 1 || c.act_split == 2) ? g->x_lo : nullptr;   // LayerNorms that feed trunk GEMMs write lo halves only when those GEMMs use them
-  const bool f8 = c.act_split >= 3;                       // e4m3 lo halves + e4m3 weight copies: the lo pass costs half a sweep
-  uint8_t* const x8p = g->x8;
-  // cfg_pair >= 2 outside a guided forward (plain forward(), sampling without guidance, the zero-scale steps of a guided run): the fp16 rounding of
-  // the WEIGHTS is 80 % of the sampled-logit error variance there (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
-  // activation pairs, 0.0045 with the weight correction alone), so all four trunk GEMMs carry the MX-fp4 weight-correction mini-tiles on every row
-  // act_split 1 composes, and is what LFQBert.resolved_precision() picks by default next to cfg_pair >= 2: the LayerNorm outputs then ALSO enter
-  // QKV / FFN-up as fp16 hi + lo pairs (the fp16 sweep of those two GEMMs doubles) -- the emulator's 63 -> 41 mismatches on configs[1], measured
-  // 5.3e-4 against 7.0e-4 over its three reference runs at 0.82-0.89 of the speed; act_split 0 is the faster opt-out.  act_split 2 / 3: hi + lo pairs alone.
-  const bool wm = g->mini_ok && c.seq == 256 && c.cfg_pair >= 2 && c.act_split <= 1 && !c.weight_split;   // (plain sequence tiles are 256 + 1 rows: the 1024 + 1-token models run their plain forward with act_split alone)
+  // The plain forward (mb_gen_forward, sampling without guidance, the zero-scale steps of a guided run), by precision:
+  //   >= 1: the LayerNorm outputs enter QKV / FFN-up as fp16 hi + lo pairs (x_h16 + x_lo: those two GEMMs sweep their weight twice, K = 2d);
+  //   >= 2 (257-token sequences): all four trunk GEMMs also carry the MX-fp4 weight-correction mini-tiles on every row -- the fp16 rounding of the
+  //         WEIGHTS is 80 % of the sampled-logit error variance here (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
+  //         activation pairs, 0.0045 with the weight correction alone); both together: 5.3e-4 over configs[1]'s three reference runs.
+  const bool xlo = c.precision >= 1;
+  h16* const xlo_trunk = xlo ? g->x_lo : nullptr;        // LayerNorms that feed trunk GEMMs write lo halves only when those GEMMs use them
+  const bool wm = g->mini_ok && c.seq == 256 && c.precision >= 2;   // (plain sequence tiles are 256 + 1 rows)
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
   Fp4Rows f4x;
   if (wm && (g->wcorr_mask & 5)) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; }
   const bool wo4 = wm && (g->wcorr_mask & 2);
   auto lo_set = [&](GemmArgs& ga, const uint8_t* a4, const uint8_t* a4s, int widx) {
-    if (!((g->wcorr_mask >> (widx & 3)) & 1)) return;
+    if (!wm || !((g->wcorr_mask >> (widx & 3)) & 1)) return;
     ga.nlo = 1; ga.lo[0] = {a4, a4s, g->w4lo[widx], g->w4los[widx]};
   };
-  const int ks = g->split ? 2 : 1;                     // split weights: W rows are [hi | lo], K doubles, A is swept twice
-  // act_split: the LayerNorm outputs exist as fp16 hi (x_h16) + lo (x_lo) halves; the GEMMs that consume them run over
-  // K = 2d K-tiles, the first d columns pairing x_h16 with W, the second d columns x_lo with the same W
-  auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, const float* sc, h16* out_lo = nullptr,
-                   const uint8_t* w8 = nullptr, const int* w8e = nullptr, uint8_t* out_lo8 = nullptr, int widx = -1) {
-    GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d * ks, 0, d, sc};
-    if (wm) {
-      ga.ka = 0; lo_set(ga, g->x4, g->x4s, widx);
-      if (epi == EPI_GELU_H16 && (g->wcorr_mask & 8)) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
-      if (c.act_split == 1) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }
-    }
-    else if (f8) { ga.K = d + d / 2; ga.ka = 0; ga.kw = d; ga.A8 = g->x8; ga.W8 = w8; ga.w8_exp = w8e; ga.out_lo8 = out_lo8; }
-    else if (c.act_split) { ga.K = 2 * d; ga.ka = 0; ga.A2 = g->x_lo; ga.kw = d; }
-    ga.out_lo = out_lo;
+  // QKV / FFN-up: consume the LayerNorm output
+  auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, int widx) {
+    GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d, 0};
+    lo_set(ga, g->x4, g->x4s, widx);
+    if (wm && epi == EPI_GELU_H16 && (g->wcorr_mask & 8)) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
+    if (xlo) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }
     ga.sat = g->sat;
     gemm_rc |= gemm_tn(s, epi, ga, wm ? 257 : 0);
   };
-  // act_split == 2: the attention output and the FFN hidden also exist as hi + lo pairs, so the two residual GEMMs sweep their weight twice as well
-  auto split2 = [&](GemmArgs& ga, const h16* lo, int kw) { if (lo) { ga.K = 2 * kw; ga.ka = 0; ga.A2 = lo; ga.kw = kw; } };
-  auto split8 = [&](GemmArgs& ga, const uint8_t* a8, int kw, int widx) {
-    if (f8) { ga.K = kw + kw / 2; ga.ka = 0; ga.kw = kw; ga.A8 = a8; ga.W8 = g->w8[widx]; ga.w8_exp = g->w8_exp + widx; }
+  // out-proj / FFN-down: + residual (prev: the LayerNorm whose output is the residual, re-derived from the row statistics; null: the buffer's own rows)
+  auto rgemm = [&](const h16* A, const h16* W, const float* bias, int K, int widx, const uint8_t* a4, const uint8_t* a4s, const float* ln_g, const float* ln_b) {
+    GemmArgs ga{A, W, bias, g->y_f32, g->y_f32, nullptr, M, d, K, 0};
+    if (ln_g) { ga.ln_stats = g->ln_stats; ga.ln_g = ln_g; ga.ln_b = ln_b; }
+    lo_set(ga, a4, a4s, widx);
+    gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0);
   };
   {
     ProfScope p("embed_ln", s, true);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
     e.x_lo = c.depth ? xlo_trunk : g->x_lo;
-    e.x8 = x8p; e.f4 = f4x;
+    e.f4 = f4x;
     embed_ln(s, e);
   }
-  if (c.prenorm) {
-    // use_prenorm (bert.py:49-59, 106-123): x = x + Attn(LN(x)); x = x + FFN(LN(x)); the fp32 stream buffer holds x itself, every
-    // LayerNorm only produces the fp16 GEMM operand and the residual GEMMs add the buffer's own rows in place.
-    for (int l = 0; l < c.depth; ++l) {
-      const mb_gen::Layer& L = g->layers[l];
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, f4x); }
-      { ProfScope p("gemm_qkv", s, true);
-        xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
-      if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-      { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
-      attn_rc |= attn_maps(l);
-      { ProfScope p("gemm_attn_out", s, true);
-        GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
-        split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
-        if (wm) { ga.ka = 0; lo_set(ga, g->att4, g->att4s, 4 * l + 1); }
-        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
-      { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, x8p, f4x); }
-      { ProfScope p("gemm_ffn_up", s, true);
-        xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
-      { ProfScope p("gemm_ffn_down", s, true);
-        GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
-        split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
-        if (wm) { ga.ka = 0; lo_set(ga, g->h4, g->h4s, 4 * l + 3); }
-        gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
-    }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }   // norm_after_transformer
-  } else {
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
-    { ProfScope p("gemm_qkv", s, true);
-      xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, g->sc(4 * l), nullptr, f8 ? g->w8[4 * l] : nullptr, f8 ? g->w8_exp + 4 * l : nullptr, nullptr, 4 * l); }
-    if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
-    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, g->att_lo, g->att8, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
+    // post-norm (every shipped config): the fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows; a LayerNorm writes only the
+    // fp16 GEMM operand and {mean, rstd}, the next residual GEMM re-derives the normalised rows in its epilogue and updates y_f32 in place (layer 0's
+    // first residual is the embedding LayerNorm output, stored as is by embed_ln).  use_prenorm (bert.py:49-59, 106-123): x = x + Attn(LN(x));
+    // x = x + FFN(LN(x)): the buffer holds x itself, every LayerNorm only produces the GEMM operand, the residual GEMMs add the buffer's own rows.
+    if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, f4x); }
+    { ProfScope p("gemm_qkv", s, true); xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, 4 * l); }
+    { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
     attn_rc |= attn_maps(l);
-    // The fp32 residual stream lives in ONE buffer, y_f32, holding pre-LayerNorm rows.  A LayerNorm writes only the fp16
-    // GEMM operand and {mean, rstd}; the next residual GEMM re-derives the normalised rows in its epilogue and updates
-    // y_f32 in place.  (Layer 0's first residual is the embedding LayerNorm output, stored as is by embed_ln.)
     { ProfScope p("gemm_attn_out", s, true);
-      GemmArgs ga{g->att, L.wo, L.bo, g->y_f32, g->y_f32, nullptr, M, d, d * ks, 0, d, g->sc(4 * l + 1)};
-      if (l > 0) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
-      split2(ga, g->att_lo, d); split8(ga, g->att8, d, 4 * l + 1);
-      if (wm) { ga.ka = 0; lo_set(ga, g->att4, g->att4s, 4 * l + 1); }
-      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, xlo_trunk, x8p, f4x); }
-    { ProfScope p("gemm_ffn_up", s, true);
-      xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, g->sc(4 * l + 2), g->h_lo, f8 ? g->w8[4 * l + 2] : nullptr, f8 ? g->w8_exp + 4 * l + 2 : nullptr, g->h8, 4 * l + 2); }
+      const bool re = !c.prenorm && l > 0;
+      rgemm(g->att, L.wo, L.bo, d, 4 * l + 1, g->att4, g->att4s, re ? g->layers[l - 1].ln2g : nullptr, re ? g->layers[l - 1].ln2b : nullptr); }
+    { ProfScope p("layernorm", s, true);
+      layernorm_rows(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, nullptr, g->x_h16, c.prenorm ? nullptr : g->ln_stats, M, d, xlo_trunk, f4x); }
+    { ProfScope p("gemm_ffn_up", s, true); xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, 4 * l + 2); }
     { ProfScope p("gemm_ffn_down", s, true);
-      GemmArgs ga{g->h, L.w2, L.b2, g->y_f32, g->y_f32, nullptr, M, d, f * ks, 0, f, g->sc(4 * l + 3)};
-      ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b;
-      split2(ga, g->h_lo, f); split8(ga, g->h8, f, 4 * l + 3);
-      if (wm) { ga.ka = 0; lo_set(ga, g->h4, g->h4s, 4 * l + 3); }
-      gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0); }
-    { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, l + 1 == c.depth ? g->x_lo : xlo_trunk, x8p,
-                                                          l + 1 == c.depth ? Fp4Rows{} : f4x); }   // the last one feeds the head
+      rgemm(g->h, L.w2, L.b2, f, 4 * l + 3, g->h4, g->h4s, c.prenorm ? nullptr : L.ln1g, c.prenorm ? nullptr : L.ln1b); }
+    if (!c.prenorm) { ProfScope p("layernorm", s, true);
+      const bool last = l + 1 == c.depth;                  // the last one feeds the head: plain hi + lo rows
+      layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, last ? g->x_lo : xlo_trunk, last ? Fp4Rows{} : f4x); }
   }
-  }
+  if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }   // norm_after_transformer
   gemm_rc |= head_gemms(g, logits, M, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   if (attn_rc) return fail(-3, "attention maps: head dim %d / %d tokens not supported", d / c.heads, N);
-  if (gemm_rc) return fail(-3, "a trunk GEMM of this forward (%d sequences x %d tokens, hidden %d, mlp %d; act_split %d, cfg_pair %d%s) is outside the "
-                               "half-tile kernel's shapes: its lo pass / correction mini-tiles cannot run", nb, N, d, f, c.act_split, c.cfg_pair,
-                               wm ? ", weight-correction mini-tiles" : "");
+  if (gemm_rc) return fail(-3, "a trunk GEMM of this forward (%d sequences x %d tokens, hidden %d, mlp %d; precision %d%s) is outside the half-tile "
+                               "kernel's shapes: its correction mini-tiles cannot run", nb, N, d, f, c.precision, wm ? ", weight-correction mini-tiles" : "");
   return 0;
 }
 
-// Differential CFG forward (mb_gen_cfg.cfg_pair): nb = 2 * B sequences laid out [B conditional | B label-dropped twins] in every buffer.
+// Differential CFG forward (mb_gen_cfg.precision >= 1): nb = 2 * B sequences laid out [B conditional | B label-dropped twins] in every buffer.
 // Wherever a fp16 GEMM operand is produced (embedding LayerNorm, the LayerNorms, attention output, GELU output), the conditional rows hold
 // fp16(x_c) and the unconditional rows the DIFFERENCE fp16(x_u - x_c); the pair GEMM (gemm_ht.hip, PAIR) adds the two products for the
 // unconditional outputs.  The fp32 residual stream, qkv and the logits hold ordinary values for both streams.  wmode: MX-fp4 correction
@@ -331,7 +272,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- an option
   // (mb_gen_set_wcorr_from), not the default
   const int wfrom = g->wcorr_from;
-  const bool alo = wmode && c.cfg_pair == 3;             // + activation-lo mini-tiles of the LayerNorm outputs (QKV / FFN-up)
+  const bool alo = wmode && c.precision == 3;            // + activation-lo mini-tiles of the LayerNorm outputs (QKV / FFN-up)
   auto f4_for = [&](int consumer_layer) {                // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
     if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) { f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; f.seq_rows = N; if (alo) { f.xl4 = g->xl4; f.xl4s = g->xl4s; } }
@@ -340,7 +281,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // lo: 0 = fp16 only, 1 = weight-correction mini-tiles (a4 / a4s = e2m1 of the conditional operand values), 2 = + the activation-lo set (x only)
   auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, int lo,
                    const uint8_t* a4 = nullptr, const uint8_t* a4s = nullptr) {
-    GemmArgs ga{A, W, bias, res, res, out16, M, Nout, g->split ? 2 * K : K, 0, g->split ? K : 0, g->sc(widx)};   // fp16x2 weights: A swept twice
+    GemmArgs ga{A, W, bias, res, res, out16, M, Nout, K, 0};
     ga.pair_rows = P;
     ga.seq_rows = N;
     if (epi != EPI_RES_F32) ga.sat = g->sat;
@@ -375,9 +316,8 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     { ProfScope p("gemm_qkv", s, true);
       GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, xlo_mode, g->x4, g->x4s);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
-    if (attn_f8_diag() && (3 * d) % 256 == 0) qkv_e4m3_round(s, g->qkv, M, 3 * d);
     const bool wo4 = wl && (g->wcorr_mask & 2), wh4 = wl && (g->wcorr_mask & 8);
-    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, g->att_aux, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
+    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
     { ProfScope p("gemm_attn_out", s, true);
       GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? 1 : 0, g->att4, g->att4s);
       if (l > 0 && !c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
@@ -429,9 +369,9 @@ int gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const u
 // Guided forward (sampling.py:83-88) over B samples: logits rows [0, B) conditional, [B, 2B) label-dropped.
 int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, hipStream_t s) {
   const size_t P = (size_t)g->c.seq * g->c.splits;
-  const bool pair = g->pair_ok && g->c.cfg_pair > 0;
+  const bool pair = g->pair_ok && g->c.precision >= 1;
   (void)scale;
-  const bool wmode = pair && g->c.cfg_pair >= 2;        // weight-rounding correction pass (every step: weight rounding costs parity late in the run too)
+  const bool wmode = pair && g->c.precision >= 2;       // weight-rounding correction pass (every step: weight rounding costs parity late in the run too)
   const int chunk = g->chunk_seqs / 2;                  // pairs per pass
   if (chunk < 1) return fail(-1, "engine holds %d sequences: too few for a guided forward", g->chunk_seqs);
   for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -486,20 +426,12 @@ int mb_prof_read(char* buf, int buflen) {
   return (int)out.size();
 }
 
-int mb_split_weights(const float* W, int N, int K, void* dst_h16, float* scale_out, void* tmp, mb_stream stream) {
-  if (!W || !dst_h16 || !scale_out || !tmp || N <= 0 || K <= 0) return fail(-1, "mb_split_weights: bad arguments");
-  mb::split_f32_to_h16x2((hipStream_t)stream, W, (h16*)dst_h16, N, K, scale_out, (unsigned*)tmp);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
-  return 0;
-}
 int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16,
-               int M, int N, int K, int ka, const float* scale, const float* ln_stats, const float* ln_g, const float* ln_b,
-               int period, int variant, mb_stream stream) {
+               int M, int N, int K, const float* ln_stats, const float* ln_g, const float* ln_b, int period, int variant, mb_stream stream) {
   if (!A || !W || !bias || epi < 0 || epi > 4) return fail(-1, "mb_gemm_ex: bad arguments");
-  if (K % 64 || (ka && (ka % 64 || K != 2 * ka || !scale))) return fail(-1, "mb_gemm_ex: K must be a multiple of 64 (and 2*ka with a scale for split weights)");
+  if (K % 64) return fail(-1, "mb_gemm_ex: K must be a multiple of 64");
   if (ln_stats && (!ln_g || !ln_b || epi != mb::EPI_RES_F32)) return fail(-1, "mb_gemm_ex: LayerNorm residual needs gamma, beta and the fp32+residual epilogue");
-  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period, ka, scale, ln_stats, ln_g, ln_b};
+  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period, nullptr, ln_stats, ln_g, ln_b};
   ProfScope p("gemm_diag", (hipStream_t)stream);
   if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
@@ -513,7 +445,7 @@ int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const
 int mb_gemm_mini_seq(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
                      void* out4_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream) {
   if (!A || !W || !bias || epi < 0 || epi > 2 || rows <= 0 || K <= 0 || K % 64 || nlo < 0 || nlo > 2 || (nlo && !lo) || (seq_rows && !pair)) return fail(-1, "mb_gemm_mini: bad arguments");
-  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, pair ? 2 * rows : rows, N, K, 0, 0, nullptr};
+  mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, pair ? 2 * rows : rows, N, K, 0};
   if (pair) { a.pair_rows = rows; a.seq_rows = seq_rows; }
   a.nlo = nlo;
   for (int i = 0; i < nlo; ++i) a.lo[i] = {(const uint8_t*)lo[4 * i], (const uint8_t*)lo[4 * i + 1], (const uint8_t*)lo[4 * i + 2], (const uint8_t*)lo[4 * i + 3]};
@@ -529,7 +461,7 @@ int mb_gemm_mini_split(int epi, const void* A_hi, const void* A_lo, const void* 
                        int rows, int N, int kw, const void* const* lo /* {A4, a_scale, W4, w_scale} */, mb_stream stream) {
   if (!A_hi || !A_lo || !W || !bias || !out_h16 || !lo || epi < 0 || epi > 1 || rows <= 0 || rows % 257 || kw <= 0 || kw % 128)
     return fail(-1, "mb_gemm_mini_split: bad arguments");
-  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, nullptr, nullptr, (h16*)out_h16, rows, N, 2 * kw, 0, 0, nullptr};
+  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, nullptr, nullptr, (h16*)out_h16, rows, N, 2 * kw, 0};
   a.A2 = (const h16*)A_lo; a.kw = kw;
   a.nlo = 1;
   a.lo[0] = {(const uint8_t*)lo[0], (const uint8_t*)lo[1], (const uint8_t*)lo[2], (const uint8_t*)lo[3]};
@@ -541,11 +473,11 @@ int mb_gemm_mini_split(int epi, const void* A_hi, const void* A_lo, const void* 
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
-int mb_attention_pair(const void* qkv, void* out_h16, float* aux, int pairs, int N, int d, int heads, mb_stream stream) {
-  if (!qkv || !out_h16 || !aux || pairs <= 0 || N <= 0 || heads <= 0 || d % heads) return fail(-1, "mb_attention_pair: bad arguments");
+int mb_attention_pair(const void* qkv, void* out_h16, int pairs, int N, int d, int heads, mb_stream stream) {
+  if (!qkv || !out_h16 || pairs <= 0 || N <= 0 || heads <= 0 || d % heads) return fail(-1, "mb_attention_pair: bad arguments");
   ProfScope p("attention", (hipStream_t)stream);
-  if (mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out_h16, aux, pairs, N, d, heads, nullptr, nullptr))
-    return fail(-3, "mb_attention_pair: N = %d tokens / head width %d is outside the on-chip attention kernel", N, d / heads);
+  if (mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out_h16, pairs, N, d, heads, nullptr, nullptr))
+    return fail(-3, "mb_attention_pair: head width %d (N = %d tokens) is outside the attention kernels", d / heads, N);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -553,20 +485,8 @@ int mb_attention_pair(const void* qkv, void* out_h16, float* aux, int pairs, int
 int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual, float* out_f32,
                       void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
   if (!A_hi || !A_lo || !W || !bias || epi < 0 || epi > 3 || kw <= 0 || kw % 64) return fail(-1, "mb_gemm_act_split: bad arguments");
-  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, 2 * kw, 0, 0, nullptr};
+  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, 2 * kw, 0};
   a.A2 = (const h16*)A_lo; a.kw = kw;
-  ProfScope p("gemm_diag", (hipStream_t)stream);
-  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
-  return 0;
-}
-int mb_gemm_f8lo(int epi, const void* A_hi, const void* A8, const void* W, const void* W8, const int* w8_exp, const float* bias,
-                 const float* residual, float* out_f32, void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
-  if (!A_hi || !A8 || !W || !W8 || !w8_exp || !bias || epi < 0 || epi > 2 || kw <= 0 || kw % 128) return fail(-1, "mb_gemm_f8lo: bad arguments");
-  mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, kw + kw / 2, 0, 0, nullptr};
-  a.kw = kw; a.A8 = (const uint8_t*)A8; a.W8 = (const uint8_t*)W8; a.w8_exp = w8_exp;
-  if (!mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_f8lo: shape not supported by the half-tile kernel");
   ProfScope p("gemm_diag", (hipStream_t)stream);
   if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
@@ -592,7 +512,7 @@ int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float
   if (!y || !gamma || !beta || (!x4 && !xl4) || (x4 && !x4_scale) || (xl4 && !xl4_scale) || M <= 0 || M % 257 || (d != 768 && d != 1024))
     return fail(-1, "mb_layernorm_f4: bad arguments (d must be 768 or 1024, M a multiple of 257)");
   mb::Fp4Rows f4{(uint8_t*)x4, (uint8_t*)x4_scale, (uint8_t*)xl4, (uint8_t*)xl4_scale, M / 257};
-  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, nullptr, M, d, nullptr, nullptr, f4);
+  mb::layernorm_rows((hipStream_t)stream, y, gamma, beta, eps, x_f32, (h16*)x_h16, nullptr, M, d, nullptr, f4);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -632,17 +552,11 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if ((size_t)c.seq * c.splits > 8192) return fail(-1, "seq * splits = %zu exceeds the step kernel's 8192 positions", (size_t)c.seq * c.splits);
   const int C = 1 << (c.bits / c.splits);
   if (C > 4096 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d (the fused step kernel holds up to 4096 codes per group)", C);
-  if (c.weight_split != 0 && c.weight_split != 1) return fail(-1, "weight_split must be 0 or 1");
   if ((c.prenorm != 0 && c.prenorm != 1) || (c.embed_tables != 0 && c.embed_tables != 1)) return fail(-1, "prenorm / embed_tables must be 0 or 1");
-  if (c.embed_tables && c.weight_split) return fail(-1, "weight_split is not supported with embed_tables (the tied head spans one table per group)");
   if (c.embed_tables && c.splits > 8) return fail(-1, "embed_tables supports up to 8 token groups");
-  if (c.act_split < 0 || c.act_split > 3) return fail(-1, "act_split must be 0 .. 3 (4, the MX-fp4 lo K-tiles of rounds 2-3, was retired with the mini-tile passes of cfg_pair 2 / 3)");
-  if (c.act_split >= 3 && (c.hidden % 256 || c.mlp % 256)) return fail(-1, "act_split = 3 (8-bit lo pass) needs hidden and mlp to be multiples of 256");
-  if (c.act_split && c.weight_split) return fail(-1, "act_split and weight_split are not combined");
-  if (c.cfg_pair < 0 || c.cfg_pair > 3) return fail(-1, "cfg_pair must be 0 .. 3");
-  if (c.cfg_pair >= 2 && c.weight_split) return fail(-1, "cfg_pair = 2 / 3 (weight-correction passes) is not combined with weight_split");
+  if (c.precision < 0 || c.precision > 3) return fail(-1, "precision must be 0 .. 3 (MB_PREC_FP16 / _DIFF / _WCORR / _ALO)");
   mb_gen* g = new mb_gen();
-  g->c = c; g->split = c.weight_split; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
+  g->c = c; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
   // rows per forward pass: 32-bit byte offsets inside the kernels need rows * max(mlp, 3 * hidden) * 4 < 2^32 (gemm_ht_supported)
   const size_t widest = (size_t)(c.mlp > 3 * c.hidden ? c.mlp : 3 * c.hidden);
@@ -651,15 +565,14 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   const size_t d = c.hidden, f = c.mlp, M = (size_t)g->chunk_seqs * g->N;
   int rc = 0;
   g->layers.resize(c.depth);
-  const size_t ws = g->split ? 2 : 1;                  // fp16 values per weight
-  rc |= galloc(g, &g->wscale, (size_t)4 * c.depth + 2); rc |= galloc(g, &g->split_tmp, 1);
+  rc |= galloc(g, &g->split_tmp, 1);
   rc |= galloc(g, &g->sat, 1);
   if (!rc) (void)hipMemset(g->sat, 0, sizeof(unsigned));
   for (auto& L : g->layers) {
-    rc |= galloc(g, &L.wqkv, ws * 3 * d * d); rc |= galloc(g, &L.bqkv, 3 * d);
-    rc |= galloc(g, &L.wo, ws * d * d); rc |= galloc(g, &L.bo, d);
-    rc |= galloc(g, &L.w1, ws * f * d); rc |= galloc(g, &L.b1, f);
-    rc |= galloc(g, &L.w2, ws * d * f); rc |= galloc(g, &L.b2, d);
+    rc |= galloc(g, &L.wqkv, 3 * d * d); rc |= galloc(g, &L.bqkv, 3 * d);
+    rc |= galloc(g, &L.wo, d * d); rc |= galloc(g, &L.bo, d);
+    rc |= galloc(g, &L.w1, f * d); rc |= galloc(g, &L.b1, f);
+    rc |= galloc(g, &L.w2, d * f); rc |= galloc(g, &L.b2, d);
     rc |= galloc(g, &L.ln1g, d); rc |= galloc(g, &L.ln1b, d); rc |= galloc(g, &L.ln2g, d); rc |= galloc(g, &L.ln2b, d);
   }
   rc |= galloc(g, &g->w_in, d * c.bits); rc |= galloc(g, &g->b_in, d);
@@ -671,35 +584,21 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   rc |= galloc(g, &g->wp, (size_t)c.splits * C * d); rc |= galloc(g, &g->bp, (size_t)c.splits * C); rc |= galloc(g, &g->head_scale, 2);
   if (!c.embed_tables) rc |= galloc(g, &g->wp_lo, (size_t)c.splits * C * d);
   rc |= galloc(g, &g->y_f32, M * d); rc |= galloc(g, &g->ln_stats, M * 2); rc |= galloc(g, &g->x_h16, M * d);
-  rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, act_split 1 / 2 for the trunk
-  if (c.act_split == 2) { rc |= galloc(g, &g->att_lo, M * d); rc |= galloc(g, &g->h_lo, M * f); }
-  if (c.act_split >= 3) {
-    rc |= galloc(g, &g->x8, M * 2 * d);
-    rc |= galloc(g, &g->att8, M * 2 * d); rc |= galloc(g, &g->h8, M * 2 * f);
-    rc |= galloc(g, &g->w8_exp, (size_t)4 * c.depth);
-    g->w8.assign((size_t)4 * c.depth, nullptr);
-    for (int l = 0; l < c.depth; ++l) {
-      rc |= galloc(g, &g->w8[4 * l], 2 * 3 * d * d); rc |= galloc(g, &g->w8[4 * l + 2], 2 * f * d);
-      rc |= galloc(g, &g->w8[4 * l + 1], 2 * d * d); rc |= galloc(g, &g->w8[4 * l + 3], 2 * d * f);
-    }
-    if (!rc) { (void)hipMemset(g->x8, 0, M * 2 * d); (void)hipMemset(g->att8, 0, M * 2 * d); (void)hipMemset(g->h8, 0, M * 2 * f); }
-  }
+  rc |= galloc(g, &g->x_lo, M * d);   // lo halves of the LayerNorm outputs: always for the head GEMMs, precision >= 1 for QKV / FFN-up of plain forwards
   rc |= galloc(g, &g->qkv, M * 3 * d); rc |= galloc(g, &g->att, M * d); rc |= galloc(g, &g->h, M * f);
-  // MX-fp4 mini-tile passes (cfg_pair 2 / 3): 257-token sequences, vector LayerNorm widths, heads of 64 (the attention kernels' e2m1 output), whole mini-tiles
-  g->mini_ok = c.cfg_pair >= 2 && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && c.hidden / c.heads == 64 && !c.weight_split;   // (FFN-up's N = mlp: whole 256-column tiles)
+  // MX-fp4 mini-tile passes (precision 2 / 3): 257- / 1025-token sequences, vector LayerNorm widths, heads of 64 (the attention kernels' e2m1 output), whole mini-tiles
+  g->mini_ok = c.precision >= 2 && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && c.hidden / c.heads == 64;   // (FFN-up's N = mlp: whole 256-column tiles)
   // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
-  // (act_split only concerns the plain forward; with fp16x2 weights the pair GEMMs sweep their operand twice)
   // (round 5: also the 1024 + 1-token models of 512 x 512 images -- a pair tile is 128 tokens of a sequence pair whatever the sequence length)
-  g->pair_ok = c.cfg_pair && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && g->chunk_seqs >= 2 &&
-               (c.cfg_pair == 1 || g->mini_ok);
-  if (g->pair_ok) rc |= galloc(g, &g->att_aux, (M / 2) * d);
+  g->pair_ok = c.precision >= 1 && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && g->chunk_seqs >= 2 &&
+               (c.precision == 1 || g->mini_ok);
   if (g->mini_ok) {
     // e2m1 operands: row stride of the fp16 sibling (2 * width bytes, first width / 2 used); scale bytes in lane order: [width / 64][sequences][256]
     const size_t ns = (size_t)g->chunk_seqs * c.seq;
     rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->att4, M * 2 * d); rc |= galloc(g, &g->att4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->h4, M * 2 * f); rc |= galloc(g, &g->h4s, (f / 64) * ns + 256);
-    if (c.cfg_pair == 3) { rc |= galloc(g, &g->xl4, M * 2 * d); rc |= galloc(g, &g->xl4s, (d / 64) * ns + 256); }
+    if (c.precision == 3) { rc |= galloc(g, &g->xl4, M * 2 * d); rc |= galloc(g, &g->xl4s, (d / 64) * ns + 256); }
     if (!rc) {
       (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, (d / 64) * ns + 256);
       (void)hipMemset(g->att4, 0, M * 2 * d); (void)hipMemset(g->att4s, 0, (d / 64) * ns + 256);
@@ -713,7 +612,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
       rc |= galloc(g, &g->w4lo[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4los[4 * l + 1], d);
       rc |= galloc(g, &g->w4lo[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4los[4 * l + 2], f);
       rc |= galloc(g, &g->w4lo[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4los[4 * l + 3], d);
-      if (c.cfg_pair == 3) {
+      if (c.precision == 3) {
         rc |= galloc(g, &g->w4[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4s[4 * l], 3 * d);
         rc |= galloc(g, &g->w4[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4s[4 * l + 2], f);
       }
@@ -806,14 +705,12 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   if (dst_f == g->w_in) mb::transpose_f32(s, data, g->w_in, (int)d, c.bits);       // [d,K] -> [K,d] for the embed kernel
   else if (dst_h == g->wl) mb::split_f32_to_h16_planes(s, data, g->wl, g->wl_lo, wrows, wcols, g->head_scale, g->split_tmp);
   else if (dst_h == g->wp) mb::split_f32_to_h16_planes(s, data, g->wp, g->wp_lo, wrows, wcols, g->head_scale + 1, g->split_tmp);
-  else if (dst_h && g->split) mb::split_f32_to_h16x2(s, data, dst_h, wrows, wcols, g->wscale + sidx, g->split_tmp);
   else if (dst_h) {
     mb::cast_f32_to_h16(s, data, dst_h, numel);
     if (g->mini_ok && sidx >= 0 && sidx < 4 * c.depth) {
       mb::w4lo_from_f32(s, data, g->w4lo[sidx], wrows, wcols, g->w4los[sidx]);
       if (g->w4[sidx]) mb::w4_from_f32(s, data, g->w4[sidx], wrows, wcols, g->w4s[sidx]);
     }
-    if (c.act_split >= 3 && sidx >= 0 && sidx < 4 * c.depth) mb::w8_from_f32(s, data, g->w8[sidx], wrows, wcols, g->w8_exp + sidx, g->split_tmp);
   }
   else HIP_TRY(hipMemcpyAsync(dst_f, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   g->loaded++;

@@ -31,13 +31,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   const int tiles_m = (a.M + BM - 1) / BM;
   const int L = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
-  const int K = a.K, KA = a.ka ? a.ka : (a.kw ? a.kw : a.K), nka = KA / BK;
+  const int K = a.K, KA = a.kw ? a.kw : a.K, nka = KA / BK;
   const int KW = a.kw ? a.kw : a.K, nkw = KW / BK;   // split activations: W has kw columns and is swept twice, A2 takes over from A
 
   // ---- staging: wave w owns rows [32w, 32w+32) of both tiles; 4 DMA instructions of 8 rows each
   const h16* xsrc[4];
   const h16* wsrc[4];
-  const ptrdiff_t a2 = a.A2 ? a.A2 - a.A : 0;       // second sweep of A: the lo halves (split activations) or A itself (split weights)
+  const ptrdiff_t a2 = a.A2 ? a.A2 - a.A : 0;       // second sweep of A: the lo halves (split activations)
   const ptrdiff_t w2 = a.W2 ? a.W2 - a.W : 0;       // three sweeps (GemmArgs.W2): the third pairs A with the weights' lo halves
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     wsrc[j] = a.W + (size_t)nr * KW + slot * 8;
   }
   auto stage = [&](int t, int buf) {
-    const int ta = t < nka ? t : t - nka;          // split weights: A is swept once per weight half
+    const int ta = t < nka ? t : t - nka;
     char* xb = smem + buf * 2 * TILE_BYTES + wave * 32 * 128;
     char* wb = xb + TILE_BYTES;
     if (a.W2) {                                    // sweeps (A, W), (A2, W), (A, W2)
@@ -140,8 +140,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
         satb |= !(fabsf(v0) <= MB_H16_MAX) | !(fabsf(v1) <= MB_H16_MAX) | !(fabsf(v2) <= MB_H16_MAX) | !(fabsf(v3) <= MB_H16_MAX);   // (fmaxf would drop a NaN)
         h16x4 o = {to_h(v0), to_h(v1), to_h(v2), to_h(v3)};
         *(h16x4*)(a.out_h16 + orow * a.N + n) = o;
-        if (a.out_lo)
-          *(h16x4*)(a.out_lo + orow * a.N + n) = h16x4{to_h(v0 - (float)o[0]), to_h(v1 - (float)o[1]), to_h(v2 - (float)o[2]), to_h(v3 - (float)o[3])};
       } else {
         *(float4*)(a.out_f32 + orow * a.N + n) = make_float4(v0, v1, v2, v3);
       }
@@ -152,16 +150,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
 
 int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
   // variant: 0 auto; -1 this 128x128 kernel; 6 / 8 the half-tile kernel with that MT; 257 its sequence-aligned tiles.
-  // Returns 0, or -1 when the request needs the half-tile kernel (8-bit / 4-bit lo pass) and the shape is outside it
+  // Returns 0, or -1 when the request needs the half-tile kernel (pair tiles, mini-tile passes) and the shape is outside it
   // (the caller reports it; nothing is launched).
-  if ((a.A8 || a.A4) && variant < 0) variant = 0;     // the lo pass exists in the half-tile kernel only
-  if (a.W2 && (!a.A2 || !a.kw || a.K != 3 * a.kw || !a.scale || a.ka)) return -1;
+  if (a.W2 && (!a.A2 || !a.kw || a.K != 3 * a.kw || !a.scale)) return -1;
   if (variant >= 0 && !a.W2 && gemm_ht_supported(epi, a)) {
     if (variant % 1000 == 257 && a.M % 257) variant = variant - variant % 1000;
     gemm_ht(s, epi, a, variant);
     return 0;
   }
-  if (a.A8 || a.A4 || a.pair_rows || a.nlo) return -1;   // (mini-tile passes exist in the half-tile kernel only: never dropped silently)
+  if (a.pair_rows || a.nlo) return -1;   // (mini-tile passes exist in the half-tile kernel only: never dropped silently)
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles), block(256);
   switch (epi) {
@@ -189,24 +186,6 @@ void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n) {
   hipLaunchKernelGGL(cast_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
 }
 
-
-// ---- e4m3 copy of a weight for the fp8 correction pass: W8[n][2K bytes] (first K used) = e4m3(W * 2^e), e = 7 - floor(log2(absmax)) ----
-__global__ void w8_kernel(const float* __restrict__ W, uint8_t* __restrict__ out, int N, int K, const unsigned* __restrict__ absmax_bits, int* __restrict__ exp_out) {
-  const float amax = __uint_as_float(*absmax_bits);
-  int e = 0;
-  if (amax > 0.f) { int ex; (void)frexpf(amax, &ex); e = 8 - ex; }           // amax = m * 2^ex, m in [0.5, 1) -> amax * 2^e in [128, 256)
-  if (blockIdx.x == 0 && threadIdx.x == 0) *exp_out = e;
-  const float sc = ldexpf(1.0f, e);
-  const size_t total = (size_t)N * (K / 4);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t n = i / (K / 4); const int c = (int)(i % (K / 4)) * 4;
-    const float4 v = *(const float4*)(W + n * K + c);
-    // the fp16 engine multiplies by fp16(W): quantise THAT value, so that hi.W16 + lo.W8 approximates (hi + lo).W16
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32((float)(h16)v.x * sc, (float)(h16)v.y * sc, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32((float)(h16)v.z * sc, (float)(h16)v.w * sc, w, true);
-    *(int*)(out + n * 2 * (size_t)K + c) = w;
-  }
-}
 
 // ---- e2m1 copy of a weight for the fp4 correction pass: one workgroup per weight row.  The row's power-of-two scale 2^r is the best of three
 // candidates around 2.2 / rms (measured optimum for Gaussian rows: quantisation error ~1.5 % of the row's energy) by summed squared error.
@@ -286,20 +265,10 @@ __global__ void split_kernel(const float* __restrict__ src, h16* __restrict__ ds
   if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = ldexpf(1.0f, -S);
   const size_t n = (size_t)N * K;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / K, k = i - r * K;
     const float w = ldexpf(src[i], S);
     const h16 hi = to_h(w);
-    if (lo_plane) { dst[i] = hi; lo_plane[i] = to_h(w - (float)hi); continue; }   // two [N,K] planes
-    dst[r * 2 * K + k] = hi;
-    dst[r * 2 * K + K + k] = to_h(w - (float)hi);
+    dst[i] = hi; lo_plane[i] = to_h(w - (float)hi);                               // two [N,K] planes
   }
-}
-void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K, float* scale_out, unsigned* tmp) {
-  const size_t n = (size_t)N * K;
-  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
-  (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
-  hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K, tmp, scale_out, (h16*)nullptr);
 }
 void split_f32_to_h16_planes(hipStream_t s, const float* src, h16* hi, h16* lo, int N, int K, float* scale_out, unsigned* tmp) {
   const size_t n = (size_t)N * K;
@@ -316,13 +285,4 @@ void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K,
   (void)hipMemsetAsync(dst4, 0, (size_t)N * K / 2, s);
   hipLaunchKernelGGL(w4lo_kernel, dim3(N), dim3(256), 0, s, src, dst4, N, K, scale_out);
 }
-void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp) {
-  const size_t n = (size_t)N * K;
-  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
-  (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);
-  (void)hipMemsetAsync(dst8, 0, 2 * n, s);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, tmp);
-  hipLaunchKernelGGL(w8_kernel, dim3(blocks), dim3(256), 0, s, src, dst8, N, K, tmp, exp_out);
-}
-
 }  // namespace mb

@@ -56,28 +56,6 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // A fragment pair (two 16-byte LDS reads of one lane) lives in ONE 8-VGPR tuple: the e4m3 MFMA takes it whole, the f16 / fp4 MFMAs its halves
 typedef h16 h16x16 __attribute__((ext_vector_type(16)));
 
-// One 16x16 output tile x one MX-fp4 K-tile of 256: two scaled MFMAs of K = 128, each over 16 bytes per lane and operand (the compiler narrows
-// the 8-VGPR operand to the 4 it reads).  SW / SX: which byte of the lane's scale VGPRs holds the E8M0 scale of this weight / token row.
-template <int SW, int SX>
-__device__ __forceinline__ f32x4 mma_f4(f32x4 c, const h16x16& w, const h16x16& x, int wsc, int xsc) {
-  const i32x8 wv = __builtin_bit_cast(i32x8, w), xv = __builtin_bit_cast(i32x8, x);
-  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 0, 1, 2, 3, -1, -1, -1, -1),
-                                                        __builtin_shufflevector(xv, xv, 0, 1, 2, 3, -1, -1, -1, -1), c, 4, 4, SW, wsc, SX, xsc);
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 4, 5, 6, 7, -1, -1, -1, -1),
-                                                          __builtin_shufflevector(xv, xv, 4, 5, 6, 7, -1, -1, -1, -1), c, 4, 4, SW, wsc, SX, xsc);
-}
-
-// The same with per-(row, 64 columns) block scales of the token operand (pair tiles): the lane's scale register of this m-tile holds the block
-// of k-step 0 in byte 0 and the block of k-step 1 in byte 2 (gemm_ht_kernel shifts the loaded dword by the lane group's block).
-template <int SW>
-__device__ __forceinline__ f32x4 mma_f4bs(f32x4 c, const h16x16& w, const h16x16& x, int wsc, int xsc) {
-  const i32x8 wv = __builtin_bit_cast(i32x8, w), xv = __builtin_bit_cast(i32x8, x);
-  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 0, 1, 2, 3, -1, -1, -1, -1),
-                                                        __builtin_shufflevector(xv, xv, 0, 1, 2, 3, -1, -1, -1, -1), c, 4, 4, SW, wsc, 0, xsc);
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wv, wv, 4, 5, 6, 7, -1, -1, -1, -1),
-                                                          __builtin_shufflevector(xv, xv, 4, 5, 6, 7, -1, -1, -1, -1), c, 4, 4, SW, wsc, 2, xsc);
-}
-
 // SEQ = true: "sequence-aligned" tiles.  The trunk's M is nb*257 (256 image tokens + the class token per
 // sequence) and 257 is prime, so every ordinary tiling leaves a nearly empty CU round.  With SEQ a tile covers exactly
 // one sequence: 256 rows through the regular MT = 8 machinery plus the class-token row as a 17th, one-row m-tile whose
@@ -111,20 +89,21 @@ __device__ long long* g_ht_trace = nullptr;
 // its 256 rows but only 64 / NS of every wave's 64 columns (column block `hb` of the 256-column tile, staged in the B0 slot; phases (A0, B1) and
 // (A1, B1) multiply nothing), so an N = 1024 GEMM over 16 sequences runs 128 / 256 tiles instead of 64 on 256 CUs.  Every output element sees the
 // same K-tiles and mini-tiles in the same order as in a full tile: bit-identical results, so the choice may depend on the batch size.
-template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, int NS = 1>   // XP: 0 = fp16 K-tiles only, 4 / 5 = fp16 K-tiles followed by an e4m3 / MX-fp4 lo pass, 6 = MX-fp4 mini-tiles
+template <int MT, int EPI, int XP = 0, bool SEQ = false, bool PAIR = false, int NS = 1>   // XP: 0 = fp16 K-tiles only, 6 = + MX-fp4 mini-tiles (4 / 5, the e4m3 / MX-fp4 lo K-TILES of rounds 1-3, were removed in round 5)
 __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m, int tiles_n) {
   constexpr bool HN = NS > 1, QN = NS == 4;
   constexpr int NTW = 4 / NS;                          // n-tiles of a wave
   static_assert(NS == 1 || NS == 2 || NS == 4, "column split");
   static_assert(!HN || (SEQ && !PAIR && XP == 6 && EPI == EPI_RES_F32), "half-column tiles: plain sequence tiles with mini-tiles, residual epilogue");
   static_assert(!SEQ || MT == 8, "sequence-aligned tiles use the 256-row machinery");
-  static_assert(!PAIR || (SEQ && XP != 4), "pair tiles are sequence-aligned (fp16 or fp4 lo pass)");
+  static_assert(XP == 0 || XP == 6, "fp16 K-tiles, optionally with mini-tiles");
+  static_assert(!PAIR || SEQ, "pair tiles are sequence-aligned");
   constexpr bool MINI = XP == 6;
   static_assert(!MINI || SEQ, "mini-tile passes are written for sequence-aligned tiles");
   constexpr int MINI_A = 128 * 64, MINI_B = 256 * 64;   // bytes: 128 token rows / 256 weight rows x 128 e2m1 values
-  // Every fp16 / fp4 instance walks the tile list persistently (round 1 kept the fp32+residual epilogue at one tile per workgroup: it spilled
+  // Every instance walks the tile list persistently (round 1 kept the fp32+residual epilogue at one tile per workgroup: it spilled
   // VGPRs inside the K loop then; with the present epilogue it does not: 244-248 VGPRs, no scratch).
-  constexpr bool PERSIST = XP != 4;   // (persistent e4m3 kernels: 140 spilled SGPRs + VGPR spills; they run one tile per workgroup)
+  constexpr bool PERSIST = true;
   constexpr int AUX = 0;   // DMA cache policy: default beats nt (-14 %) and sc1 (-6 %) here, sc0 is equal (measured)
   constexpr int BM = 32 * MT, MH = MT / 2;
   constexpr int AH_ROWS = BM / 2;
@@ -142,31 +121,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
   const int K = a.K, nk = K / 64;
-  const int KA = a.ka ? a.ka : (a.kw ? a.kw : K), nka = KA / 64;   // split weights: A has KA = K/2 columns and is swept twice
+  const int KA = a.kw ? a.kw : K, nka = KA / 64;       // split activations: A and A2 have kw = K/2 columns each
   const int KW = a.kw ? a.kw : K, nkw = KW / 64;       // split activations: W has K/2 columns and is swept twice, A2 (lo halves) takes over from A
-  constexpr bool F8 = XP == 4;                         // e4m3 lo pass: K-tiles >= nka come from (A8, W8), 128 K-elements per tile
-  constexpr bool F4 = XP == 5;                         // MX-fp4 lo pass: K-tiles >= nka come from (A4, W4), 256 K-elements per tile, fp16 fragment reads
-  constexpr bool LO = F8 || F4;
-  // pair tiles + fp4 pass: the token operand's scales are per (row, 64 K-elements) -- a_scale[row][kw / 64] -- and reloaded per lo K-tile (one dword
-  // per m-tile = the tile's 4 blocks), so that producers whose rows span several workgroups (attention heads, FFN-up column tiles) can scale locally
-  constexpr bool BS = PAIR && F4;
-  static_assert(!F4 || MT == 8, "the fp4 lo pass is written for the 256-row machinery");
-  // Sequence-aligned e4m3 kernels: the DMA of an e4m3 K-tile permutes the 16-byte chunks of a row on the way into LDS (position ks*4+g
-  // receives chunk 2g+ks, the 32 bytes lane group g feeds to the K = 128 MFMA), so the fragment reads are the fp16 ones -- reading
-  // chunks 2g+ks in place was a 2-way LDS bank conflict on every read (PMC: 10.2 M conflict cycles of 40.9 M active, fp16 tiles: 0)
-  constexpr bool PERM = F8 && SEQ;
+  // split activations (A2 / kw): K-tiles >= nka read the lo halves A2 against the same W columns
+  const h16* const Alo = a.A2 ? a.A2 : a.A;
+  const h16* const Wlo = a.W;
   // pair tiles: SQ rows per sequence (class token last), TPS = (SQ - 1) / 128 tiles per sequence pair (2 or 8: a power of two), 2 TPS groups of 64 tokens
   const int SQ = a.seq_rows ? a.seq_rows : 257;
   const int tps_sh = PAIR ? 31 - __builtin_clz((unsigned)((SQ - 1) >> 7)) : 1;
   const int TPS = 1 << tps_sh;
-  const h16* const Alo = F8 ? (const h16*)a.A8 : (F4 ? (const h16*)a.A4 : (a.A2 ? a.A2 : a.A));
-  const h16* const Wlo = F8 ? (const h16*)a.W8 : (F4 ? (const h16*)a.W4 : a.W);
   const int ntiles = tiles_m * tiles_n;
 
   // ---- per-tile DMA plan of this wave: 2 instructions per half-tile; lane -> (row 8j + lane>>3, slot lane&7)
   struct Plan {
     uint32_t offA[2][2], offB[2][2], offX;   // element offsets into A / W
-    int d8;                                  // PERM: added to offA / offB for e4m3 K-tiles (permuted source chunk)
     int m0, n0;
     int cls;                                 // PAIR: the conditional class-token row of this tile's sequence pair; odd tiles store it
     int q;                                   // PAIR: which 128-token half of the sequence this tile covers
@@ -207,11 +175,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     }
     // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
     p.offX = (uint32_t)(PAIR ? p.cls + ((lane_o >> 3) == 1 ? a.pair_rows : 0) : min(p.m0 + 256, a.M - 1)) * (uint32_t)KA + ((lane_o & 7) ^ MB_SWZ(lane_o >> 3)) * 8;
-    if (PERM) {
-      const int ra = wave * 8 + (lane_o >> 3);                           // row of instruction j = 0 inside its half-tile (A and B alike)
-      const int qa = (lane_o & 7) ^ MB_SWZ(ra);
-      p.d8 = (2 * (qa & 3) + (qa >> 2) - qa) * 8;
-    }
   };
   // trace builds, modes 3 / 4: the K loop's DMA is dropped / re-reads K-tiles 0 and 1 (always L2 hits) -- what the loop costs without (slow) memory
 #if defined(MB_HT_TRACE) && MB_HT_TRACE == 3
@@ -223,21 +186,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #endif
   auto dma_x = [&](const Plan& p, int t) {
     MB_TRACE_DMA(t);
-    int dx = 0;
-    if (PERM && t >= nka) { int lo_ = lane; asm volatile("" : "+v"(lo_)); const int qx = (lo_ & 7) ^ MB_SWZ(lo_ >> 3); dx = (2 * (qx & 3) + (qx >> 2) - qx) * 8; }
-    if (SEQ && wave == 7) MB_GLDS16_AUX((t < nka ? a.A : Alo) + (p.offX + dx) + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
+    if (SEQ && wave == 7) MB_GLDS16_AUX((t < nka ? a.A : Alo) + p.offX + (t < nka ? t : t - nka) * 64, smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + 2 * BH_BYTES, AUX);
   };
   auto dma_a = [&](const Plan& p, int t, int h) {
     MB_TRACE_DMA(t);
     char* buf = smem + (t & 1) * PAR_BYTES + h * AH_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      // sequence-aligned tiles never clamp a row, so the four half-tile instructions of a wave differ by whole rows only:
-      // one per-lane offset + a uniform (h * 64 + j * 128) * KA (6 VGPRs less than a table; used where VGPRs are the limit: the e4m3 kernels)
-      uint32_t o = (SEQ && LO) ? p.offA[0][0] + ((PERM && t >= nka) ? p.d8 : 0) : p.offA[h][j];
-      if (LO) asm volatile("" : "+v"(o));               // keeps the 64-bit address arithmetic at the use (it was hoisted out of the two K loops and spilled)
-      const uint32_t u = (SEQ && LO) ? (uint32_t)(PAIR ? h * a.pair_rows + j * 64 : h * 64 + j * 128) * (uint32_t)KA : 0u;
-      MB_GLDS16_AUX((t < nka ? a.A : Alo) + u + o + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
+      // (a "compressed" plan -- one per-lane offset + uniform row steps instead of this table of four, 6-11 VGPRs less -- measured 3.5 % slower in the
+      // pair mini-tile kernels and equal in the plain ones, round 5: the address arithmetic lands in the [L] phases)
+      MB_GLDS16_AUX((t < nka ? a.A : Alo) + p.offA[h][j] + (t < nka ? t : t - nka) * 64, buf + dstA[j], AUX);
     }
   };
   auto dma_b = [&](const Plan& p, int t, int h) {
@@ -246,10 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     char* buf = smem + (t & 1) * PAR_BYTES + 2 * AH_BYTES + h * BH_BYTES;
 #pragma unroll
     for (int j = 0; j < (QN ? 1 : 2); ++j) {
-      uint32_t o = (SEQ && LO) ? p.offB[0][0] + ((PERM && t >= nkw) ? p.d8 : 0) : p.offB[h][j];
-      if (LO) asm volatile("" : "+v"(o));
-      const uint32_t u = (SEQ && LO) ? (uint32_t)(h * 32 + j * 128) * (uint32_t)KW : 0u;
-      MB_GLDS16_AUX((t < nkw ? a.W : Wlo) + u + o + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
+      MB_GLDS16_AUX((t < nkw ? a.W : Wlo) + p.offB[h][j] + (t < nkw ? t : t - nkw) * 64, buf + dstB[j], AUX);
     }
   };
   // ---- mini-tiles (XP = 6).  nmk per operand set / row half; mini j: set or half ps = j / nmk, K-elements [128 jj, 128 jj + 128), jj = j % nmk.
@@ -311,9 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 
   // ---- fragment read offsets inside a half-tile (rows 128 B, slot swizzled with (row>>1)&7)
   int foff[2], xoffe[2];
-  // F8 kernels: xoffe[ks] == foff[ks] + xadd (lane row 0's foff is its slot offset), one VGPR less.  PAIR: lane row 1 reads X row 1 (the
-  // class row's difference operand): foff of lane row 1 = 128 + slot offset = its X-row offset as well
-  const int xadd = (l15 == 0 || (PAIR && l15 == 1)) ? 2 * AH_BYTES + 2 * BH_BYTES : 0;
+  // PAIR: lane row 1 reads X row 1 (the class row's difference operand): foff of lane row 1 = 128 + slot offset = its X-row offset as well
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     foff[ks] = l15 * 128 + (((ks * 4 + g) ^ MB_SWZ(l15)) * 16);
@@ -321,21 +274,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     // A-fragment addresses instead of the X buffer -- 16 lanes on the 8 X rows was a 2-way bank conflict on every read
     xoffe[ks] = (l15 == 0 || (PAIR && l15 == 1)) ? 2 * AH_BYTES + 2 * BH_BYTES + foff[ks] : foff[ks];
   }
-  // e4m3 K-tile of 128: lane group g owns K bytes 32g .. 32g+31 of its row = slots 2g and 2g+1 (tools/micro/mfma_f8_probe.hip); the F8
-  // kernels recompute their fragment offsets per K-tile instead of holding a second set in registers
-  // E8M0 scales of the e4m3 pass (products * 2^-(LO8_EXP + w8_exp)), both in ONE VGPR: byte 0 = the weights' scale, byte 1 = the
-  // activations' (the instruction's op_sel picks the byte)
-  int sc_ab = ((127 - LO8_EXP) << 8) | 127;
-  if (F8) sc_ab = ((127 - LO8_EXP) << 8) | ((127 - *a.w8_exp) & 0xff);
-  // Both scales live in VGPRs of their own for the whole kernel (opaque here, used again after every K-tile): a rematerialised copy
-  // was allocated INSIDE the destination registers of the class-row v_mfma_scale (dst v[78:81], scales v79 / v78) and produced garbage.
-  if (F8) asm volatile("" : "+v"(sc_ab));
-  // MX-fp4 pass: per-lane E8M0 scale bytes of this tile's rows -- wsc: the 4 weight rows (n-tiles) of this lane, xsc0 / xsc1: the 4 + 4 token rows
-  // (m-tiles of the two A halves), xscc: the class-token row.  Loaded once per tile by plain loads that complete under the prologue's wait.
-  int wsc = 0, xsc0 = 0, xsc1 = 0, xscc = 0;
-  int xs_cur[5] = {}, xs_nxt[5] = {};       // BS: block scales of this lane's 4 conditional m-tiles + the class row, current / next lo K-tile
-  uint32_t bs_off[5] = {};                  // BS: byte offsets of those rows' scale records
-  const int bs_shift = (g >> 1) * 8;        // BS: lane groups 0,1 read the first 64 K-elements of a k-step, 2,3 the second
   const int xbase = wm * (8 * MT) * 128;              // this wave's rows inside an A half-tile
   const int wbase = 2 * AH_BYTES + wn * 32 * 128;     // this wave's rows inside a B half-tile (from the parity base)
 
@@ -349,21 +287,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   __builtin_amdgcn_s_barrier();                         \
   __builtin_amdgcn_sched_barrier(0);                    \
   __builtin_amdgcn_s_setprio(1);
-  // one 16x16 output tile x one K-tile: two f16 MFMAs of K = 32, or (e4m3 K-tile) one scaled MFMA of K = 128 over the same 2 x 16 bytes per lane
+  // one 16x16 output tile x one K-tile: two f16 MFMAs of K = 32
   auto frag_set = [](h16x16 f, h16x8 v, int ks) -> h16x16 {
     return ks == 0 ? __builtin_shufflevector(__builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7), f, 0, 1, 2, 3, 4, 5, 6, 7, 24, 25, 26, 27, 28, 29, 30, 31)
                    : __builtin_shufflevector(f, __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23);
   };
-  auto mma_tile = [&](f32x4 c, const h16x16& w, const h16x16& x, bool f8t) -> f32x4 {
-    if (F8 && f8t) return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8, w), __builtin_bit_cast(i32x8, x), c, 0, 0, 0, sc_ab, 1, sc_ab);
+  auto mma_tile = [&](f32x4 c, const h16x16& w, const h16x16& x) -> f32x4 {
     c = MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(x, x, 0, 1, 2, 3, 4, 5, 6, 7), c);
     return MB_MFMA_16x16x32(__builtin_shufflevector(w, w, 8, 9, 10, 11, 12, 13, 14, 15), __builtin_shufflevector(x, x, 8, 9, 10, 11, 12, 13, 14, 15), c);
   };
-#define MB_F4_ONE(AH, BH, I, N)                                                                     \
-  if constexpr (BS) acc[(BH) * 2 + (N)][(AH) * MH + (I)] =                                          \
-      mma_f4bs<(BH) * 2 + (N)>(acc[(BH) * 2 + (N)][(AH) * MH + (I)], wb[BH][N], xa[I], wsc, xs_cur[I]);  \
-  else if constexpr (F4) acc[(BH) * 2 + (N)][(AH) * MH + (I)] =                                     \
-      mma_f4<(BH) * 2 + (N), (I)>(acc[(BH) * 2 + (N)][(AH) * MH + (I)], wb[BH][N], xa[I], wsc, (AH) ? xsc1 : xsc0);
 #define MB_MMA_END                                                                                  \
   __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -391,75 +323,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     asm volatile("" : "+v"(acc[n][(AH) * MH + i]));
 #define MB_MMA_DO(AH, BH)                                                                           \
   {                                                                                                 \
-    if (F4 && f8t) {                                                                                \
-      MB_F4_ONE(AH, BH, 0, 0) MB_F4_ONE(AH, BH, 0, 1) MB_F4_ONE(AH, BH, 1, 0) MB_F4_ONE(AH, BH, 1, 1)  \
-      MB_F4_ONE(AH, BH, 2, 0) MB_F4_ONE(AH, BH, 2, 1) MB_F4_ONE(AH, BH, 3, 0) MB_F4_ONE(AH, BH, 3, 1)  \
-      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
-        asm volatile("" : "+v"(acc[(BH) * 2 + n][(AH) * MH + i]));                                  \
-    } else if (F8 && f8t) {                                                                         \
-      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
-        acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], true);  \
-      /* pin: left alone, the compiler sank all 32 scaled MFMAs of a K-tile below the phase barriers into one burst at the loop end */ \
-      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < 2; ++n)  \
-        asm volatile("" : "+v"(acc[(BH) * 2 + n][(AH) * MH + i]));                                  \
-    } else {                                                                                        \
-      _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < (QN ? 1 : 2); ++n)  \
-        acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i], false); \
-    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int n = 0; n < (QN ? 1 : 2); ++n)  \
+      acc[(BH) * 2 + n][(AH) * MH + i] = mma_tile(acc[(BH) * 2 + n][(AH) * MH + i], wb[BH][n], xa[i]); \
   }
 
   Plan cur;
   int vb = blockIdx.x;
   make_plan(vb, cur);
-  uint32_t sb[8] = {};                                 // F4: raw scale bytes of this lane's 8 token rows
   auto scales_load = [&](const Plan& p) {             // plain loads; scales_pack() after a vmcnt(0) that the loaded registers are tied through
     int lo_ = lane; asm volatile("" : "+v"(lo_));
     const int r15 = lo_ & 15;
-    if constexpr (MINI) {
-      mwsc0 = ((const int*)a.lo[0].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
-      if (PAIR && a.nlo > 1) mwsc1 = ((const int*)a.lo[1].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
-      mxs = *(const int*)(a.lo[0].a_scale + mini_scale_off(p, 0));
-      return;
-    }
-    wsc = ((const int*)a.w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
-    if (BS) {
-      const uint32_t nb = (uint32_t)(a.kw >> 6);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bs_off[i] = (uint32_t)(p.m0 + wm * 64 + i * 16 + r15) * nb;
-      bs_off[4] = (uint32_t)p.cls * nb;            // (lane row 1 of the class m-tile = the difference row: takes no part in the lo pass)
-    } else if (PAIR) {
-      const uint8_t* sp = a.a_scale + p.m0 + wm * 64 + r15;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sb[i] = sp[(i >> 2) * a.pair_rows + (i & 3) * 16];
-      xscc = a.a_scale[p.cls + (r15 == 1 ? a.pair_rows : 0)];
-    } else {
-      const uint8_t* sp = a.a_scale + p.m0 + wm * (16 * MT) + r15;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sb[i] = sp[min((i >> 2) * (8 * MT) + (i & 3) * 16, a.M - 1 - (p.m0 + wm * (16 * MT) + r15))];   // rows past M (ragged last tile) re-read row M-1
-      if (SEQ) xscc = a.a_scale[p.m0 + 256];
-    }
-  };
-  // BS: request the 4 block scales of lo K-tile kt for this lane's rows (inline asm: counted by the K loop's own vmcnt waits, which the registers are tied through)
-  auto bs_issue = [&](int kt) {
-#ifdef MB_BS_NOLOAD                                      // experiment (timing only): no block-scale loads in the lo K-tiles
-    return;
-#endif
-    const uint8_t* base = a.a_scale + 4 * kt;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) asm volatile("global_load_dword %0, %1, %2" : "=v"(xs_nxt[i]) : "v"(bs_off[i]), "s"(base) : "memory");
+    mwsc0 = ((const int*)a.lo[0].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
+    if (PAIR && a.nlo > 1) mwsc1 = ((const int*)a.lo[1].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
+    mxs = *(const int*)(a.lo[0].a_scale + mini_scale_off(p, 0));
   };
   auto scales_pack = [&]() {
     if constexpr (MINI && PAIR) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwsc0), "+v"(mwsc1), "+v"(mxs) :: "memory"); asm volatile("" : "+v"(mwsc0), "+v"(mwsc1)); return; }
     if constexpr (MINI) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwsc0), "+v"(mxs) :: "memory"); asm volatile("" : "+v"(mwsc0)); return; }
-    if (BS) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc) :: "memory"); asm volatile("" : "+v"(wsc)); return; }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsc), "+v"(xscc), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]) :: "memory");
-    xsc0 = sb[0] | (sb[1] << 8) | (sb[2] << 16) | (sb[3] << 24);
-    xsc1 = sb[4] | (sb[5] << 8) | (sb[6] << 16) | (sb[7] << 24);
-    asm volatile("" : "+v"(wsc), "+v"(xsc0), "+v"(xsc1), "+v"(xscc));   // held in VGPRs of their own through the K loops (cf. sc_ab)
   };
-  if constexpr (F4 || MINI) scales_load(cur);
+  if constexpr (MINI) scales_load(cur);
   prologue(cur);
-  if constexpr (F4 || MINI) scales_pack();
+  if constexpr (MINI) scales_pack();
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // K-tiles 0 and 1 of the first tile are in LDS for everyone
 
@@ -502,84 +386,47 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #else
 #define MB_MINI_X_MMA(...) __VA_ARGS__
 #endif
-#define MB_KTILE(F8T) MB_KTILE_(F8T, 0)
-#define MB_KTILE_(F8T, MAH)         /* MAH: plain tiles with mini-tiles: the accumulator half this K loop's mini-tiles update (compile time) */ \
+#define MB_KTILE MB_KTILE_(0)
+#define MB_KTILE_(MAH)              /* MAH: plain tiles with mini-tiles: the accumulator half this K loop's mini-tiles update (compile time) */ \
     {                                                                                                    \
       const char* par = smem + (t & 1) * PAR_BYTES; \
-      constexpr bool f8t = LO && (F8T);                 /* this K-tile holds e4m3 / fp4 operands */ \
       int fo[2], xo[2]; \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
-        if (F8 && !PERM) { \
-          int lo_ = lane; \
-          asm volatile("" : "+v"(lo_));                  /* opaque: keeps this arithmetic inside the loop (VGPR budget) */ \
-          const int r15 = lo_ & 15, gg = lo_ >> 4, sl = f8t ? 2 * gg + ks : ks * 4 + gg; \
-          fo[ks] = r15 * 128 + ((sl ^ MB_SWZ(r15)) * 16); \
-          xo[ks] = r15 == 0 ? 2 * AH_BYTES + 2 * BH_BYTES + sl * 16 : fo[ks]; \
-        } else { fo[ks] = foff[ks]; xo[ks] = LO ? foff[ks] + xadd : xoffe[ks]; } \
-      } \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { fo[ks] = foff[ks]; xo[ks] = xoffe[ks]; } \
       /* DMA issue is placed where the read phase is short (a global_load_lds blocks the issuing wave until the address unit takes */ \
       /* it): none in phase 0 (12 fragment reads), A1(t+1) in phase 1, A0(t+2) in phase 2, B1, X and B0 of K-tile t+2 in phase 3 */ \
       /* (no reads).  Every half-tile is re-filled >= 2 phases after its last reader; K-tile 1 came with the prologue. */ \
       const bool n1 = t >= 1 && t + 1 < nk, n2 = t + 2 < nk; \
-      if (BS && f8t) {                                     /* landed under the previous K-tile's counted wait */ \
-        _Pragma("unroll") for (int i = 0; i < 5; ++i) xs_cur[i] = (int)((uint32_t)xs_nxt[i] >> bs_shift); \
-        if (l15 != 0) xs_cur[4] = 0;                       /* class m-tile: only lane row 0 (the conditional class row) takes part; scale 2^-127 silences the rest */ \
-      } \
-      if (BS && t + 1 >= nka && t + 1 < nk) bs_issue(t + 1 - nka); \
       /* ---- phase 0: quadrant (A0, B0) [+ class row x B0 for wave row 0] */ \
       MB_LOAD_B(0) MB_LOAD_A(0)                          /* B first: the first MFMAs need both B fragments and only xa[0] */ \
       h16x16 xe; \
       if (SEQ && wm == 0 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       MB_SYNC_L() \
-      if (SEQ && wm == 0 && cls_on) { \
-        if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<0>(acce[0], wb[0][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<1>(acce[1], wb[0][1], xe, wsc, xs_cur[4]); } } \
-        else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<0, 0>(acce[0], wb[0][0], xe, wsc, xscc); acce[1] = mma_f4<1, 0>(acce[1], wb[0][1], xe, wsc, xscc); } } \
-        else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, true); } \
-        else { _Pragma("unroll") for (int n = 0; n < (QN ? 1 : 2); ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe, false); } \
-        /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
-        /* cover this pair here): pad before the register moves that end this block */ \
-        if (f8t) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
-      } \
+      if (SEQ && wm == 0 && cls_on) { _Pragma("unroll") for (int n = 0; n < (QN ? 1 : 2); ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe); } \
       MB_MMA(0, 0) \
       /* ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1 */ \
       if constexpr (!HN) { MB_LOAD_B(1) } \
       if (!HN && SEQ && wm == 1 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
-      /* PAIR: the difference rows (A1) take no part in the lo pass (their scale byte is 0): lo K-tiles neither stage nor multiply them */ \
       /* MINI: the next mini-tile's scale dword and A part go out first (older than everything the phase-3 wait leaves in flight) */ \
       const bool mini_issue = MINI && t >= 1 && (mini_every || !(t & 1)); \
       const int mini_j = mini_every ? t : (t >> 1); \
       if (MINI && mini_issue) { mini_scale_issue(cur, mini_j); MB_MINI_X_DMA(mini_dma_a(cur, mini_j);) } \
-      if (n1 && !(PAIR && LO && t + 1 >= nka)) dma_a(cur, t + 1, 1); \
+      if (n1) dma_a(cur, t + 1, 1); \
       MB_SYNC_L() \
-      if (!HN && SEQ && wm == 1 && cls_on) { \
-        if (BS && f8t) { if constexpr (BS) { acce[0] = mma_f4bs<2>(acce[0], wb[1][0], xe, wsc, xs_cur[4]); acce[1] = mma_f4bs<3>(acce[1], wb[1][1], xe, wsc, xs_cur[4]); } } \
-        else if (F4 && f8t) { if constexpr (F4) { acce[0] = mma_f4<2, 0>(acce[0], wb[1][0], xe, wsc, xscc); acce[1] = mma_f4<3, 0>(acce[1], wb[1][1], xe, wsc, xscc); } } \
-        else if (F8 && f8t) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, true); } \
-        else { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe, false); } \
-        /* v_mfma_scale_f32_16x16x128 results read by a VALU copy too early came back half-written (the compiler's hazard table does not */ \
-        /* cover this pair here): pad before the register moves that end this block */ \
-        if (f8t) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
-      } \
+      if (!HN && SEQ && wm == 1 && cls_on) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe); } \
       if constexpr (!HN) { MB_MMA_DO(0, 1) } MB_MMA_END \
       /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
-      if (!(PAIR && f8t)) { MB_LOAD_A(1) } \
+      MB_LOAD_A(1) \
       if (MINI && mini_issue) { MB_MINI_X_DMA(mini_dma_b(cur, mini_j);) } \
       if (n2) dma_a(cur, t + 2, 0); \
-      MB_SYNC_L() if (!HN && !(PAIR && f8t)) { MB_MMA_DO(1, 1) } MB_MMA_END \
+      MB_SYNC_L() if (!HN) { MB_MMA_DO(1, 1) } MB_MMA_END \
       /* ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed. */ \
       /* In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output */ \
       /* stores stay in flight until the wait of K-tile 1. */ \
       if (n2) { dma_b(cur, t + 2, 1); dma_x(cur, t + 2); dma_b(cur, t + 2, 0); } \
       if (t >= 1) { \
-        if (BS) {                                        /* the next lo K-tile's block scales (requested in phase 0) are older than those: tied through. */ \
-          /* ONE asm statement for the three cases: with one statement per case the compiler copied the still-in-flight registers to their */ \
-          /* loop-carried homes AHEAD of two of the waits (v_mov ... ; s_waitcnt) -- stale block scales whenever the loads were slow */ \
-          const int wsel = __builtin_amdgcn_readfirstlane(n2 ? (wave == 7 ? 2 : 1) : 0); \
-          asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(7)\n\ts_branch 3f\n" \
-                       "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(6)\n3:" \
-                       : "+v"(xs_nxt[0]), "+v"(xs_nxt[1]), "+v"(xs_nxt[2]), "+v"(xs_nxt[3]), "+v"(xs_nxt[4]) : [w] "s"(wsel) : "memory", "scc"); \
-        } else if (MINI) {                               /* the mini-tile's scale dword (requested in phase 1) is older than those: tied through, */ \
-          /* ONE asm statement for the three cases (see the block-scale wait above) */ \
+        if (MINI) {                               /* the mini-tile's scale dword (requested in phase 1) is older than those: tied through, */ \
+          /* ONE asm statement for the three cases: with one statement per case the compiler copied the still-in-flight register to its */ \
+          /* loop-carried home AHEAD of two of the waits (v_mov ... ; s_waitcnt) -- a stale scale whenever the load was slow (round 2) */ \
           const int wsel = __builtin_amdgcn_readfirstlane(n2 ? (wave == 7 ? 2 : 1) : 0); \
           if constexpr (QN)                              /* (quarter-column tiles: A0, (X,) B0 of K-tile t+2 stay in flight: 3 / 4 instructions) */ \
             asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(4)\n\ts_branch 3f\n" \
@@ -598,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
       } \
-      MB_SYNC_L() if (!(PAIR && f8t)) { MB_MMA_DO(1, 0) } MB_MMA_END \
+      MB_SYNC_L() MB_MMA_DO(1, 0) MB_MMA_END \
       /* ---- phase 4 (MINI): the mini-tile that landed under this (or the previous) K-tile's wait x the accumulators of its 128 token rows */ \
       if constexpr (MINI) { \
         if (MB_MINI_PHASE_ON && (mini_every || (t & 1))) { \
@@ -621,18 +468,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         } \
         if constexpr (PAIR) asm volatile("" :: "v"(mwsc0), "v"(mwsc1)); else asm volatile("" :: "v"(mwsc0)); \
       } \
-      if (F8) asm volatile("" :: "v"(sc_ab)); \
-      if (F4 && !BS) asm volatile("" :: "v"(wsc), "v"(xsc0), "v"(xsc1), "v"(xscc)); \
-      if (BS) asm volatile("" :: "v"(wsc)); \
     }
     {
       int t = 0;
       if constexpr (MINI && !PAIR) {        // plain tiles: mini-tile t belongs to K-tile t; the first K / 128 update rows 0..127 of the tile, the others rows 128..255
-        for (; t < nk / 2; ++t) MB_KTILE_(false, 0)
-        for (; t < nk; ++t) MB_KTILE_(false, 1)
+        for (; t < nk / 2; ++t) MB_KTILE_(0)
+        for (; t < nk; ++t) MB_KTILE_(1)
       } else {
-        for (; t < (LO ? nka : nk); ++t) MB_KTILE(false)
-        if (LO) for (; t < nk; ++t) MB_KTILE(true)
+        for (; t < nk; ++t) MB_KTILE
       }
     }
 #undef MB_KTILE
@@ -649,7 +492,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int m0 = cur.m0, n0 = cur.n0, clsrow = cur.cls, tq = cur.q;
     constexpr int NROWS = SEQ ? MT + 1 : MT;
     int l15e = l15, ge = g;                              // opaque copies (see make_plan): no per-row address tables
-    if (LO) { int lo_ = lane; asm volatile("" : "+v"(lo_)); l15e = lo_ & 15; ge = lo_ >> 4; }   // (recomputed: l15 / g need not live through the K loops)
     asm volatile("" : "+v"(l15e), "+v"(ge));             // carried in VGPRs through the main loop
     auto row_of = [&](int r) {
       if (PAIR) return r < MT ? m0 + (r / MH) * a.pair_rows + wm * 64 + (r % MH) * 16 + l15e : clsrow + (l15e == 1 ? a.pair_rows : 0);
@@ -672,17 +514,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     Plan nxt;
     if (has_next) { make_plan(nvb, nxt); dma_x(nxt, 0); dma_x(nxt, 1); }
     f32x4 bias4[4], bcls[2];           // bcls: class-token row (indexing bias4 by wave id would put the array in scratch)
-    if constexpr (LO || MINI) {
-      // The e4m3 kernels run at the 256-VGPR limit, where the allocator may move registers around: an asm load whose result it does
+    if constexpr (MINI) {
+      // The mini-tile kernels run at the 256-VGPR limit, where the allocator may move registers around: an asm load whose result it does
       // not track could be copied while still in flight.  Plain loads here (the compiler waits for them; the overlap with the next
-      // tile's prologue DMA is given up in this mode).
+      // tile's prologue DMA is given up in this mode: <= 0.6 us per tile, profiles/r04_gemm_minitiles.md section 9).
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bias4[nt] = *(const f32x4*)(a.bias + col_of(0, nt));
       if (SEQ) { bcls[0] = *(const f32x4*)(a.bias + col_of(MT, 0)); bcls[1] = *(const f32x4*)(a.bias + col_of(MT, 1)); }
       else { bcls[0] = bias4[0]; bcls[1] = bias4[1]; }
-      if constexpr (F4 || MINI) { if (has_next) scales_load(nxt); }          // this tile's K loops are over: the scale registers are free
+      if (has_next) scales_load(nxt);                                        // this tile's K loops are over: the scale registers are free
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]), "+v"(bcls[0]), "+v"(bcls[1]) :: "memory");
-      if constexpr (F4 || MINI) { if (has_next) scales_pack(); }
+      if (has_next) scales_pack();
       if (has_next) { prologue_rest(nxt); if constexpr (MINI) { mini_dma_a(nxt, 0); mini_dma_b(nxt, 0); } }
     } else {
 #define MB_LDG16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
@@ -737,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         acce[n] = l15e == 1 ? dl : c;
       }
     } else {
-      const float osc = a.scale ? *a.scale : 1.0f;          // split weights: undo their power-of-two pre-scale
+      const float osc = a.scale ? *a.scale : 1.0f;          // (pre-scaled weights: undo their power of two)
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
         const int nn = r < MT ? NTW : (QN ? 1 : 2);
@@ -812,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       // made every wait for a residual row also wait for the ACKNOWLEDGEMENT of the store two rows back (tools/micro/store_path.hip: 19 us per tile
       // interleaved, 15 / 12 / 9 us with 4 / 8 / 16 loads batched ahead of their stores).  Now: batches of two rows, the next batch's loads issued
       // BEFORE the current batch's stores: 22.8 -> 19.5 us per tile.
-      constexpr int RB = (PAIR && (F4 || MINI)) ? 1 : 2;        // rows per batch: 4 float4 per lane -- what fits next to 136 accumulator registers without spilling (2 in the fp4 pair kernel)
+      constexpr int RB = (PAIR && MINI) ? 1 : 2;        // rows per batch: 4 float4 per lane -- what fits next to 136 accumulator registers without spilling (2 in the fp4 pair kernel)
       // (Measured with larger / growing batches -- 4 rows, or 2 + 2 + 4 rows then a whole sweep into the registers the first sweep vacated: 16-42 spilled
       // VGPRs in the pair kernels and no gain in the kernels that did not spill: with every CU in its epilogue at once the pass runs at the chip's
       // ~6.5-6.9 TB/s of mixed read + write traffic, profiles/r03_power_and_streams.md section 6.)
@@ -918,17 +760,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             const int n = col_of(r, 2 * pr + (ge & 1)) - (ge & 1) * 4;
             const size_t ob = (size_t)(((uint32_t)row_of(r) * (uint32_t)a.N + (uint32_t)n) * 2u);
             if (ok) *(uint4*)((char*)out16 + ob) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-            if (a.out_lo) {                                // split activations for the consumer: the lo halves c - fp16(c), same layout
-              const h16x2 la0 = {to_h(ca[0] - (float)ta0[0]), to_h(ca[1] - (float)ta0[1])}, la1 = {to_h(ca[2] - (float)ta1[0]), to_h(ca[3] - (float)ta1[1])};
-              const h16x2 lb0 = {to_h(cb[0] - (float)tb0[0]), to_h(cb[1] - (float)tb0[1])}, lb1 = {to_h(cb[2] - (float)tb1[0]), to_h(cb[3] - (float)tb1[1])};
-              const auto l0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, la0), __builtin_bit_cast(uint32_t, lb0), false, false);
-              const auto l1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, la1), __builtin_bit_cast(uint32_t, lb1), false, false);
-              if (ok) *(uint4*)((char*)a.out_lo + ob) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
-            }
-            if (a.out_lo8) {                               // e4m3 lo halves: 4 columns per dword, the swap gives a lane its 8 columns (row stride 2N bytes)
-              const auto q = __builtin_amdgcn_permlane16_swap(lo8_pack4(ca[0], ca[1], ca[2], ca[3]), lo8_pack4(cb[0], cb[1], cb[2], cb[3]), false, false);
-              if (ok) *(uint2*)(a.out_lo8 + (size_t)((uint32_t)row_of(r) * (uint32_t)a.N * 2u + (uint32_t)n)) = make_uint2(q[0], q[1]);
-            }
           }
         } else if (ok) {
 #pragma unroll
@@ -960,7 +791,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #undef MB_MMA
 #undef MB_MMA_DO
 #undef MB_MMA_END
-#undef MB_F4_ONE
 #undef MB_MINI_ONE
 #undef MB_MINI_MMA
 #undef MB_MINI_MMA_HN
@@ -996,27 +826,23 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
   }
   const int sq_rows = a.seq_rows ? a.seq_rows : 257;
   const int tiles_m = PAIR ? (a.pair_rows / sq_rows) * ((sq_rows - 1) / 128) : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * NS;
-  static const bool f4_persist = !getenv("MASKBIT_AMD_F4_PERSIST") || atoi(getenv("MASKBIT_AMD_F4_PERSIST")) != 0;   // A/B switch (experiments)
   static const bool res_persist = !getenv("MASKBIT_AMD_RES_PERSIST") || atoi(getenv("MASKBIT_AMD_RES_PERSIST")) != 0;   // A/B switch (experiments)
-  if (XP == 5 && !f4_persist) persistent = false;
   if (EPI == EPI_RES_F32 && !res_persist) persistent = false;
-  const int grid = (XP != 4 && persistent) ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
+  const int grid = persistent ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
   hipLaunchKernelGGL((gemm_ht_kernel<MT, EPI, XP, SEQ, PAIR, NS>), dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n);
 }
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
-  if (a.A8 && (!a.W8 || !a.w8_exp || a.kw % 128 || a.K != a.kw + a.kw / 2 || epi == EPI_GELU_F32)) return false;
   const int sqr = a.seq_rows ? a.seq_rows : 257;
   if (a.seq_rows && (!a.pair_rows || (sqr - 1) % 128 || ((sqr - 1) / 128 & ((sqr - 1) / 128 - 1)))) return false;   // pair tiles only; 128-token tiles, a power of two per sequence
-  if (a.pair_rows && (a.pair_rows % sqr || a.M != 2 * a.pair_rows || a.A8 || a.A2 || (a.ka && a.A4) || a.out_lo || a.out_lo8 || epi == EPI_GELU_F32)) return false;
+  if (a.pair_rows && (a.pair_rows % sqr || a.M != 2 * a.pair_rows || a.A2 || epi == EPI_GELU_F32)) return false;
   // (plain tiles may combine the mini-tiles with split activations: A2 / kw, K = 2 kw -- hi + lo LayerNorm outputs AND the weight correction)
-  if (a.nlo && (a.nlo > 2 || (a.pair_rows ? a.pair_rows % sqr : a.M % 257) || (a.kw ? a.kw : a.K) % 128 || a.A8 || a.A4 || a.ka || a.out_lo || a.out_lo8 || (!a.pair_rows && a.nlo != 1) ||
+  if (a.nlo && (a.nlo > 2 || (a.pair_rows ? a.pair_rows % sqr : a.M % 257) || (a.kw ? a.kw : a.K) % 128 || (!a.pair_rows && a.nlo != 1) ||
                 ((a.A2 || a.kw) && (a.pair_rows || !a.A2 || a.K != 2 * a.kw)) ||
                 !a.lo[0].A4 || !a.lo[0].W4 || !a.lo[0].a_scale || !a.lo[0].w_scale ||
                 (a.nlo == 2 && (!a.lo[1].A4 || !a.lo[1].W4 || !a.lo[1].a_scale || !a.lo[1].w_scale)) || (uint64_t)a.M * a.K * 2 >= (1ull << 32) ||
                 epi == EPI_GELU_F32)) return false;
-  if (a.A4 && (a.A8 || !a.W4 || !a.a_scale || !a.w_scale || a.kw % 256 || a.K != a.kw + a.kw / 4 || epi == EPI_GELU_F32)) return false;
-  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.A8 || a.A4 || a.nlo) &&
+  return epi != EPI_LOGITS_F32 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.M >= 512 || a.nlo) &&
          (uint64_t)a.M * a.K < (1ull << 32) && (uint64_t)a.N * a.K < (1ull << 32) &&
          (uint64_t)a.M * a.N * 4 < (1ull << 32);      // 32-bit element / byte offsets inside the kernel
 }
@@ -1052,31 +878,11 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
     }
     return;
   }
-  if (a.pair_rows) {                                                       // CFG pair tiles (sequence-aligned; fp16, or fp16 + MX-fp4 lo pass)
+  if (a.pair_rows) {                                                       // CFG pair tiles (sequence-aligned, fp16 K-tiles only)
     switch (epi) {
-      case EPI_H16: if (a.A4) launch_ht<8, EPI_H16, 5, true, true>(s, a, persistent); else launch_ht<8, EPI_H16, 0, true, true>(s, a, persistent); break;
-      case EPI_GELU_H16: if (a.A4) launch_ht<8, EPI_GELU_H16, 5, true, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 0, true, true>(s, a, persistent); break;
-      case EPI_RES_F32: if (a.A4) launch_ht<8, EPI_RES_F32, 5, true, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 0, true, true>(s, a, persistent); break;
-      default: break;
-    }
-    return;
-  }
-  if (a.A4) {                                                              // MX-fp4 lo pass (XP = 5 instantiations)
-    const bool seq = a.M % 257 == 0 && mt != 8;
-    switch (epi) {
-      case EPI_H16: if (seq) launch_ht<8, EPI_H16, 5, true>(s, a, persistent); else launch_ht<8, EPI_H16, 5>(s, a, persistent); break;
-      case EPI_GELU_H16: if (seq) launch_ht<8, EPI_GELU_H16, 5, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 5>(s, a, persistent); break;
-      case EPI_RES_F32: if (seq) launch_ht<8, EPI_RES_F32, 5, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 5>(s, a, persistent); break;
-      default: break;
-    }
-    return;
-  }
-  if (a.A8) {                                                              // e4m3 lo pass (XP = 4 instantiations)
-    const bool seq = a.M % 257 == 0 && mt != 8;
-    switch (epi) {
-      case EPI_H16: if (seq) launch_ht<8, EPI_H16, 4, true>(s, a, persistent); else launch_ht<8, EPI_H16, 4>(s, a, persistent); break;
-      case EPI_GELU_H16: if (seq) launch_ht<8, EPI_GELU_H16, 4, true>(s, a, persistent); else launch_ht<8, EPI_GELU_H16, 4>(s, a, persistent); break;
-      case EPI_RES_F32: if (seq) launch_ht<8, EPI_RES_F32, 4, true>(s, a, persistent); else launch_ht<8, EPI_RES_F32, 4>(s, a, persistent); break;
+      case EPI_H16: launch_ht<8, EPI_H16, 0, true, true>(s, a, persistent); break;
+      case EPI_GELU_H16: launch_ht<8, EPI_GELU_H16, 0, true, true>(s, a, persistent); break;
+      case EPI_RES_F32: launch_ht<8, EPI_RES_F32, 0, true, true>(s, a, persistent); break;
       default: break;
     }
     return;

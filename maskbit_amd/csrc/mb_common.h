@@ -97,20 +97,7 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x}).x; }
 
-// e4m3 "lo halves" for the strict-parity mode's fp8 correction pass: e4m3((v - fp16(v)) * 2^12) (LO8_EXP in mb_kernels.h; clamped to +-448), four per dword (byte i = column i)
-__device__ __forceinline__ uint32_t lo8_pack4h(float v0, float v1, float v2, float v3, h16x4 hi) {   // hi = the fp16 halves already computed by the caller
-  const float s = 4096.0f;
-  const float l0 = __builtin_amdgcn_fmed3f((v0 - (float)hi[0]) * s, -448.0f, 448.0f), l1 = __builtin_amdgcn_fmed3f((v1 - (float)hi[1]) * s, -448.0f, 448.0f);
-  const float l2 = __builtin_amdgcn_fmed3f((v2 - (float)hi[2]) * s, -448.0f, 448.0f), l3 = __builtin_amdgcn_fmed3f((v3 - (float)hi[3]) * s, -448.0f, 448.0f);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(l2, l3, w, true);
-  return (uint32_t)w;
-}
-__device__ __forceinline__ uint32_t lo8_pack4(float v0, float v1, float v2, float v3) {
-  return lo8_pack4h(v0, v1, v2, v3, h16x4{to_h(v0), to_h(v1), to_h(v2), to_h(v3)});
-}
-
-// MX-fp4 (e2m1) "lo halves" for the strict mode's 4-bit correction pass.  A block of lo values (one LayerNorm row, or 64 columns of an
+// MX-fp4 (e2m1) operands of the mini-tile correction passes (gemm_ht.hip).  A block of lo values (one LayerNorm row, or 64 columns of an
 // attention / GELU output row) shares one power-of-two scale chosen from the block's largest |lo|: v = lo * 2^s with 4 <= max|v| < 8,
 // i.e. s = 129 - biased_exponent(max|lo|); values in [5, 8) saturate to 6 (measured residual 1.7-2.5 % of the lo variance on Gaussian,
 // GELU and heavy-tailed rows, DESIGN.md "Precision").  The MFMA's E8M0 scale byte that undoes 2^s is 127 - s = biased_exponent - 2.

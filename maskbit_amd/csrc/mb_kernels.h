@@ -12,9 +12,6 @@ enum GemmEpi {
   EPI_GELU_F32 = 3,     // f32 out  = gelu_erf(acc + bias)            (last_layer.0)
   EPI_LOGITS_F32 = 4,   // f32 out, rows with (m % period)==period-1 dropped, rest compacted (head)
 };
-// lo halves are <= 2^-11 |x|: scaled by 2^12 they are <= 2 |x|, inside e4m3's range (448) for |x| <= 224 and still normal numbers down to
-// |x| ~ 2^-6; larger values are clamped (their correction is then partial), never NaN
-constexpr int LO8_EXP = 12;
 struct GemmArgs {
   const h16* A;        // [M,K] row-major
   const h16* W;        // [N,K] row-major (torch Linear layout)
@@ -24,9 +21,7 @@ struct GemmArgs {
   h16* out_h16;
   int M, N, K;
   int period;           // EPI_LOGITS_F32 only: tokens per sequence incl. the class row
-  // Split-weight ("fp16x2") GEMMs: W rows are [hi(K/2) | lo(K/2)] of a weight pre-scaled by a power of two, A has
-  // ka = K/2 columns and is swept twice, out = acc * (*scale) + bias.  ka = 0 / scale = null: plain GEMM.
-  int ka = 0;
+  // out = acc * (*scale) + bias for weights stored pre-scaled by a power of two (the head GEMMs' hi / lo planes, W2 below); null: 1
   const float* scale = nullptr;
   // EPI_RES_F32 with ln_stats != null: `residual` holds the PRE-LayerNorm rows y; the residual that is added is
   // LayerNorm(y) = (y - mean) * rstd * ln_g + ln_b re-derived from ln_stats[m] = {mean, rstd} (what layernorm_rows
@@ -38,63 +33,39 @@ struct GemmArgs {
   int bias_per_pos = 0;
   // Split-activation ("fp16 hi+lo") GEMMs: A2 = the lo halves x - fp16(x) of the activations whose fp16 hi halves are A, both
   // [M, kw]; W has kw = K/2 columns and is swept twice (K-tiles below K/2 pair A with W, the others A2 with W), so both
-  // products land in the same fp32 accumulator.  A2 = null / kw = 0: plain GEMM.  Not combined with ka.
+  // products land in the same fp32 accumulator.  A2 = null / kw = 0: plain GEMM.
   const h16* A2 = nullptr;
   int kw = 0;
   // ... with W2 != null as well (128x128 kernel only; the two head GEMMs): THREE sweeps of kw columns, K = 3 kw -- (A, W), (A2, W), (A, W2) with
   // W = fp16(w * 2^S), W2 = fp16(w * 2^S - W) [N, kw] each and *scale = 2^-S: hi + lo inputs against hi + lo weights (the lo x lo term, 2^-22, is dropped)
   const h16* W2 = nullptr;
-  // fp16 epilogues only: also store the lo halves v - fp16(v) of the results ([M,N] like out_h16), so that the consumer GEMM can
-  // take this output as a split-activation pair
-  h16* out_lo = nullptr;
-  // e4m3 "lo pass" of a split-activation GEMM (half-tile kernel only): A8 = e4m3(lo * 2^LO8_EXP) of the activations whose hi halves are A,
-  // W8 = e4m3(W * 2^(*w8_exp)); both with the SAME row stride in bytes as their fp16 siblings (2*kw, first kw bytes used).  K-tiles
-  // below kw/64 are fp16 (A, W), the following kw/128 K-tiles are e4m3 tiles of 128 (v_mfma_scale_f32_16x16x128_f8f6f4, the E8M0 scales
-  // undo the two power-of-two factors); K = kw + kw/2.  out_lo8: fp16 epilogues also store e4m3(lo * 2^LO8_EXP) of their results (row
-  // stride 2*N bytes).
-  const uint8_t* A8 = nullptr;
-  const uint8_t* W8 = nullptr;
-  const int* w8_exp = nullptr;
-  uint8_t* out_lo8 = nullptr;
-  // MX-fp4 "lo pass" (half-tile kernel only), the cheaper sibling of the e4m3 one: A4 = e2m1(lo * 2^s) two per byte, W4 = e2m1(W * 2^r), both
-  // with the row stride in bytes of their fp16 siblings (2*kw, first kw/2 used).  K-tiles below kw/64 are fp16 (A, W), the following kw/256
-  // K-tiles hold 256 K-elements per 128-byte row and run on v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = blgp = 4 (two MFMAs of K = 128
-  // per 16x16 tile, the fp16 tiles' fragment reads); K = kw + kw/4.  a_scale[m] = the E8M0 byte undoing row m's 2^s (mb_common.h
-  // fp4_scale_byte), w_scale = the weights' bytes in the lane order of the kernel: entry ((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3).
-  const uint8_t* A4 = nullptr;
-  const uint8_t* W4 = nullptr;
-  const uint8_t* a_scale = nullptr;
-  const uint8_t* w_scale = nullptr;
   // "CFG pair" GEMM (sequence-aligned half-tile kernel only): the M = 2 * pair_rows rows are pair_rows conditional rows followed by their
-  // unconditional twins (whole 257-token sequences); in A the unconditional rows hold the difference operand fp16(x_u - x_c).  Output
+  // unconditional twins (whole sequences); in A the unconditional rows hold the difference operand fp16(x_u - x_c).  Output
   // rows: out_c = f(A_c . W), out_u = f(A_c . W + A_delta . W) -- with the GELU epilogue the unconditional rows receive gelu(u) - gelu(c),
   // i.e. the next GEMM's difference operand.  See gemm_ht.hip and DESIGN.md "Precision".
   int pair_rows = 0;
-  // pair tiles: rows per sequence incl. the class token (0 = 257).  A pair tile is 128 tokens of one sequence pair, so any (seq_rows - 1) % 128 == 0
-  // is served: 257 (256 x 256 images) and 1 025 (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144); the LAST tile of a pair stores the class rows.
+  // pair tiles: rows per sequence incl. the class token (0 = 257).  A pair tile is 128 tokens of one sequence pair, so any (seq_rows - 1) / 128 that is
+  // a power of two is served: 257 (256 x 256 images) and 1 025 (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144); the LAST tile of a pair
+  // stores the class rows.
   int seq_rows = 0;
-  // pair tiles + fp4 pass: a_scale is a_scale[row][kw / 64] (one E8M0 byte per 64 K-elements of a conditional row).  GELU epilogue (pair tiles):
-  // out4 / out4_scale (optional) receive e2m1 of the conditional OUTPUT values (row stride 2N bytes) and their block bytes out4_scale[row][N / 64],
-  // the token operand of the next GEMM's weight-correction pass; class-token rows are left untouched (their bytes stay 0: no correction).
+  // GELU epilogue of sequence-aligned tiles (optional): out4 / out4_scale receive e2m1 of the (conditional) OUTPUT values (row stride 2N bytes) and
+  // their lane-ordered scale bytes -- the token operand of the next GEMM's weight-correction pass; class-token rows are left untouched.
   uint8_t* out4 = nullptr;
   uint8_t* out4_scale = nullptr;
-  // MX-fp4 MINI-TILE correction passes (round 4; sequence-aligned half-tile kernel, M % 257 == 0, K % 128 == 0): the corrections no longer run as
-  // K-tiles of their own behind the fp16 sweep -- those were bound by staging at a quarter of a tile's arithmetic -- but as mini-tiles of
-  // 128 token rows x 256 weight rows x 128 K-elements (24 KiB of LDS behind the two K-tile parities), staged while the fp16 K-tiles run and multiplied
-  // in a fifth phase between them (16 v_mfma_scale_f32_16x16x128_f8f6f4 per wave).  nlo = number of operand sets:
+  // MX-fp4 MINI-TILE correction passes (sequence-aligned half-tile kernel, K % 128 == 0): mini-tiles of 128 token rows x 256 weight rows x 128
+  // K-elements (24 KiB of LDS behind the two K-tile parities), staged while the fp16 K-tiles run and multiplied in a fifth phase between them
+  // (16 v_mfma_scale_f32_16x16x128_f8f6f4 per wave).  nlo = number of operand sets:
   //   pair tiles : lo[0] (, lo[1]) on the CONDITIONAL rows: K / 128 mini-tiles per set (one per two fp16 K-tiles with one set, one per K-tile with two);
-  //   plain tiles: lo[0] on both 128-row halves of the sequence tile (nlo = 1): 2 K / 128 mini-tiles, one per fp16 K-tile.
+  //   plain tiles: lo[0] on both 128-row halves of the 257-row sequence tile (nlo = 1): 2 K / 128 mini-tiles, one per fp16 K-tile.
   // Operands: A4 = e2m1 token operand, two values per byte, row stride 2 K bytes (first K / 2 used); W4 = e2m1 weight operand, mini-tile-packed
-  // (w4_packed_offset; N K / 2 bytes);
-  // w_scale = the weights' E8M0 bytes in the kernel's lane order (entry ((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)); a_scale = the token
-  // operand's E8M0 bytes per (row, 64 K-elements) in LANE ORDER: a_scale[((blk * nseq + seq) * 4 + grp) * 64 + (r & 15) * 4 + ((r >> 4) & 3)] for
-  // token r = grp * 64 + (r & 63) of sequence seq (nseq = M / 257; pair tiles: conditional sequences, nseq = pair_rows / 257) -- one dword per lane
-  // holds the scales of its four m-tiles (fp4_scale_index).  Class-token rows take no part in these passes.
-  // fp16 epilogues (optional): lanes that clamped a result at +-65504 add 1 to *sat (mb_gen_saturation_count)
-  unsigned* sat = nullptr;
+  // (w4_packed_offset; N K / 2 bytes); w_scale = the weights' E8M0 bytes in the kernel's lane order (entry ((n >> 6) * 16 + (n & 15)) * 4 +
+  // ((n >> 4) & 3)); a_scale = the token operand's E8M0 bytes per (row, 64 K-elements) in LANE ORDER (fp4_scale_index: one dword per lane holds the
+  // scales of its four m-tiles).  Class-token rows take no part in these passes.
   struct LoSet { const uint8_t* A4; const uint8_t* a_scale; const uint8_t* W4; const uint8_t* w_scale; };
   LoSet lo[2] = {};
   int nlo = 0;
+  // fp16 epilogues (optional): lanes that stored a value outside fp16's range (or a NaN) add 1 to *sat (mb_gen_saturation_count)
+  unsigned* sat = nullptr;
 };
 // Byte offset of element (row n, K-element k) of an e2m1 WEIGHT operand of the mini-tile passes.  The operand is stored MINI-TILE-PACKED:
 // [N / 16][K / 128] chunks of 1 KiB = 16 rows x 64 B, the 16-byte pieces of a row swizzled with (row >> 1) & 3 -- the LDS image of one DMA
@@ -113,8 +84,6 @@ int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant = 0);   /
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
 void set_cu_count(int n);   // persistent grids are sized for n CUs (0 = the device's count): for launches on CU-masked streams
-// e4m3 copy of a weight (row stride 2K bytes, first K used) for the fp8 correction pass; *exp_out = the power of two it was scaled by
-void w8_from_f32(hipStream_t s, const float* src, uint8_t* dst8, int N, int K, int* exp_out, unsigned* tmp);
 
 // e2m1 copy of a weight for the mini-tile passes: e2m1(fp16(W[n]) * 2^r_n) in the mini-tile-packed layout (w4_packed_offset; N K / 2 bytes), r_n
 // per row chosen to minimise the row's quantisation error; scale_out in the kernel's lane order (GemmArgs.lo w_scale).  N % 16 == 0, K % 128 == 0.
@@ -129,8 +98,8 @@ struct Fp4Rows { uint8_t* x4 = nullptr; uint8_t* x4s = nullptr; uint8_t* xl4 = n
 
 // ---- LayerNorm over rows of y[M,d] -> x_f32 (optional), x_h16 (optional), stats[M][2] = {mean, rstd} (optional) ---
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr, uint8_t* x8 = nullptr,
-                    const Fp4Rows& f4 = Fp4Rows{});   // x8: e4m3(lo * 2^12), row stride 2d bytes (vector path only); x_lo: fp16(x - fp16(x)), optional
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo = nullptr,
+                    const Fp4Rows& f4 = Fp4Rows{});   // x_lo: fp16(x - fp16(x)), optional
 
 // "CFG pair" forms (hidden = 768 / 1024 only; -1 otherwise): rows r < P are conditional, r + P their unconditional twins.  Writes
 // x_h16[r] = fp16(x_c), x_h16[r + P] = fp16(x_u - x_c), both rows' {mean, rstd}; optional f4: e2m1 copies of the CONDITIONAL rows.
@@ -153,7 +122,6 @@ struct EmbedArgs {
   // Bert (modeling/bert.py:313-315): per-group embedding tables [m][2^gbits + 1][d] summed instead of the bit projection
   const float* tables = nullptr;
   h16* x_lo = nullptr;     // optional: lo halves of x_h16 (split-activation GEMMs)
-  uint8_t* x8 = nullptr;   // optional: e4m3 lo halves, row stride 2d bytes
   Fp4Rows f4;              // optional: e2m1 copies for the mini-tile passes (embed_pair: of the conditional rows)
 };
 void embed_ln(hipStream_t s, const EmbedArgs& a);
@@ -164,15 +132,14 @@ int embed_pair(hipStream_t s, const EmbedArgs& a);
 void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /*[cols,rows]*/, int rows, int cols);
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
-void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads, h16* out_lo = nullptr, uint8_t* out_lo8 = nullptr,
-               uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);   // out_lo: optional lo halves (split activations); out4 / out4s (N = 257, head width 64):
-                                                                      // e2m1 of the outputs + lane-ordered scale bytes for the out-proj GEMM's mini-tile pass
-// "CFG pair" attention: sequences [0, P) are conditional, [P, 2P) their unconditional twins.  Two launches: the conditional sequences also
-// store their fp32 output rows to `aux` [P*N, d]; the unconditional ones then write out[r + P*N] = fp16(att_u - att_c) (difference operand of
-// the out-proj pair GEMM).  Short-sequence kernel only (N <= 288): returns -1 otherwise.
-void qkv_e4m3_round(hipStream_t s, h16* qkv, int rows, int width);   // diagnostic: Q/K/V rows -> e4m3 values (per token, head, operand scale), in place; width % 256 == 0
-int attention_pair(hipStream_t s, const h16* qkv, h16* out, float* aux, int P, int N, int d, int heads, uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);
-// (out4 / out4s, head dimension 64 only: e2m1 of the conditional output values, row stride 2d bytes, + lane-ordered E8M0 scale bytes, GemmArgs.lo)
+void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads,
+               uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);   // out4 / out4s (N = 257, head width 64): e2m1 of the outputs + lane-ordered scale
+                                                                      // bytes for the out-proj GEMM's mini-tile pass
+// "CFG pair" attention: sequences [0, P) are conditional, [P, 2P) their unconditional twins; one workgroup runs a (pair, head) -- conditional pass,
+// then the twin with the conditional output tiles kept in registers -- and writes out[r + P*N] = fp16(att_u - att_c), the difference operand of the
+// out-proj pair GEMM.  N <= 288: K / V of a head in LDS; longer sequences (the 1024 + 1-token models): the streaming kernel in pair form.
+// out4 / out4s (head dimension 64 only): e2m1 of the conditional output values, row stride 2d bytes, + lane-ordered E8M0 scale bytes (GemmArgs.lo)
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d, int heads, uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 
@@ -195,10 +162,8 @@ void combine_groups(hipStream_t s, const int64_t* tokens /*[rows,m]*/, int64_t* 
 
 // ---- fp32 -> h16 repack ------------------------------------------------------------------------
 void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n);
-// W[N,K] fp32 -> dst[N,2K] = [fp16(W*2^S) | fp16(W*2^S - hi)], S chosen from max|W| (tmp: one device uint32 of scratch);
-// *scale_out = 2^-S.  Stream-ordered, no host synchronisation.
-void split_f32_to_h16x2(hipStream_t s, const float* src, h16* dst, int N, int K, float* scale_out, unsigned* tmp);
-// the same halves as two planes: hi[N,K] and lo[N,K] (GemmArgs.W / W2)
+// W[N,K] fp32 -> two planes hi[N,K] = fp16(W*2^S), lo[N,K] = fp16(W*2^S - hi) (GemmArgs.W / W2), S chosen from max|W| (tmp: one device uint32 of
+// scratch); *scale_out = 2^-S.  Stream-ordered, no host synchronisation.
 void split_f32_to_h16_planes(hipStream_t s, const float* src, h16* hi, h16* lo, int N, int K, float* scale_out, unsigned* tmp);
 
 }  // namespace mb

@@ -42,7 +42,7 @@ __device__ __forceinline__ void fp4_rows_out(const Fp4Rows& f4, float4* v, int l
 template <int NV>
 __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, int d, int lane,
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr, uint8_t* x8 = nullptr,
+                                          float eps, float* xo, h16* xb, float* st = nullptr, h16* xl = nullptr,
                                           const Fp4Rows* f4 = nullptr, int row = 0) {
   // f4 (optional): e2m1 copies of the row for the mini-tile passes (vector path only)
   // xl (optional): the fp16 lo halves o - fp16(o) of the same row, for the split-activation GEMMs
@@ -79,7 +79,6 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
       const h16x4 hi = {to_h(o.x), to_h(o.y), to_h(o.z), to_h(o.w)};
       if (xb) *(h16x4*)(xb + c) = hi;
       if (xl) *(h16x4*)(xl + c) = h16x4{to_h(o.x - (float)hi[0]), to_h(o.y - (float)hi[1]), to_h(o.z - (float)hi[2]), to_h(o.w - (float)hi[3])};
-      if (x8) *(uint32_t*)(x8 + c) = lo8_pack4h(o.x, o.y, o.z, o.w, hi);
       if (f4) v[q] = o;                                               // keep the normalised row for the e2m1 copies
     }
     if constexpr (VEC) { if (f4) fp4_rows_out<NV>(*f4, v, lane, row, d); }
@@ -91,7 +90,6 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
         if (xo) xo[c] = o;
         if (xb) xb[c] = to_h(o);
         if (xl) xl[c] = to_h(o - (float)to_h(o));
-        if (x8) x8[c] = (uint8_t)(lo8_pack4(o, 0.f, 0.f, 0.f) & 0xffu);
       }
     }
   }
@@ -100,7 +98,7 @@ __device__ __forceinline__ void ln_finish(float4* v, const float* sc, int ns, in
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* x_f32,
-                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, Fp4Rows f4) {
+                                                      h16* x_h16, float* stats, int M, int d, h16* x_lo, Fp4Rows f4) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -115,7 +113,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   else     { for (int q = 0; q < ns; ++q) { const int c = lane + q * 64; sc[q] = c < d ? yr[c] : 0.f; } }
   ln_finish<NV>(v, sc, ns, d, lane, gamma, beta, eps, x_f32 ? x_f32 + (size_t)row * d : nullptr,
                  x_h16 ? x_h16 + (size_t)row * d : nullptr, stats ? stats + (size_t)row * 2 : nullptr,
-                 x_lo ? x_lo + (size_t)row * d : nullptr, x8 ? x8 + (size_t)row * 2 * d : nullptr,
+                 x_lo ? x_lo + (size_t)row * d : nullptr,
                  (f4.x4 || f4.xl4) ? &f4 : nullptr, row);
 }
 
@@ -202,11 +200,11 @@ int pairify_rows(hipStream_t s, const float* x32, h16* x_h16, int P, int d, cons
 }
 
 void layernorm_rows(hipStream_t s, const float* y, const float* gamma, const float* beta, float eps,
-                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, uint8_t* x8, const Fp4Rows& f4) {
+                    float* x_f32, h16* x_h16, float* stats, int M, int d, h16* x_lo, const Fp4Rows& f4) {
   dim3 grid((M + 3) / 4), block(256);      // f4 (e2m1 values / lo halves): vector path only (d = 768 / 1024; mb_gen_create restricts the modes to those)
-  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, f4);
-  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, f4);
-  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, x8, Fp4Rows{});
+  if (d == 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, f4);
+  else if (d == 768) hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, f4);
+  else hipLaunchKernelGGL(ln_rows_kernel<0>, grid, block, 0, s, y, gamma, beta, eps, x_f32, x_h16, stats, M, d, x_lo, Fp4Rows{});
 }
 
 // One wave per (sequence, row).  Rows 0..seq-1 are image tokens, row seq is the class token (LAST,
@@ -291,7 +289,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(EmbedArgs a) {
     }
   }
   ln_finish<NV>(v, sc, ns, d, lane, a.gamma, a.beta, 1e-12f, a.x_f32 + (size_t)row * d, a.x_h16 + (size_t)row * d, nullptr,
-                 a.x_lo ? a.x_lo + (size_t)row * d : nullptr, a.x8 ? a.x8 + (size_t)row * 2 * d : nullptr,
+                 a.x_lo ? a.x_lo + (size_t)row * d : nullptr,
                  (a.f4.x4 || a.f4.xl4) ? &a.f4 : nullptr, row);
 }
 

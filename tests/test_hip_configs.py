@@ -21,9 +21,9 @@ def _teacher_forced(cfg, sd, model, B, N, labels, seed, **kw):
     O.sample_loop(lambda t, yy, dd: O.lfq_bert_forward(sd, cfg, t, yy, dd), B, labels, num_steps=N, mask_token=C_,
                   codebook_splits=m, record=rec, **kw)
     if os.environ.get("MB_TEST_ALSO_FP16"):              # context: the single-fp16 mode on the same oracle run
-        model.act_split, model.cfg_pair = 0, 0
+        model.precision = 0
         r0 = _replay(lib, _lib, cfg, model, rec, B, labels, kw)
-        model.act_split, model.cfg_pair = -1, -1
+        model.precision = -1
         print(f"  [single fp16: mismatch {r0[0]:.2e} ({r0[2]}/{r0[3]}), mean |logit err| {r0[1]:.4f}]")
     r = _replay(lib, _lib, cfg, model, rec, B, labels, kw)
     print(f"  [default precision: {r[2]}/{r[3]} mismatches]")
@@ -78,14 +78,14 @@ def test_other_bit_widths_tiny(bits, splits):
 
 def _vs_reference_run(name, modes):
     """Teacher-forced replay of one of the REAL reference's full-size runs (tests/golden/<name>.npz, oracle/make_golden.py RUNS) in the given
-    engine modes (tag, weight_split, act_split, cfg_pair) -> {tag: (mismatches, positions)}."""
+    engine modes (tag, LFQBert.precision) -> {tag: (mismatches, positions)}."""
     import parity_replay as R
     g = R.load_run(name)
     gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
     noise = R.reference_noise(g, gen.device)
     out = {}
-    for tag, ws, act, pair in modes:
-        gen.weight_split, gen.act_split, gen.cfg_pair = ws, act, pair
+    for tag, prec in modes:
+        gen.precision = prec
         bad, tot, per, _ = R.teacher_forced(gen, g, noise)
         nb = max(1, len(per) // 8)
         print(f"{name} [{tag}]: {bad}/{tot} = {bad / tot:.2e}; per eighth of the run {[sum(per[i:i + nb]) for i in range(0, len(per), nb)]}")
@@ -96,19 +96,18 @@ def _vs_reference_run(name, modes):
 @pytest.mark.timeout(900)
 def test_baseline_config1_10bit_16steps_nocfg_vs_reference_runs():
     """BASELINE configs[1] as named -- 10-bit generator, 16 steps, no guidance, batch 16 -- against THREE runs of the real reference (other weights,
-    head gain, noise and labels; 87 040 sampled positions each).  Without guidance the plain forward runs; its product default (round 4: the
-    LayerNorm outputs as fp16 hi + lo pairs AND the MX-fp4 weight-correction mini-tiles on every trunk GEMM + hi/lo head weights) measures
-    5.2e-4 / 4.3e-4 / 6.4e-4 = 5.3e-4 over all; the weight correction over single fp16 activations (act_split 0, cfg_pair 2: the faster opt-out)
-    8.2e-4 / 5.1e-4 / 7.7e-4 = 7.0e-4; single fp16 1.06e-3 / 7.1e-4.  Asserted: <= 7e-4 on each run and <= 6e-4 over all for the default, the
-    north star's <= 1e-3 on each run for the opt-out."""
+    head gain, noise and labels; 87 040 sampled positions each).  Without guidance the plain forward runs; its product default (the LayerNorm
+    outputs as fp16 hi + lo pairs AND the MX-fp4 weight-correction mini-tiles on every trunk GEMM + hi/lo head weights) measures
+    5.2e-4 / 4.3e-4 / 6.4e-4 = 5.3e-4 over all (round 4 also shipped the correction over single fp16 activations as a faster opt-out: 7.0e-4 over
+    all, 8.2e-4 on one run; removed with the one-knob precision of round 5); single fp16 1.06e-3 / 7.1e-4.  Asserted: <= 7e-4 on each run and
+    <= 6e-4 over all."""
     import parity_replay as R
     tb = tt = 0
     for name in (R.RUN_CFG1, R.RUN_CFG1_S2, R.RUN_CFG1_S3):
-        r = _vs_reference_run(name, [("product default", 0, -1, -1), ("weight correction, single fp16 activations", 0, 0, 2), ("single fp16", 0, 0, 0)])
+        r = _vs_reference_run(name, [("product default", -1), ("hi + lo LayerNorm outputs alone (precision 1)", 1), ("single fp16", 0)])
         bad, tot = r["product default"]
         assert tot == 87040 and bad / tot <= 7e-4, name
         tb += bad; tt += tot
-        assert r["weight correction, single fp16 activations"][0] / tot <= 1e-3, name
     print(f"configs[1], three reference runs, product default: {tb}/{tt} = {tb / tt:.2e}")
     assert tb / tt <= 6e-4
 
@@ -118,21 +117,20 @@ def test_baseline_config5_14bit_256steps_vs_reference_runs():
     """BASELINE configs[4]'s generator and sampler as named -- 14-bit (C = 128 per group), 256 steps, CFG 5.8 cosine (configs/generator/
     maskbit_generator_14bit_256steps.yaml:38-44) -- against THREE 256-step runs of the real reference (B = 2, 2 and 4: 668 496 sampled positions).
     MEASURED: the differential form alone misses 1e-3 here (1.4e-3; single fp16: 2.0e-3); with the weight-correction mini-tiles and hi/lo head
-    weights (cfg_pair 2) the first run measures 6.6e-4; the product default at 7 bits per group (cfg_pair 3: + the activation-lo mini-tiles of the
+    weights (precision 2) the first run measures 6.6e-4; the product default at 7 bits per group (precision 3: + the activation-lo mini-tiles of the
     LayerNorm outputs) 5.4e-4 / 8.6e-4 / 4.2e-4 = 5.6e-4 over all.  Asserted without allowance: <= 1e-3 on each run, <= 7e-4 over all."""
     import parity_replay as R
-    r = _vs_reference_run(R.RUN_CFG5, [("product default", 0, -1, -1), ("weight correction + activation-lo pass", 0, -1, 3),
-                                       ("weight correction alone", 0, -1, 2), ("differential operands only", 0, -1, 1),
-                                       ("fp16x2 weights + differential CFG", 1, -1, -1), ("single fp16", 0, 0, 0)])
+    r = _vs_reference_run(R.RUN_CFG5, [("product default", -1), ("weight correction + activation-lo pass", 3),
+                                       ("weight correction alone", 2), ("differential operands only", 1), ("single fp16", 0)])
     bad, tot = r["differential operands only"]
     assert tot == 167124 and bad / tot <= 2e-3
     assert r["product default"] == r["weight correction + activation-lo pass"]          # what the default resolves to at 7 bits per group
-    for tag in ("product default", "weight correction alone", "fp16x2 weights + differential CFG"):
+    for tag in ("product default", "weight correction alone"):
         bad, tot = r[tag]
         assert bad / tot <= 1e-3, tag
     tb, tt = r["product default"]
     for name in (R.RUN_CFG5_S2, R.RUN_CFG5_S3):
-        bad, tot = _vs_reference_run(name, [("product default", 0, -1, -1)])["product default"]
+        bad, tot = _vs_reference_run(name, [("product default", -1)])["product default"]
         assert bad / tot <= 1e-3, name
         tb += bad; tt += tot
     print(f"configs[4], three reference runs, product default: {tb}/{tt} = {tb / tt:.2e}")
@@ -152,8 +150,8 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
         gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
         noise = R.reference_noise(g, gen.device)
         out = {}
-        for tag, act, pair in (("product default", -1, -1), ("single fp16", 0, 0)):
-            gen.act_split, gen.cfg_pair = act, pair
+        for tag, prec in (("product default", -1), ("single fp16", 0)):
+            gen.precision = prec
             bad, tot, per, _ = R.teacher_forced(gen, g, noise)
             out[tag] = (bad, tot)
             print(f"{name} [{tag}, resolves to {gen.resolved_precision()}]: {bad}/{tot} = {bad / tot:.2e}")
@@ -168,7 +166,7 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("name,expect,bound", [("sample_full12_64_prenorm", (1, 2), 8e-4), ("sample_full12_64_seq1024", (1, 2), 7e-4)])
+@pytest.mark.parametrize("name,expect,bound", [("sample_full12_64_prenorm", 2, 8e-4), ("sample_full12_64_seq1024", 2, 7e-4)])
 def test_generator_variants_full_width_vs_reference_runs(name, expect, bound):
     """configs[2]'s sampler (64 steps, CFG 7.1 cosine) on the two generator variants of the reference that differ in how the engine runs the guided
     forward, against full-width runs of the REAL reference (oracle/make_golden.py RUNS):
@@ -177,7 +175,7 @@ def test_generator_variants_full_width_vs_reference_runs(name, expect, bound):
         mini-tiles measured 1.44e-3 (guidance multiplies the two streams' separate fp16 roundings), hi + lo activation pairs 8.4e-4;
       * 1024 + 1 tokens (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144): since round 5 the differential form with the weight-correction
         mini-tiles here too (eight 128-token pair tiles per sequence pair, the streaming attention kernel in pair form); rounds 3-4 ran the plain forward
-        over [cond | uncond] with hi + lo activation pairs (act_split 3) and measured 7.6e-4 (single fp16: 1.11e-3)."""
+        over [cond | uncond] with hi + lo activation pairs (the e4m3 lo pass, retired in round 5) and measured 7.6e-4 (single fp16: 1.11e-3)."""
     import parity_replay as R
     g = R.load_run(name)
     gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
@@ -272,8 +270,8 @@ def test_baseline_config3_three_reference_runs_other_weights_noise_and_labels():
         g = R.load_run(name)
         gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
         noise = R.reference_noise(g, gen.device)
-        for tag, act, pair in (("product default", -1, -1), ("differential only", -1, 1)):
-            gen.act_split, gen.cfg_pair = act, pair
+        for tag, prec in (("product default", -1), ("differential only", 1)):
+            gen.precision = prec
             bad, tot, per, _ = R.teacher_forced(gen, g, noise)
             tot_all[tag][0] += bad; tot_all[tag][1] += tot
             print(f"{name}, {tag}: {bad}/{tot} = {bad / tot:.2e}; per 8 steps {[sum(per[i:i + 8]) for i in range(0, 64, 8)]}")

@@ -116,8 +116,7 @@ def test_pair_attention_long_sequences(pairs, heads, d, N):
     qu = qc + torch.randn(pairs * N, 3 * d, device=DEV) * 0.02
     qkv = torch.cat([qc, qu]).half().contiguous()
     out = torch.full((2 * pairs * N, d), float("nan"), device=DEV, dtype=torch.float16)
-    aux = torch.empty(pairs * N, d, device=DEV)
-    _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), pairs, N, d, heads, torch.cuda.current_stream().cuda_stream), "mb_attention_pair")
+    _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), pairs, N, d, heads, torch.cuda.current_stream().cuda_stream), "mb_attention_pair")
     torch.cuda.synchronize()
     x = qkv.double().view(2 * pairs, N, 3, heads, dh).permute(2, 0, 3, 1, 4)
     p = torch.softmax(x[0] @ x[1].transpose(-1, -2) / dh ** 0.5, dim=-1)
@@ -133,12 +132,12 @@ def test_pair_attention_long_sequences(pairs, heads, d, N):
 @pytest.mark.timeout(900)
 def test_guided_forward_1025_tokens_full_width_vs_oracle():
     """forward_cfg of a full-width (hidden 1024, 16 heads, mlp 4096) two-layer generator over 1024 + 1 tokens: the product default now resolves to the
-    differential form with the weight-correction mini-tiles (cfg_pair 2) here too; with cfg_pair = 0 it is the plain forward over [cond | uncond] bit
+    differential form with the weight-correction mini-tiles (precision 2) here too; with precision = 0 it is the plain forward over [cond | uncond] bit
     for bit; in differential form the guided combination at s = 6 is several times closer to the fp32 oracle; batch invariance of a pair."""
     cfg = O.GenCfg(bits=12, splits=2, hidden=1024, depth=2, heads=16, mlp=4096, seq=1024, nclass=1000)
     sd = O.make_generator_weights(cfg, seed=77, head_gain=12.0)
     m = _gen(cfg, sd)
-    assert m.resolved_precision() == (1, 2)
+    assert m.resolved_precision() == 2
     g = torch.Generator().manual_seed(5)
     t = torch.randint(0, 65, (3, 1024, 2), generator=g)
     y = torch.tensor([5, 321, 999])
@@ -147,18 +146,18 @@ def test_guided_forward_1025_tokens_full_width_vs_oracle():
     ref = O.lfq_bert_forward(sd, cfg, torch.cat([t, t]), torch.cat([y, y]), drop)
     s = 6.0
     guided = lambda lg: lg[:3] + s * (lg[:3] - lg[3:])
-    m.act_split, m.cfg_pair = 0, 0
+    m.precision = 0
     plain = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV))
     assert torch.equal(m.forward_cfg(t.to(DEV), y.to(DEV)), plain)
     e_plain = float((guided(plain.cpu()) - guided(ref)).abs().mean())
     for pair in (1, 2):
-        m.act_split, m.cfg_pair = -1, pair
+        m.precision = pair
         lg = m.forward_cfg(t.to(DEV), y.to(DEV))
         rel = float((lg.cpu() - ref).norm() / ref.norm())
         e = float((guided(lg.cpu()) - guided(ref)).abs().mean())
-        print(f"1025 tokens, cfg_pair = {pair}: rel-Frobenius logit error {rel:.2e}; mean |guided logit error| {e:.4f} (plain fp16 forward over [cond | uncond]: {e_plain:.4f})")
+        print(f"1025 tokens, precision = {pair}: rel-Frobenius logit error {rel:.2e}; mean |guided logit error| {e:.4f} (plain fp16 forward over [cond | uncond]: {e_plain:.4f})")
         assert rel < 2e-3 and e < 0.6 * e_plain
         one = m.forward_cfg(t[1:2].to(DEV), y[1:2].to(DEV))
         assert torch.equal(one[0], lg[1]) and torch.equal(one[1], lg[4])
     assert m.saturation_count() == 0
-    m.act_split, m.cfg_pair = -1, -1
+    m.precision = -1

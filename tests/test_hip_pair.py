@@ -1,4 +1,4 @@
-"""Differential classifier-free guidance (mb_gen_cfg.cfg_pair, DESIGN.md "Precision"): the pair GEMM, the pair LayerNorm / attention
+"""Differential classifier-free guidance (mb_gen_cfg.precision >= 1, DESIGN.md "Precision"): the pair GEMM, the pair LayerNorm / attention
 operands, and the guided forward against the CPU oracle.  The reference computes the guided logits as
 c + s (c - u) from one forward over [cond | uncond] (sampling.py:83-99); the engine carries the unconditional stream's fp16 GEMM operands
 as differences from the conditional stream's, so that operand rounding cancels in (c - u)."""
@@ -56,8 +56,8 @@ def _full12():
 
 @pytest.mark.timeout(900)
 def test_guided_forward_full_size_vs_oracle():
-    """forward_cfg at full size (B = 3 pairs, masked / unmasked tokens): (a) with cfg_pair = 0 it IS the plain forward over [cond | uncond], bit for
-    bit; (b) in differential form (cfg_pair = 1, 2) both streams stay as close to the fp32 oracle as the plain fp16 forward does, and the
+    """forward_cfg at full size (B = 3 pairs, masked / unmasked tokens): (a) with precision = 0 it IS the plain forward over [cond | uncond], bit for
+    bit; (b) in differential form (precision 1, 2, 3) both streams stay as close to the fp32 oracle as the plain fp16 forward does, and the
     guided combination c + s (c - u) at s = 6 is several times closer -- the operand rounding no longer reaches (c - u)."""
     cfg, sd, m = _full12()
     g = torch.Generator().manual_seed(3)
@@ -68,28 +68,28 @@ def test_guided_forward_full_size_vs_oracle():
     ref = O.lfq_bert_forward(sd, cfg, torch.cat([t, t]), torch.cat([y, y]), drop)
     s = 6.0
     guided = lambda lg: lg[:3] + s * (lg[:3] - lg[3:])
-    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0
+    m.precision = 0
     plain = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV))
     assert torch.equal(m.forward_cfg(t.to(DEV), y.to(DEV)), plain)
     e_plain = float((guided(plain.cpu()) - guided(ref)).abs().mean())
     e_by_mode = {}
     for pair in (1, 2, 3):                                                          # differential form; + weight-correction mini-tiles; + activation-lo mini-tiles
-        m.cfg_pair = pair
+        m.precision = pair
         lg = m.forward_cfg(t.to(DEV), y.to(DEV)).cpu()
         rel = float((lg - ref).norm() / ref.norm())
         e_by_mode[pair] = float((guided(lg) - guided(ref)).abs().mean())
-        print(f"cfg_pair = {pair}: rel-Frobenius logit error {rel:.2e}; mean |guided logit error| {e_by_mode[pair]:.4f} (plain fp16 forward: {e_plain:.4f})")
+        print(f"precision = {pair}: rel-Frobenius logit error {rel:.2e}; mean |guided logit error| {e_by_mode[pair]:.4f} (plain fp16 forward: {e_plain:.4f})")
         assert rel < 2e-3 and e_by_mode[pair] < 0.6 * e_plain
     assert e_by_mode[2] < 0.8 * e_by_mode[1] and e_by_mode[3] < e_by_mode[2]
-    # the plain forward() of a cfg_pair >= 2 engine carries the weight-correction mini-tiles on every trunk GEMM: closer to the oracle than single fp16
-    m.act_split, m.cfg_pair = 0, 2
+    # the plain forward() of a precision >= 2 engine carries the weight-correction mini-tiles on every trunk GEMM (and hi + lo LayerNorm outputs): closer to the oracle than single fp16
+    m.precision = 2
     w = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV)).cpu()
     e_w, e_0 = float((w - ref).abs().mean()), float((plain.cpu() - ref).abs().mean())
     print(f"plain forward: mean |logit error| single fp16 {e_0:.4f}, with the MX-fp4 weight-rounding correction {e_w:.4f}")
     assert e_w < 0.7 * e_0
     sat = m.saturation_count()
     assert sat == 0, sat
-    m.act_split, m.cfg_pair = -1, -1
+    m.precision = -1
 
 
 @pytest.mark.parametrize("pairs,heads,d", [(2, 16, 1024), (3, 4, 128)])
@@ -106,8 +106,7 @@ def test_pair_attention_vs_fp32_reference(pairs, heads, d):
     qu = qc + torch.randn(pairs * N, 3 * d, device=DEV) * 0.02          # the unconditional stream differs a little
     qkv = torch.cat([qc, qu]).half().contiguous()
     out = torch.full((2 * pairs * N, d), float("nan"), device=DEV, dtype=torch.float16)
-    aux = torch.empty(pairs * N, d, device=DEV)
-    _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), pairs, N, d, heads, torch.cuda.current_stream().cuda_stream),
+    _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), pairs, N, d, heads, torch.cuda.current_stream().cuda_stream),
                "mb_attention_pair")
     torch.cuda.synchronize()
     x = qkv.double().view(2 * pairs, N, 3, heads, dh).permute(2, 0, 3, 1, 4)          # [3, seq, head, N, dh]
@@ -119,4 +118,4 @@ def test_pair_attention_vs_fp32_reference(pairs, heads, d):
     err = float((out[pairs * N:].double() - diff).abs().max())
     assert err < 6e-4 * float(oc.abs().max()) and err < 2e-2 * float(diff.abs().max()), (err, float(diff.abs().max()), float(oc.abs().max()))
     with pytest.raises(RuntimeError):                                             # head widths other than 32 / 64 are refused (N > 288 runs the streaming pair kernel: test_hip_long_seq.py)
-        _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), 1, N, d, d // 16, torch.cuda.current_stream().cuda_stream), "mb_attention_pair")
+        _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), 1, N, d, d // 16, torch.cuda.current_stream().cuda_stream), "mb_attention_pair")

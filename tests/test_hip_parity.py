@@ -50,67 +50,41 @@ def test_generator_forward_full12_vs_reference_golden():
     assert float(agree) > 0.995
 
 
-def test_generator_fp16x2_weights_full12():
-    """weight_split = 1 (hi + lo fp16 weight halves, DESIGN.md "Precision"): same golden, about half the logit error
-    (measured 5.5e-4 vs 1.14e-3 relative Frobenius), and switching the mode on a live model rebuilds the engine."""
+def test_generator_plain_forward_precision_modes_full12_and_tiny():
+    """The plain forward() under the engine's ONE precision knob (LFQBert.precision): 0 = single fp16 operands; 1 = + the LayerNorm outputs as fp16
+    hi + lo pairs into QKV / FFN-up (the GEMM-input rounding is 13 % of the error variance); 2 = + the MX-fp4 weight-correction mini-tiles on every
+    trunk GEMM (the weights' rounding is most of the rest).  Each step moves the logits closer to the reference's fp32 golden; batch invariance holds
+    bit for bit in every mode; switching the mode on a live model rebuilds the engine.  The tiny model (128-square GEMM kernel, no pair / mini tiles)
+    runs modes >= 1 with hi + lo LayerNorm outputs alone."""
     z = load_golden("gen_full12.npz")
     cfg = O.GenCfg(bits=12, splits=2)
     sd = O.make_generator_weights(cfg, seed=int(z["seed"]), head_gain=float(z["head_gain"]))
     m = hip_generator(cfg, sd)
     args = (torch.from_numpy(z["tokens"]).to(DEV), torch.from_numpy(z["labels"]).to(DEV), torch.from_numpy(z["drop"]).to(DEV))
     ref = torch.from_numpy(z["logits"])
-    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0                              # independent of MASKBIT_AMD_* in the environment
-    e0 = rel_fro(m(*args), ref)
-    m.weight_split = 1
-    e1 = rel_fro(m(*args), ref)
-    print(f"rel-Frobenius logit error: fp16 weights {e0:.2e}, fp16x2 weights {e1:.2e}")
-    assert e1 < 1.5e-3 and e1 < 0.7 * e0
-    m.weight_split = 0
-    assert abs(rel_fro(m(*args), ref) - e0) < 1e-9
-
-
-def test_generator_split_activations_full12_and_tiny():
-    """act_split = 1 (fp16 hi + lo pairs for the LayerNorm outputs feeding the QKV and FFN-up GEMMs, DESIGN.md "Precision"): the logits
-    move closer to the fp32 golden (the GEMM-input rounding is 13 % of the error variance), batch invariance still holds bit for bit,
-    and switching the mode on a live model rebuilds the engine.  Also on the tiny model (128-square GEMM kernel)."""
-    z = load_golden("gen_full12.npz")
-    cfg = O.GenCfg(bits=12, splits=2)
-    sd = O.make_generator_weights(cfg, seed=int(z["seed"]), head_gain=float(z["head_gain"]))
-    m = hip_generator(cfg, sd)
-    args = (torch.from_numpy(z["tokens"]).to(DEV), torch.from_numpy(z["labels"]).to(DEV), torch.from_numpy(z["drop"]).to(DEV))
-    ref = torch.from_numpy(z["logits"])
-    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0                              # independent of MASKBIT_AMD_* in the environment
-    e0 = rel_fro(m(*args), ref)
-    m.act_split = 1
-    out1 = m(*args)
-    e1 = rel_fro(out1, ref)
-    print(f"rel-Frobenius logit error: fp16 activations {e0:.2e}, hi+lo LayerNorm outputs {e1:.2e}")
-    assert e1 < 0.98 * e0
-    assert torch.equal(m(args[0][1:2], args[1][1:2], args[2][1:2]), out1[1:2])                  # batch invariance in this mode too
-    rep = m(args[0].repeat(9, 1, 1), args[1].repeat(9), args[2].repeat(9))                      # half-tile kernel (M >= 512)
-    nb = args[0].shape[0]
-    assert torch.equal(rep[:nb], rep[-nb:]) and rel_fro(rep[:nb], ref) < 0.98 * e0
-    for level in (2, 3):                                                                        # every trunk GEMM activation as a pair (fp16 / e4m3 lo halves)
-        m.act_split = level
-        e_l = rel_fro(m(*args), ref)
-        print(f"act_split = {level}: {e_l:.2e}")
-        assert e_l < e1 and torch.equal(m(args[0][1:2], args[1][1:2], args[2][1:2]), m(*args)[1:2])
-    m.act_split = 1
-    m.weight_split = 1
-    with pytest.raises(RuntimeError):
-        m(*args)                                                                                # the two modes are not combined
-    m.weight_split, m.act_split, m.cfg_pair = 0, 0, 0
-    assert abs(rel_fro(m(*args), ref) - e0) < 1e-9
+    err = {}
+    for prec in (0, 1, 2):
+        m.precision = prec                                                                     # independent of MASKBIT_AMD_PRECISION in the environment
+        out = m(*args)
+        err[prec] = rel_fro(out, ref)
+        assert torch.equal(m(args[0][1:2], args[1][1:2], args[2][1:2]), out[1:2])               # batch invariance in this mode too
+        rep = m(args[0].repeat(9, 1, 1), args[1].repeat(9), args[2].repeat(9))                  # half-tile kernel (M >= 512)
+        nb = args[0].shape[0]
+        assert torch.equal(rep[:nb], rep[-nb:]) and abs(rel_fro(rep[:nb], ref) - err[prec]) < 2e-5
+    print(f"rel-Frobenius logit error: single fp16 {err[0]:.2e}, hi + lo LayerNorm outputs {err[1]:.2e}, + weight correction {err[2]:.2e}")
+    assert err[1] < 0.98 * err[0] and err[2] < 0.75 * err[1]
+    m.precision = 0
+    assert abs(rel_fro(m(*args), ref) - err[0]) < 1e-9
+    m.precision = -1
+    assert m.resolved_precision() == 2
     zt = load_golden("gen_tiny.npz")
     mt = hip_generator(TINY_GEN, golden_weights(zt))
     t, y, d = torch.from_numpy(zt["tokens"]).to(DEV), torch.from_numpy(zt["labels"]).to(DEV), torch.from_numpy(zt["drop"]).to(DEV)
     rt = torch.from_numpy(zt["logits"])
-    mt.weight_split, mt.act_split, mt.cfg_pair = 0, 0, 0
+    assert mt.resolved_precision() == 1                           # hidden 128: neither pair tiles nor mini-tiles
+    mt.precision = 0
     a0 = rel_fro(mt(t, y, d), rt)
-    mt.act_split = 3
-    with pytest.raises(RuntimeError):
-        mt(t, y, d)                                               # the e4m3 lo pass needs hidden and mlp to be multiples of 256: loud, no silent fallback
-    mt.act_split = 1
+    mt.precision = 1
     a1 = rel_fro(mt(t, y, d), rt)
     print(f"tiny: {a0:.2e} -> {a1:.2e}")
     assert a1 < 2e-3 and a1 < 1.02 * a0

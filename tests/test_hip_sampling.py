@@ -60,11 +60,9 @@ def test_teacher_forced_token_parity_full_size():
     from the oracle's inputs and noise.  Mismatch is counted over the positions that are sampled
     (masked) at that step.  Engine modes against the same oracle run:
       * the product default (guided forward with differential CFG operands at this width): must meet the north star's 1e-3;
-      * act_split = 0 (single fp16 operands -- the 10-bit mantissa of the TF32 matmuls the reference's configs enable): ~1.2e-3 on this
+      * precision = 0 (single fp16 operands -- the 10-bit mantissa of the TF32 matmuls the reference's configs enable): ~1.2e-3 on this
         8-step stress schedule (CFG scale up to 5.4 while 30% of the tokens are still masked); context only, bound 3e-3;
-      * act_split = 2 (every GEMM activation as an fp16 hi+lo pair) and act_split = 3 (the lo halves and a copy of the weights as e4m3, a
-        half-cost correction pass on the scaled fp8 MFMA): must meet the north star's 1e-3 (measured 6.0e-4 / 5.9e-4 over 84 284 tokens of
-        a 64-step run, tests/diag/gpu_check.py tf_full).
+      * precision = 1 (the differential form alone): must meet the north star's 1e-3 on this run.
     The per-step logit error is bounded too."""
     from maskbit_amd import _lib
     lib = _lib.load()
@@ -79,10 +77,10 @@ def test_teacher_forced_token_parity_full_size():
                   guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2, mask_schedule_strategy="arccos",
                   mask_token=64, codebook_splits=2, record=rec)
     drop = torch.cat([torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool)]).to(DEV)
-    # (act_split, cfg_pair): (-1, -1) = the product default (differential CFG operands for the guided forward at this shape); (0, 0) = single
-    # fp16, reported with a loose bound as context; (2, 0) / (3, 0) = hi + lo activation pairs (fp16 / e4m3 lo halves)
-    for act_split, cfg_pair, bound in ((-1, -1, 1e-3), (0, 0, 3e-3), (2, 0, 1e-3), (3, 0, 1e-3)):
-        m.act_split, m.cfg_pair = act_split, cfg_pair
+    # LFQBert.precision: -1 = the product default (differential CFG operands + weight-correction mini-tiles at this shape); 0 = single fp16,
+    # reported with a loose bound as context; 1 = the differential form alone
+    for prec, bound in ((-1, 1e-3), (0, 3e-3), (1, 1e-3)):
+        m.precision = prec
         bad = tot = 0
         for r in rec:
             tin = r.tokens_in.to(DEV).contiguous()
@@ -98,7 +96,7 @@ def test_teacher_forced_token_parity_full_size():
             msk = r.tokens_in == 64
             bad += int((pred.cpu() != r.pred)[msk].sum())
             tot += int(msk.sum())
-        print(f"act_split={act_split} cfg_pair={cfg_pair}: teacher-forced mismatch {bad}/{tot} = {bad / tot:.2e}")
+        print(f"precision={prec}: teacher-forced mismatch {bad}/{tot} = {bad / tot:.2e}")
         assert bad / tot < bound
 
 

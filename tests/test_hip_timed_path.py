@@ -4,7 +4,7 @@ bench.py times 64 sequence pairs per guided forward: M = 32 896 rows, 512-2 048 
 mini-tile buffer reused from tile to tile.  Every comparison with the oracle / the reference's recorded runs used 2-8 pairs (one tile per workgroup).
 These tests close the gap with size-independent properties, bit for bit:
   * a sequence pair's guided logits do not depend on the batch it rides in (1 .. 64 pairs), in the two precision modes the product default
-    resolves to (cfg_pair 2 for the 12-bit generator, cfg_pair 3 for the 14-bit one) -- so the parity measured at 4 pairs IS the parity at 64;
+    resolves to (precision 2 for the 12-bit generator, 3 for the 14-bit one) -- so the parity measured at 4 pairs IS the parity at 64;
   * the mini-tile kernels (pair and plain tiles, every epilogue, one and two operand sets, whole / half- / quarter-column tiles) give the same
     bits whether 256, 24 or 8 workgroups walk the tile list (mb_set_cu_count: up to 10 tiles per workgroup);
   * the teacher-forced replay of the reference's own run with its samples EMBEDDED in a 64-sample batch counts exactly the mismatches of the plain
@@ -28,8 +28,8 @@ def test_guided_forward_batch_invariance_full_size(bits, pair):
     cfg = O.GenCfg(bits=bits, splits=2)
     sd = O.make_generator_weights(cfg, seed=100, head_gain=12.0)
     m = hip_generator(cfg, sd)
-    m.act_split, m.cfg_pair = -1, -1
-    assert m.resolved_precision() == (1, pair)                     # the product default of this codebook
+    m.precision = -1
+    assert m.resolved_precision() == pair                          # the product default of this codebook
     g = torch.Generator().manual_seed(bits)
     C_ = cfg.group_codes
     tok = torch.randint(0, C_ + 1, (64, 256, 2), generator=g)
@@ -148,12 +148,12 @@ def test_replay_embedded_in_the_timed_batch_counts_the_same_mismatches():
     noise = R.reference_noise(g, gen.device)
     rate = {}
     for pair in (-1, 1):
-        gen.act_split, gen.cfg_pair = -1, pair
+        gen.precision = pair
         small = R.teacher_forced(gen, g, noise)
         big = R.teacher_forced(gen, g, noise, batch=64)
-        print(f"cfg_pair {pair} (resolves to {gen.resolved_precision()}): batch 4 {small[0]}/{small[1]}, embedded in batch 64 {big[0]}/{big[1]}")
+        print(f"precision {pair} (resolves to {gen.resolved_precision()}): batch 4 {small[0]}/{small[1]}, embedded in batch 64 {big[0]}/{big[1]}")
         assert big[1] == small[1] == 84284
         assert big[2] == small[2] and big[3] == small[3]               # per-step mismatch counts and the re-mask differences
         rate[pair] = big[0] / big[1]
-    gen.cfg_pair = -1
+    gen.precision = -1
     assert rate[-1] <= 7e-4                                            # the product default, at the timed batch size

@@ -21,19 +21,19 @@ def test_library_exports_every_declared_symbol():
     from maskbit_amd import _lib
     abi = open(os.path.join(ROOT, "include", "maskbit_hip.h")).read()
     header = abi + open(os.path.join(ROOT, "include", "maskbit_hip_diag.h")).read()
-    assert not re.findall(r"\b(mb_gemm[a-z0-9_]*|mb_layernorm[a-z0-9_]*|mb_w4[a-z0-9_]*|mb_set_cu_count)\s*\(", abi)
+    assert not re.findall(r"\b(mb_gemm[a-z0-9_]*|mb_layernorm[a-z0-9_]*|mb_w4[a-z0-9_]*|mb_set_cu_count|mb_gen_set_wcorr)\s*\(", abi)
     declared = set(re.findall(r"\b(mb_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mb_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.mb_abi_version() == _lib.ABI_VERSION == 7
     assert isinstance(lib.mb_last_error(), bytes)
 
 
 def test_struct_layouts_match_header():
     from maskbit_amd import _lib
-    assert ctypes.sizeof(_lib.GenCfg) == 13 * 4
+    assert ctypes.sizeof(_lib.GenCfg) == 11 * 4
     assert ctypes.sizeof(_lib.DecCfg) == (5 + 8 + 1 + 3) * 4
     assert ctypes.sizeof(_lib.SamplePlan) == 8 + 3 * 8 + 8
 

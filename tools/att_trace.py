@@ -56,8 +56,8 @@ def run():
     fn = lambda: lib.mb_debug_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), P, N, d, heads, st)
     plib = C.CDLL(os.path.join(ROOT, "maskbit_amd", "libmaskbit_hip.so"))           # the product library, for the uninstrumented time
     plib.mb_attention_pair.restype = C.c_int
-    plib.mb_attention_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    pfn = lambda: plib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), P, N, d, heads, st)
+    plib.mb_attention_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    pfn = lambda: plib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), P, N, d, heads, st)
     for _ in range(3): assert pfn() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -70,7 +70,7 @@ def run():
         qlib = C.CDLL(prev)
         qlib.mb_attention_pair.restype = C.c_int
         qlib.mb_attention_pair.argtypes = plib.mb_attention_pair.argtypes
-        qfn = lambda: qlib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), P, N, d, heads, st)
+        qfn = lambda: qlib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), P, N, d, heads, st)
         for rep in range(3):
             for name, f in (("previous build", qfn), ("product library", pfn)):
                 for _ in range(3): assert f() == 0

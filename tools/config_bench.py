@@ -47,7 +47,7 @@ def main():
           torch.cuda.synchronize()
           dt = (time.perf_counter() - t0) / n
           prof = _lib.prof_read(); _lib.prof_enable(False)
-          print(f"{name}: resolved precision (act_split, cfg_pair) = {gen.resolved_precision()}; {B / dt:.2f} images/s ({dt * 1e3:.0f} ms per batch of {B}; with the event pairs on every launch)", flush=True)
+          print(f"{name}: resolved LFQBert.precision = {gen.resolved_precision()}; {B / dt:.2f} images/s ({dt * 1e3:.0f} ms per batch of {B}; with the event pairs on every launch)", flush=True)
           for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
               print(f"    {k:16s} {c:6d} launches, {ms / c * 1e3:8.1f} us each, {ms / n:8.1f} ms per batch")
           del gen, tok

@@ -103,7 +103,7 @@ class Layer:
         ln = lambda: ck(lib.mb_layernorm(self.y.data_ptr(), self.g.data_ptr(), self.bt.data_ptr(), 1e-12, None, self.x.data_ptr(), None, self.stats.data_ptr(),
                                          2 * P, d, st))
         return [("qkv", lambda: gp(0, self.x, 0, None, None, self.qkv.data_ptr(), 3 * d, d)),
-                ("attention", lambda: ck(lib.mb_attention_pair(self.qkv.data_ptr(), self.att.data_ptr(), self.aux.data_ptr(), self.pairs, 257, d, 16, st))),
+                ("attention", lambda: ck(lib.mb_attention_pair(self.qkv.data_ptr(), self.att.data_ptr(), self.pairs, 257, d, 16, st))),
                 ("attn_out", lambda: gp(2, self.att, 1, self.y.data_ptr(), self.y.data_ptr(), None, d, d)),
                 ("layernorm", ln),
                 ("ffn_up", lambda: gp(1, self.x, 2, None, None, self.h.data_ptr(), f, d)),

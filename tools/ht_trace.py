@@ -48,7 +48,7 @@ def run(mode):
         res = torch.randn(M, N, device=dev) if epi == 2 else None
         o32 = torch.empty(M, N, device=dev) if epi == 2 else None
         o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if epi != 2 else None
-        nlo = int(os.environ.get("HT_MINI", "0"))        # with 1 / 2 MX-fp4 mini-tile operand sets on the conditional half (cfg_pair 2 / 3)
+        nlo = int(os.environ.get("HT_MINI", "0"))        # with 1 / 2 MX-fp4 mini-tile operand sets on the conditional half (precision 2 / 3)
         sets = []
         for _ in range(nlo):
             x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8)

@@ -13,9 +13,9 @@ GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C
           "trained-like weights: configs[1]": [R.RUN_CFG1_OUTLIER],
           "use_prenorm=True, configs[2]'s sampler (guided forward = plain forward over [cond | uncond])": [R.RUN_C3_PRENORM],
           "1024 + 1 tokens (512 x 512 models), configs[2]'s sampler (guided forward = plain forward over [cond | uncond])": [R.RUN_C3_SEQ1024]}
-MODES = (("default", -1, -1), ("differential only (cfg_pair = 1)", -1, 1))
-if os.environ.get("PARITY_MODES"):            # e.g. PARITY_MODES="default:-1:-1,fp16:0:0"
-    MODES = tuple((t.split(":")[0], int(t.split(":")[1]), int(t.split(":")[2])) for t in os.environ["PARITY_MODES"].split(","))
+MODES = (("default", -1), ("differential only (precision 1)", 1))
+if os.environ.get("PARITY_MODES"):            # e.g. PARITY_MODES="default:-1,fp16:0"   (tag:LFQBert.precision)
+    MODES = tuple((t.split(":")[0], int(t.split(":")[1])) for t in os.environ["PARITY_MODES"].split(","))
 only = set(sys.argv[1:])
 for grp, names in GROUPS.items():
     pooled = {m[0]: [0, 0] for m in MODES}
@@ -27,8 +27,8 @@ for grp, names in GROUPS.items():
         g = R.load_run(name)
         gen, _ = R.build_models("cuda", with_tokenizer=False, name=name)
         noise = R.reference_noise(g, gen.device)
-        for tag, asplit, pair in MODES:
-            gen.act_split, gen.cfg_pair = asplit, pair
+        for tag, prec in MODES:
+            gen.precision = prec
             bad, tot, per, _ = R.teacher_forced(gen, g, noise)
             pooled[tag][0] += bad; pooled[tag][1] += tot
             S = len(per)

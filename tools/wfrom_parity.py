@@ -11,7 +11,7 @@ for name in ("sample_full12_64", R.RUN_C3_S2, R.RUN_C3_S3):
     g = R.load_run(name)
     gen, _ = R.build_models("cuda", with_tokenizer=False, name=name)
     noise = R.reference_noise(g, gen.device)
-    gen.cfg_pair = 2
+    gen.precision = 2
     for wf in vals:
         gen.wcorr_from = wf
         bad, tot, per, _ = R.teacher_forced(gen, g, noise)
