@@ -433,7 +433,7 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
   if (ln_stats && (!ln_g || !ln_b || epi != mb::EPI_RES_F32)) return fail(-1, "mb_gemm_ex: LayerNorm residual needs gamma, beta and the fp32+residual epilogue");
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period, nullptr, ln_stats, ln_g, ln_b};
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the kernels' shapes", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -488,7 +488,7 @@ int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W
   mb::GemmArgs a{(const h16*)A_hi, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, 2 * kw, 0};
   a.A2 = (const h16*)A_lo; a.kw = kw;
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the kernels' shapes", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -533,7 +533,7 @@ int mb_gemm(int epi, const void* A, const void* W, const float* bias, const floa
   if (K % 64) return fail(-1, "mb_gemm: K must be a multiple of 64");
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, M, N, K, period};
   ProfScope p("gemm_diag", (hipStream_t)stream);
-  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the half-tile kernel (lo pass)", a.M, a.N, a.K);
+  if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, variant)) return fail(-3, "GEMM shape M=%d N=%d K=%d is outside the kernels' shapes", a.M, a.N, a.K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;

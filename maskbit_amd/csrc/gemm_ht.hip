@@ -53,7 +53,7 @@ namespace mb {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-// A fragment pair (two 16-byte LDS reads of one lane) lives in ONE 8-VGPR tuple: the e4m3 MFMA takes it whole, the f16 / fp4 MFMAs its halves
+// A fragment pair (two 16-byte LDS reads of one lane: k-steps 0 and 1 of a K-tile) lives in ONE 8-VGPR tuple; the f16 MFMAs take its halves
 typedef h16 h16x16 __attribute__((ext_vector_type(16)));
 
 // SEQ = true: "sequence-aligned" tiles.  The trunk's M is nb*257 (256 image tokens + the class token per

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-4 rocprofv3 evidence of the product default (guided forward with the weight-correction mini-tiles) on the GPU box (run through gpurun from the repo root):  bash tools/profile_round4.sh <tag>
+# rocprofv3 evidence (rounds 4-5) of the product default (guided forward with the weight-correction mini-tiles) on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh <tag>
 #   -> gpurun_out/prof_<tag>/{kt, pmc/<gemm>.<counter>, pmc/dec.<counter>}
 # Kernel-trace statistics of the default bench workload, then separate --pmc passes (never combined with other trace domains) over the
 # trunk GEMM shapes as the guided forward runs them (CFG pair tiles) and over the decoder.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
