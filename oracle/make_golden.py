@@ -123,6 +123,8 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # "trained-like" weights (heavy-tailed, six massive-activation channels: maskbit_amd/synth.py _trained_like) -- what per-row / per-block MX-fp4
     # scales and fp16 activations are sensitive to and Gaussian draws do not show
     "sample_full14_256_s3": (14, 181, 12.0, 4, CFG5_256, False, 4325, 8),
+    # round 5: a FOURTH 14-bit / 256-step run (batch 4) so that the worst single run of configs[4] (8.7e-4 on _s2, batch 2) has company (round-4 review, item 4)
+    "sample_full14_256_s4": (14, 183, 16.0, 4, CFG5_256, False, 4331, 12),
     "sample_full10_16_nocfg_s3": (10, 182, 12.0, 16, CFG1_16, False, 4330, 0),
     "sample_full12_64_outlier": (12, 190, 12.0, 4, FULL64, False, 4326, 2, "outlier"),
     "sample_full10_16_nocfg_outlier": (10, 191, 12.0, 16, CFG1_16, False, 4327, 0, "outlier"),

@@ -189,3 +189,29 @@ def test_host_noise_draws_restore_the_thread_pool_and_keep_the_stream():
     g = torch.distributions.Gumbel(0.0, 1.0)
     want = torch.stack([g.sample((2, 256, 2)) * 4.5 * (1 - (i + 1) / 3) for i in range(3)])
     assert torch.equal(conf, want)
+
+
+def test_precision_knob_resolution(monkeypatch):
+    """LFQBert.precision is the ONE precision knob (mb_gen_cfg.precision: 0 fp16, 1 differential guidance, 2 + weight-correction mini-tiles, 3 +
+    activation-lo mini-tiles): the default resolves by codebook and degrades by what the pair / mini tiles serve; the header's enum, the ctypes struct and
+    the host constants agree."""
+    from maskbit_amd import LFQBert, _lib
+    from maskbit_amd import bert as B
+    monkeypatch.delenv("MASKBIT_AMD_PRECISION", raising=False)
+    full = dict(hidden_dim=1024, depth=1, heads=16, mlp_dim=4096, codebook_splits=2)
+    assert LFQBert(codebook_size=4096, **full).resolved_precision() == B.PREC_WCORR == 2          # 6 bits per group
+    assert LFQBert(codebook_size=2 ** 14, **full).resolved_precision() == B.PREC_ALO == 3         # 7 bits per group
+    assert LFQBert(codebook_size=4096, img_size=512, **full).resolved_precision() == 2             # 1024 + 1 tokens: pair tiles since round 5
+    assert LFQBert(codebook_size=4096, use_prenorm=True, **full).resolved_precision() == 2
+    assert LFQBert(codebook_size=4096, hidden_dim=1024, depth=1, heads=32, mlp_dim=4096, codebook_splits=2).resolved_precision() == 1   # heads of 32: no e2m1 attention output
+    assert LFQBert(codebook_size=4096, hidden_dim=128, depth=1, heads=4, mlp_dim=256, codebook_splits=2).resolved_precision() == 1      # tiny: engine falls back to [cond | uncond] with hi + lo LayerNorm outputs
+    m = LFQBert(codebook_size=4096, **full)
+    for p in (0, 1, 2, 3):
+        m.precision = p
+        assert m.resolved_precision() == p
+    monkeypatch.setenv("MASKBIT_AMD_PRECISION", "1")
+    assert LFQBert(codebook_size=4096, **full).resolved_precision() == 1
+    hdr = open(os.path.join(ROOT, "include", "maskbit_hip.h")).read()
+    assert "MB_PREC_FP16 = 0, MB_PREC_DIFF = 1, MB_PREC_WCORR = 2, MB_PREC_ALO = 3" in hdr
+    assert [n for n, _ in _lib.GenCfg._fields_][-3:] == ["prenorm", "embed_tables", "precision"]
+    assert not re.search(r"\b(weight_split|act_split|cfg_pair)\b", hdr)
