@@ -24,7 +24,7 @@ from .base_model import BaseModel, ParamSpec
 #   PREC_FP16  0  single fp16 operands, the guided forward as independent streams (1.4e-3 token mismatch on configs[2]: a baseline, not a product mode)
 #   PREC_DIFF  1  classifier-free guidance in differential form; plain forwards with the LayerNorm outputs as fp16 hi + lo pairs (~1.0e-3: AT the bound)
 #   PREC_WCORR 2  + MX-fp4 weight-correction mini-tiles on every trunk GEMM, guided and plain (5.5e-4 over three reference runs of configs[2]; 5.3e-4 on configs[1])
-#   PREC_ALO   3  + activation-lo mini-tiles for the LayerNorm outputs of the guided forward (5.5e-4 on the 14-bit / 256-step runs)
+#   PREC_ALO   3  + activation-lo mini-tiles for the LayerNorm outputs feeding FFN-up in the guided forward (4.9e-4 over four 14-bit / 256-step runs)
 # -1 = auto: 2, or 3 from 7 bits per group on, degraded to what the shape allows (resolved_precision()).
 PREC_AUTO, PREC_FP16, PREC_DIFF, PREC_WCORR, PREC_ALO = -1, 0, 1, 2, 3
 DEFAULT_PRECISION = PREC_AUTO

@@ -117,10 +117,10 @@ struct mb_gen {
   // MX-fp4 weight-correction mini-tiles (gemm_ht.hip, XP = 6) -- in the guided forward on the conditional rows, in the plain forward (257-token sequences)
   // on every row: x4 / att4 / h4 hold e2m1 of the LayerNorm outputs, attention outputs and FFN hiddens (values; x4s / att4s / h4s their lane-ordered
   // block scales), w4lo / w4los e2m1 of the weights' fp16 rounding errors.  precision 3 additionally corrects the fp16 rounding of the LayerNorm OUTPUTS
-  // in the guided forward's QKV / FFN-up GEMMs: xl4 / xl4s = e2m1 of their lo halves, w4 / w4s = e2m1 of the (fp16) weights qkv / net.0.
+  // in the guided forward's FFN-up GEMM: xl4 / xl4s = e2m1 of their lo halves, w4 / w4s = e2m1 of the (fp16) weight net.0.
   bool pair_ok = false, mini_ok = false;
   uint8_t *x4 = nullptr, *x4s = nullptr, *xl4 = nullptr, *xl4s = nullptr;
-  std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {qkv, -, 1, -}]
+  std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {-, -, 1, -}]: net.0 only
   float* logits_tmp = nullptr;                          // guided forwards over more pairs than one pass holds
   // The two head GEMMs run hi + lo inputs against hi + lo WEIGHTS in every mode (GemmArgs.W2: three sweeps): their rounding reaches the logits
   // un-averaged -- fp16 head weights alone were a quarter of the sampled-logit error variance left after the trunk's weight correction
@@ -272,10 +272,16 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- an option
   // (mb_gen_set_wcorr_from), not the default
   const int wfrom = g->wcorr_from;
+  // precision 3: + activation-lo mini-tiles of the LayerNorm outputs in FFN-UP.  (Rounds 4 ran the set in QKV as well; over FOUR 14-bit / 256-step reference
+  // runs -- 1 002 744 positions -- the QKV set buys nothing: 496 mismatches with both, 491 with FFN-up alone, 555 with QKV alone, 625 with neither,
+  // profiles/raw/r05/alo_mask.log -- and costs 34 us per layer.)
   const bool alo = wmode && c.precision == 3;            // + activation-lo mini-tiles of the LayerNorm outputs (QKV / FFN-up)
-  auto f4_for = [&](int consumer_layer) {                // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
+  auto f4_for = [&](int consumer_layer, bool feeds_ffn = false) {   // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
-    if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) { f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; f.seq_rows = N; if (alo) { f.xl4 = g->xl4; f.xl4s = g->xl4s; } }
+    if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) {
+      f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; f.seq_rows = N;
+      if (alo && feeds_ffn) { f.xl4 = g->xl4; f.xl4s = g->xl4s; }        // (the lo halves' e2m1 copy: only the LayerNorm in front of FFN-up)
+    }
     return f;
   };
   // lo: 0 = fp16 only, 1 = weight-correction mini-tiles (a4 / a4s = e2m1 of the conditional operand values), 2 = + the activation-lo set (x only)
@@ -314,7 +320,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     const bool wl = wmode && l >= wfrom;
     const int xlo_mode = wl ? (alo ? 2 : 1) : 0;
     { ProfScope p("gemm_qkv", s, true);
-      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, xlo_mode, g->x4, g->x4s);
+      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wl ? 1 : 0, g->x4, g->x4s);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
     const bool wo4 = wl && (g->wcorr_mask & 2), wh4 = wl && (g->wcorr_mask & 8);
     { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
@@ -325,7 +331,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     // post-norm: LayerNorm 1 follows the attention block; pre-norm: LayerNorm 2 precedes the FFN (same place in the launch order, other parameters;
     // the stream buffer then holds the raw residual and no GEMM re-derives a LayerNorm from the statistics)
     { ProfScope p("layernorm", s, true);
-      rc |= layernorm_pair(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, g->x_h16, c.prenorm ? nullptr : g->ln_stats, P, d, f4_for(l)); }
+      rc |= layernorm_pair(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, g->x_h16, c.prenorm ? nullptr : g->ln_stats, P, d, f4_for(l, true)); }
     { ProfScope p("gemm_ffn_up", s, true);
       GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, xlo_mode, g->x4, g->x4s);
       if (wh4) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
@@ -613,7 +619,6 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
       rc |= galloc(g, &g->w4lo[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4los[4 * l + 2], f);
       rc |= galloc(g, &g->w4lo[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4los[4 * l + 3], d);
       if (c.precision == 3) {
-        rc |= galloc(g, &g->w4[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4s[4 * l], 3 * d);
         rc |= galloc(g, &g->w4[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4s[4 * l + 2], f);
       }
     }

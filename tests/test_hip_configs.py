@@ -115,10 +115,11 @@ def test_baseline_config1_10bit_16steps_nocfg_vs_reference_runs():
 @pytest.mark.timeout(1500)
 def test_baseline_config5_14bit_256steps_vs_reference_runs():
     """BASELINE configs[4]'s generator and sampler as named -- 14-bit (C = 128 per group), 256 steps, CFG 5.8 cosine (configs/generator/
-    maskbit_generator_14bit_256steps.yaml:38-44) -- against THREE 256-step runs of the real reference (B = 2, 2 and 4: 668 496 sampled positions).
+    maskbit_generator_14bit_256steps.yaml:38-44) -- against FOUR 256-step runs of the real reference (B = 2, 2, 4 and 4: 1 002 744 sampled positions).
     MEASURED: the differential form alone misses 1e-3 here (1.4e-3; single fp16: 2.0e-3); with the weight-correction mini-tiles and hi/lo head
     weights (precision 2) the first run measures 6.6e-4; the product default at 7 bits per group (precision 3: + the activation-lo mini-tiles of the
-    LayerNorm outputs) 5.4e-4 / 8.6e-4 / 4.2e-4 = 5.6e-4 over all.  Asserted without allowance: <= 1e-3 on each run, <= 7e-4 over all."""
+    LayerNorm outputs, since round 5 in FFN-up only: the QKV set measured no gain over the four runs) 4.8e-4 / 8.3e-4 / 4.4e-4 / 3.7e-4 = 4.9e-4
+    over all; without the set 6.2e-4 over all and 1.05e-3 on the second run.  Asserted without allowance: <= 1e-3 on each run, <= 6e-4 over all."""
     import parity_replay as R
     r = _vs_reference_run(R.RUN_CFG5, [("product default", -1), ("weight correction + activation-lo pass", 3),
                                        ("weight correction alone", 2), ("differential operands only", 1), ("single fp16", 0)])
@@ -129,12 +130,12 @@ def test_baseline_config5_14bit_256steps_vs_reference_runs():
         bad, tot = r[tag]
         assert bad / tot <= 1e-3, tag
     tb, tt = r["product default"]
-    for name in (R.RUN_CFG5_S2, R.RUN_CFG5_S3):
+    for name in (R.RUN_CFG5_S2, R.RUN_CFG5_S3, R.RUN_CFG5_S4):
         bad, tot = _vs_reference_run(name, [("product default", -1)])["product default"]
         assert bad / tot <= 1e-3, name
         tb += bad; tt += tot
-    print(f"configs[4], three reference runs, product default: {tb}/{tt} = {tb / tt:.2e}")
-    assert tt == 668496 and tb / tt <= 7e-4
+    print(f"configs[4], four reference runs, product default: {tb}/{tt} = {tb / tt:.2e}")
+    assert tt == 1002744 and tb / tt <= 6e-4
 
 
 @pytest.mark.timeout(900)
