@@ -187,12 +187,14 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   };
   int attn_rc = 0, gemm_rc = 0;
   // The plain forward (mb_gen_forward, sampling without guidance, the zero-scale steps of a guided run), by precision:
-  //   >= 1: the LayerNorm outputs enter QKV / FFN-up as fp16 hi + lo pairs (x_h16 + x_lo: those two GEMMs sweep their weight twice, K = 2d);
+  //   >= 1: the LayerNorm output enters FFN-UP as an fp16 hi + lo pair (x_h16 + x_lo: that GEMM sweeps its weight twice, K = 2d).  Rounds 3-4 did the
+  //         same in QKV; over configs[1]'s three reference runs + the trained-like one (348 160 positions) the QKV sweep buys nothing -- 153 mismatches
+  //         with both, 158 with FFN-up alone, 192 with QKV alone, 195 with neither (profiles/raw/r05/xlo_mask.log) -- and costs 19-69 us per layer;
   //   >= 2 (257-token sequences): all four trunk GEMMs also carry the MX-fp4 weight-correction mini-tiles on every row -- the fp16 rounding of the
   //         WEIGHTS is 80 % of the sampled-logit error variance here (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
   //         activation pairs, 0.0045 with the weight correction alone); both together: 5.3e-4 over configs[1]'s three reference runs.
   const bool xlo = c.precision >= 1;
-  h16* const xlo_trunk = xlo ? g->x_lo : nullptr;        // LayerNorms that feed trunk GEMMs write lo halves only when those GEMMs use them
+  h16* const xlo_ffn = xlo ? g->x_lo : nullptr;          // the LayerNorm in front of FFN-up writes lo halves (the one in front of QKV does not; the last one feeds the head)
   const bool wm = g->mini_ok && c.seq == 256 && c.precision >= 2;   // (plain sequence tiles are 256 + 1 rows)
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
   Fp4Rows f4x;
@@ -207,7 +209,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d, 0};
     lo_set(ga, g->x4, g->x4s, widx);
     if (wm && epi == EPI_GELU_H16 && (g->wcorr_mask & 8)) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
-    if (xlo) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }
+    if (xlo && (widx & 3) == 2) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }   // FFN-up only (see above)
     ga.sat = g->sat;
     gemm_rc |= gemm_tn(s, epi, ga, wm ? 257 : 0);
   };
@@ -222,7 +224,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     ProfScope p("embed_ln", s, true);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
-    e.x_lo = c.depth ? xlo_trunk : g->x_lo;
+    e.x_lo = c.depth ? nullptr : g->x_lo;
     e.f4 = f4x;
     embed_ln(s, e);
   }
@@ -232,7 +234,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // fp16 GEMM operand and {mean, rstd}, the next residual GEMM re-derives the normalised rows in its epilogue and updates y_f32 in place (layer 0's
     // first residual is the embedding LayerNorm output, stored as is by embed_ln).  use_prenorm (bert.py:49-59, 106-123): x = x + Attn(LN(x));
     // x = x + FFN(LN(x)): the buffer holds x itself, every LayerNorm only produces the GEMM operand, the residual GEMMs add the buffer's own rows.
-    if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_trunk, f4x); }
+    if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, nullptr, f4x); }
     { ProfScope p("gemm_qkv", s, true); xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, 4 * l); }
     { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
     attn_rc |= attn_maps(l);
@@ -240,13 +242,13 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       const bool re = !c.prenorm && l > 0;
       rgemm(g->att, L.wo, L.bo, d, 4 * l + 1, g->att4, g->att4s, re ? g->layers[l - 1].ln2g : nullptr, re ? g->layers[l - 1].ln2b : nullptr); }
     { ProfScope p("layernorm", s, true);
-      layernorm_rows(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, nullptr, g->x_h16, c.prenorm ? nullptr : g->ln_stats, M, d, xlo_trunk, f4x); }
+      layernorm_rows(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, nullptr, g->x_h16, c.prenorm ? nullptr : g->ln_stats, M, d, xlo_ffn, f4x); }
     { ProfScope p("gemm_ffn_up", s, true); xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, 4 * l + 2); }
     { ProfScope p("gemm_ffn_down", s, true);
       rgemm(g->h, L.w2, L.b2, f, 4 * l + 3, g->h4, g->h4s, c.prenorm ? nullptr : L.ln1g, c.prenorm ? nullptr : L.ln1b); }
     if (!c.prenorm) { ProfScope p("layernorm", s, true);
       const bool last = l + 1 == c.depth;                  // the last one feeds the head: plain hi + lo rows
-      layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, last ? g->x_lo : xlo_trunk, last ? Fp4Rows{} : f4x); }
+      layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, last ? g->x_lo : nullptr, last ? Fp4Rows{} : f4x); }
   }
   if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }   // norm_after_transformer
   gemm_rc |= head_gemms(g, logits, M, s);

@@ -51,8 +51,8 @@ def test_generator_forward_full12_vs_reference_golden():
 
 
 def test_generator_plain_forward_precision_modes_full12_and_tiny():
-    """The plain forward() under the engine's ONE precision knob (LFQBert.precision): 0 = single fp16 operands; 1 = + the LayerNorm outputs as fp16
-    hi + lo pairs into QKV / FFN-up (the GEMM-input rounding is 13 % of the error variance); 2 = + the MX-fp4 weight-correction mini-tiles on every
+    """The plain forward() under the engine's ONE precision knob (LFQBert.precision): 0 = single fp16 operands; 1 = + the LayerNorm output in front of
+    FFN-up as an fp16 hi + lo pair (the GEMM-input rounding is 13 % of the error variance); 2 = + the MX-fp4 weight-correction mini-tiles on every
     trunk GEMM (the weights' rounding is most of the rest).  Each step moves the logits closer to the reference's fp32 golden; batch invariance holds
     bit for bit in every mode; switching the mode on a live model rebuilds the engine.  The tiny model (128-square GEMM kernel, no pair / mini tiles)
     runs modes >= 1 with hi + lo LayerNorm outputs alone."""
@@ -72,7 +72,7 @@ def test_generator_plain_forward_precision_modes_full12_and_tiny():
         nb = args[0].shape[0]
         assert torch.equal(rep[:nb], rep[-nb:]) and abs(rel_fro(rep[:nb], ref) - err[prec]) < 2e-5
     print(f"rel-Frobenius logit error: single fp16 {err[0]:.2e}, hi + lo LayerNorm outputs {err[1]:.2e}, + weight correction {err[2]:.2e}")
-    assert err[1] < 0.98 * err[0] and err[2] < 0.75 * err[1]
+    assert err[1] < 0.995 * err[0] and err[2] < 0.75 * err[1]
     m.precision = 0
     assert abs(rel_fro(m(*args), ref) - err[0]) < 1e-9
     m.precision = -1
