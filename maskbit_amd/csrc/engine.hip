@@ -274,15 +274,18 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- an option
   // (mb_gen_set_wcorr_from), not the default
   const int wfrom = g->wcorr_from;
-  // precision 3: + activation-lo mini-tiles of the LayerNorm outputs in FFN-UP.  (Rounds 4 ran the set in QKV as well; over FOUR 14-bit / 256-step reference
-  // runs -- 1 002 744 positions -- the QKV set buys nothing: 496 mismatches with both, 491 with FFN-up alone, 555 with QKV alone, 625 with neither,
-  // profiles/raw/r05/alo_mask.log -- and costs 34 us per layer.)
-  const bool alo = wmode && c.precision == 3;            // + activation-lo mini-tiles of the LayerNorm outputs (QKV / FFN-up)
+  // precision 3: + activation-lo mini-tiles of the LayerNorm outputs in FFN-UP of the layers >= depth / 2.  Round 4 ran the set in QKV and FFN-up of every
+  // layer.  Over FOUR 14-bit / 256-step reference runs (1 002 744 positions; profiles/r05_coverage.md, raw/r05/alo_mask.log, alo_layers.log): both GEMMs,
+  // all layers 496 mismatches; FFN-up alone 491-493; QKV alone 555; neither 625 -- the QKV set buys nothing and cost 34 us per layer.  FFN-up set by
+  // layer range: [0, 24) 493, [12, 24) 531, [18, 24) 560, [6, 18) 579, [0, 12) 612, [0, 6) 627 -- the late layers carry the gain: the second half
+  // keeps 70 % of it (5.3e-4 pooled, the worst single run 8.7e-4 against 8.3e-4) for half of the 84 us per layer.
+  const bool alo = wmode && c.precision == 3;
+  auto alo_layer = [&](int l) { return alo && 2 * l >= c.depth; };
   auto f4_for = [&](int consumer_layer, bool feeds_ffn = false) {   // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
     if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) {
       f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; f.seq_rows = N;
-      if (alo && feeds_ffn) { f.xl4 = g->xl4; f.xl4s = g->xl4s; }        // (the lo halves' e2m1 copy: only the LayerNorm in front of FFN-up)
+      if (feeds_ffn && alo_layer(consumer_layer)) { f.xl4 = g->xl4; f.xl4s = g->xl4s; }        // (the lo halves' e2m1 copy: only the LayerNorm in front of such an FFN-up)
     }
     return f;
   };
@@ -320,7 +323,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     const bool wl = wmode && l >= wfrom;
-    const int xlo_mode = wl ? (alo ? 2 : 1) : 0;
+    const int xlo_mode = wl ? (alo_layer(l) ? 2 : 1) : 0;
     { ProfScope p("gemm_qkv", s, true);
       GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wl ? 1 : 0, g->x4, g->x4s);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
