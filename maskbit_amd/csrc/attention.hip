@@ -448,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
   }
   const int q = qt * 16 + l15;
   const float inv = 1.0f / l_run;
-  if constexpr (PAIRM && DH == 64) {
-    if (out4s && pass == 0) {                              // block (row, head) = this lane's 16 values x its 4 lane groups (cf. attention_kernel)
+  if constexpr (DH == 64) {
+    if (out4s && pass == 0) {                              // (plain form: every sequence; pair form: the conditional ones)                              // block (row, head) = this lane's 16 values x its 4 lane groups (cf. attention_kernel)
       float am = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -549,7 +549,7 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
   if (N > ATT_NP) {                                           // longer than one head's K/V fits in LDS: streaming kernel
     const int nchunk = (N + 63) / 64;
     dim3 grid(nb * heads * nchunk), block(256);
-    if (dh == 64) hipLaunchKernelGGL(attention_long_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e);
+    if (dh == 64) hipLaunchKernelGGL(attention_long_kernel<64>, grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e, 0, (N - 1) % 64 ? nullptr : out4, (N - 1) % 64 ? nullptr : out4s, nb);
     else hipLaunchKernelGGL(attention_long_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e);
     return;
   }

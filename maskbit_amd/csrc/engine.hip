@@ -190,15 +190,15 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   //   >= 1: the LayerNorm output enters FFN-UP as an fp16 hi + lo pair (x_h16 + x_lo: that GEMM sweeps its weight twice, K = 2d).  Rounds 3-4 did the
   //         same in QKV; over configs[1]'s three reference runs + the trained-like one (348 160 positions) the QKV sweep buys nothing -- 153 mismatches
   //         with both, 158 with FFN-up alone, 192 with QKV alone, 195 with neither (profiles/raw/r05/xlo_mask.log) -- and costs 19-69 us per layer;
-  //   >= 2 (257-token sequences): all four trunk GEMMs also carry the MX-fp4 weight-correction mini-tiles on every row -- the fp16 rounding of the
+  //   >= 2: all four trunk GEMMs also carry the MX-fp4 weight-correction mini-tiles on every row -- the fp16 rounding of the
   //         WEIGHTS is 80 % of the sampled-logit error variance here (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
   //         activation pairs, 0.0045 with the weight correction alone); both together: 5.3e-4 over configs[1]'s three reference runs.
   const bool xlo = c.precision >= 1;
   h16* const xlo_ffn = xlo ? g->x_lo : nullptr;          // the LayerNorm in front of FFN-up writes lo halves (the one in front of QKV does not; the last one feeds the head)
-  const bool wm = g->mini_ok && c.seq == 256 && c.precision >= 2;   // (plain sequence tiles are 256 + 1 rows)
+  const bool wm = g->mini_ok && c.precision >= 2;   // (sequence tiles: 256 + 1 rows, or four tiles per 1024 + 1-row sequence)
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
   Fp4Rows f4x;
-  if (wm && (g->wcorr_mask & 5)) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; }
+  if (wm && (g->wcorr_mask & 5)) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; f4x.seq_rows = N; }
   const bool wo4 = wm && (g->wcorr_mask & 2);
   auto lo_set = [&](GemmArgs& ga, const uint8_t* a4, const uint8_t* a4s, int widx) {
     if (!wm || !((g->wcorr_mask >> (widx & 3)) & 1)) return;
@@ -207,6 +207,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   // QKV / FFN-up: consume the LayerNorm output
   auto xgemm = [&](GemmEpi epi, const h16* W, const float* bias, h16* out, int Nout, int widx) {
     GemmArgs ga{g->x_h16, W, bias, nullptr, nullptr, out, M, Nout, d, 0};
+    if (wm) ga.seq_rows = N;
     lo_set(ga, g->x4, g->x4s, widx);
     if (wm && epi == EPI_GELU_H16 && (g->wcorr_mask & 8)) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
     if (xlo && (widx & 3) == 2) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }   // FFN-up only (see above)
@@ -217,6 +218,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   auto rgemm = [&](const h16* A, const h16* W, const float* bias, int K, int widx, const uint8_t* a4, const uint8_t* a4s, const float* ln_g, const float* ln_b) {
     GemmArgs ga{A, W, bias, g->y_f32, g->y_f32, nullptr, M, d, K, 0};
     if (ln_g) { ga.ln_stats = g->ln_stats; ga.ln_g = ln_g; ga.ln_b = ln_b; }
+    if (wm) ga.seq_rows = N;
     lo_set(ga, a4, a4s, widx);
     gemm_rc |= gemm_tn(s, EPI_RES_F32, ga, wm ? 257 : 0);
   };
@@ -455,9 +457,10 @@ int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const
 }
 int mb_gemm_mini_seq(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
                      void* out4_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream) {
-  if (!A || !W || !bias || epi < 0 || epi > 2 || rows <= 0 || K <= 0 || K % 64 || nlo < 0 || nlo > 2 || (nlo && !lo) || (seq_rows && !pair)) return fail(-1, "mb_gemm_mini: bad arguments");
+  if (!A || !W || !bias || epi < 0 || epi > 2 || rows <= 0 || K <= 0 || K % 64 || nlo < 0 || nlo > 2 || (nlo && !lo)) return fail(-1, "mb_gemm_mini: bad arguments");
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, pair ? 2 * rows : rows, N, K, 0};
-  if (pair) { a.pair_rows = rows; a.seq_rows = seq_rows; }
+  if (pair) a.pair_rows = rows;
+  a.seq_rows = seq_rows;
   a.nlo = nlo;
   for (int i = 0; i < nlo; ++i) a.lo[i] = {(const uint8_t*)lo[4 * i], (const uint8_t*)lo[4 * i + 1], (const uint8_t*)lo[4 * i + 2], (const uint8_t*)lo[4 * i + 3]};
   a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale;

@@ -154,7 +154,7 @@ int gemm_tn(hipStream_t s, GemmEpi epi, const GemmArgs& a, int variant) {
   // (the caller reports it; nothing is launched).
   if (a.W2 && (!a.A2 || !a.kw || a.K != 3 * a.kw || !a.scale)) return -1;
   if (variant >= 0 && !a.W2 && gemm_ht_supported(epi, a)) {
-    if (variant % 1000 == 257 && a.M % 257) variant = variant - variant % 1000;
+    if (variant % 1000 == 257 && a.M % (a.seq_rows ? a.seq_rows : 257)) variant = variant - variant % 1000;
     gemm_ht(s, epi, a, variant);
     return 0;
   }

@@ -58,7 +58,7 @@ typedef h16 h16x16 __attribute__((ext_vector_type(16)));
 
 // SEQ = true: "sequence-aligned" tiles.  The trunk's M is nb*257 (256 image tokens + the class token per
 // sequence) and 257 is prime, so every ordinary tiling leaves a nearly empty CU round.  With SEQ a tile covers exactly
-// one sequence: 256 rows through the regular MT = 8 machinery plus the class-token row as a 17th, one-row m-tile whose
+// one sequence (GemmArgs.seq_rows = 1025, the 512 x 512 models: a quarter of one, the last quarter with the class token): 256 rows through the regular MT = 8 machinery plus the class-token row as a 17th, one-row m-tile whose
 // 4 n-tiles are split between the two wave rows (wm = 0 takes the B0 half in phase 0, wm = 1 the B1 half in phase 1:
 // +4 MFMAs per wave per K-tile).  The extra row lives in a 1 KiB "X" buffer per parity, re-filled by one extra DMA
 // instruction of wave 7 in phase 3.  tiles = nb * N/256: whole CU rounds for nb = 128.
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   constexpr int X_BYTES = SEQ ? 1024 : 0;
   constexpr int PAR_BYTES = 2 * AH_BYTES + 2 * BH_BYTES + X_BYTES;
   constexpr int MINI_OFF = 2 * PAR_BYTES;
-  constexpr int TILE_ROWS = SEQ ? 257 : BM;
   constexpr int A_INSTR = AH_ROWS / 8;                 // 1 KiB DMA instructions per A half-tile (12 or 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -126,9 +125,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // split activations (A2 / kw): K-tiles >= nka read the lo halves A2 against the same W columns
   const h16* const Alo = a.A2 ? a.A2 : a.A;
   const h16* const Wlo = a.W;
-  // pair tiles: SQ rows per sequence (class token last), TPS = (SQ - 1) / 128 tiles per sequence pair (2 or 8: a power of two), 2 TPS groups of 64 tokens
+  // sequence tiles: SQ rows per sequence (class token last), TPS tiles per sequence (pair) -- a power of two: (SQ - 1) / 128 pair tiles (2 or 8) of 2 groups
+  // of 64 tokens, (SQ - 1) / 256 plain tiles (1 or 4) of 4 groups; the LAST tile of a sequence computes and stores the class-token row(s)
   const int SQ = a.seq_rows ? a.seq_rows : 257;
-  const int tps_sh = PAIR ? 31 - __builtin_clz((unsigned)((SQ - 1) >> 7)) : 1;
+  const int tps_sh = 31 - __builtin_clz((unsigned)((SQ - 1) >> (PAIR ? 7 : 8)));
   const int TPS = 1 << tps_sh;
   const int ntiles = tiles_m * tiles_n;
 
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   struct Plan {
     uint32_t offA[2][2], offB[2][2], offX;   // element offsets into A / W
     int m0, n0;
-    int cls;                                 // PAIR: the conditional class-token row of this tile's sequence pair; odd tiles store it
-    int q;                                   // PAIR: which 128-token half of the sequence this tile covers
+    int cls;                                 // SEQ: the (conditional) class-token row of this tile's sequence (pair); its last tile stores it
+    int q;                                   // SEQ: which 256-token (pair: 128-token) part of the sequence this tile covers
     int seq;                                 // SEQ: the (conditional) sequence of this tile
     int hb;                                  // NS > 1: which 64 / NS-column block of every wave's 64 columns this tile computes
   };
@@ -152,10 +152,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     const int rows_sr = min(8, tiles_m - sr * 8);
     const int rem = L - sr * 8 * tiles_n;
     const int tn = rem / rows_sr, tm = sr * 8 + (rem - tn * rows_sr);
-    p.m0 = PAIR ? (tm >> tps_sh) * SQ + (tm & (TPS - 1)) * 128 : tm * TILE_ROWS; p.n0 = (tn / NS) * 256;
+    p.m0 = SEQ ? (tm >> tps_sh) * SQ + (tm & (TPS - 1)) * (PAIR ? 128 : 256) : tm * BM; p.n0 = (tn / NS) * 256;
     p.hb = tn % NS;
-    p.cls = PAIR ? (tm >> tps_sh) * SQ + SQ - 1 : 0; p.q = tm & (TPS - 1);
-    p.seq = PAIR ? tm >> tps_sh : tm;
+    p.cls = SEQ ? (tm >> tps_sh) * SQ + SQ - 1 : 0; p.q = SEQ ? tm & (TPS - 1) : 0;
+    p.seq = SEQ ? tm >> tps_sh : tm;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ja = min(wave + 8 * j, A_INSTR - 1);   // surplus slot re-loads the last chunk (uniform vmcnt)
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       }
     }
     // X: the class-token row of this sequence, 8 identical source rows (only LDS row 0 is ever consumed)
-    p.offX = (uint32_t)(PAIR ? p.cls + ((lane_o >> 3) == 1 ? a.pair_rows : 0) : min(p.m0 + 256, a.M - 1)) * (uint32_t)KA + ((lane_o & 7) ^ MB_SWZ(lane_o >> 3)) * 8;
+    p.offX = (uint32_t)(PAIR ? p.cls + ((lane_o >> 3) == 1 ? a.pair_rows : 0) : min(p.cls, a.M - 1)) * (uint32_t)KA + ((lane_o & 7) ^ MB_SWZ(lane_o >> 3)) * 8;
   };
   // trace builds, modes 3 / 4: the K loop's DMA is dropped / re-reads K-tiles 0 and 1 (always L2 hits) -- what the loop costs without (slow) memory
 #if defined(MB_HT_TRACE) && MB_HT_TRACE == 3
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // (KM: the K extent of the operands = of the corrections; with split activations -- A2 / kw, plain tiles -- the fp16 sweep is twice as long)
   const int KM = a.kw ? a.kw : K;
   const int nmk = KM / 128;
-  const int nseq = PAIR ? a.pair_rows / SQ : a.M / 257;
-  const int grp_bytes = PAIR ? TPS * 128 : 256;          // scale bytes per (64-column block, sequence): 64 per 64-token group
+  const int nseq = PAIR ? a.pair_rows / SQ : a.M / SQ;
+  const int grp_bytes = PAIR ? TPS * 128 : TPS * 256;    // scale bytes per (64-column block, sequence): 64 per 64-token group
   const bool mini_every = MINI && (PAIR ? a.nlo == 2 : !a.kw);   // one mini-tile per fp16 K-tile (else one per two)
   auto mini_lane = [&]() -> uint32_t {
     int lo_ = lane; asm volatile("" : "+v"(lo_));
@@ -247,8 +247,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   // the token operand's scale dword of this lane for mini j: its four m-tiles' bytes of block 2 jj + (lane >= 32) (GemmArgs.lo: lane order)
   auto mini_scale_off = [&](const Plan& p, int j) -> uint32_t {
     const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
-    const int gq = PAIR ? p.q * 2 + wm : wm * 2 + ps;
+    const int gq = PAIR ? p.q * 2 + wm : p.q * 4 + wm * 2 + ps;
     int lo_ = lane; asm volatile("" : "+v"(lo_));
+    if constexpr (!PAIR) return ((((uint32_t)(2 * jj + (lo_ >> 5)) * nseq + p.seq) << tps_sh) << 8) + gq * 64 + (lo_ & 15) * 4;   // (grp_bytes = 256 TPS)
     return ((uint32_t)(2 * jj + (lo_ >> 5)) * nseq + p.seq) * grp_bytes + gq * 64 + (lo_ & 15) * 4;
   };
   int mwsc0 = 0, mwsc1 = 0, mxs = 0;                    // MINI: weight scale dwords of the (two) operand sets, the current mini's token scale dword
@@ -356,11 +357,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acce[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // SEQ: class row x this wave row's 2 n-tiles
-    // pair tiles: both 128-token halves of a sequence pair stage the class rows, only the second one (q == 1) stores them -- the first skips their MFMAs
+    // every tile of a sequence (pair) stages the class row(s), only the last one stores them -- the others skip their MFMAs
 #ifdef MB_NO_CLS                                            /* experiment (timing only): what the class-token rows' MFMAs and fragment reads cost */
     const bool cls_on = false;
 #else
-    const bool cls_on = !PAIR || __builtin_amdgcn_readfirstlane(cur.q) == TPS - 1;
+    const bool cls_on = __builtin_amdgcn_readfirstlane(cur.q) == TPS - 1;
 #endif
     h16x16 xa[MH], wb[2][2];      // wb[0] (the B0 fragments) is kept from phase 0 to phase 3: every operand fragment is read once per K-tile
 
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     asm volatile("" : "+v"(l15e), "+v"(ge));             // carried in VGPRs through the main loop
     auto row_of = [&](int r) {
       if (PAIR) return r < MT ? m0 + (r / MH) * a.pair_rows + wm * 64 + (r % MH) * 16 + l15e : clsrow + (l15e == 1 ? a.pair_rows : 0);
-      return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : m0 + 256;
+      return r < MT ? m0 + wm * (16 * MT) + (r / MH) * (8 * MT) + (r % MH) * 16 + l15e : clsrow;
     };
     auto col_of = [&](int r, int nt) {
       if (HN) return n0 + wn * 64 + cur.hb * (64 / NS) + (nt & (NTW - 1)) * 16 + ge * 4;      // (this tile's block of the wave's columns)
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     };
     auto row_ok = [&](int r) {
       if (PAIR) return r < MT ? true : (l15e < 2 && tq == TPS - 1);
-      return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : (l15e == 0 && (!HN || wm == 0));
+      return r < MT ? row_of(r) < (SEQ ? m0 + 256 : a.M) : (l15e == 0 && (!HN || wm == 0) && tq == TPS - 1);
     };
     // ---- next tile: start its first two K-tiles NOW (all LDS is free), so they fly during the epilogue math.
     // The bias of THIS tile is fetched in between by inline-asm loads the compiler does not track: vmcnt retires in
@@ -608,8 +609,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         // block (4 n-tiles x 4 lane groups x 4 columns), and the four m-tiles of a lane in one 64-row group are one dword of the lane-ordered scale
         // array (GemmArgs.lo); class-token rows are skipped (they take no part in those passes)
         const uint32_t blk = (uint32_t)(n0 >> 6) + wn;
-        const uint32_t nsq = PAIR ? (uint32_t)a.pair_rows / (uint32_t)SQ : (uint32_t)a.M / 257;
-        const uint32_t ngrp = PAIR ? (uint32_t)TPS * 2 : 4u;
+        const uint32_t nsq = (uint32_t)(PAIR ? a.pair_rows : a.M) / (uint32_t)SQ;
+        const uint32_t ngrp = (uint32_t)TPS * (PAIR ? 2 : 4);
 #pragma unroll
         for (int hh = 0; hh < (PAIR ? 1 : 2); ++hh) {
           uint32_t sc4 = 0;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #endif
             *(uint2*)(a.out4 + (size_t)row * 2 * a.N + ((n0 + wn * 64) >> 1) + (ge >> 1) * 16 + (ge & 1) * 8) = make_uint2(sx[0], sx[1]);
           }
-          const uint32_t gq = PAIR ? (uint32_t)tq * 2 + wm : (uint32_t)wm * 2 + hh;
+          const uint32_t gq = PAIR ? (uint32_t)tq * 2 + wm : (uint32_t)tq * 4 + wm * 2 + hh;
           if (ge == 0) ((uint32_t*)a.out4_scale)[((blk * nsq + (uint32_t)cur.seq) * ngrp + gq) * 16 + l15e] = sc4;
         }
       }
@@ -825,7 +826,7 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
     configured = true;
   }
   const int sq_rows = a.seq_rows ? a.seq_rows : 257;
-  const int tiles_m = PAIR ? (a.pair_rows / sq_rows) * ((sq_rows - 1) / 128) : (SEQ ? a.M / 257 : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * NS;
+  const int tiles_m = PAIR ? (a.pair_rows / sq_rows) * ((sq_rows - 1) / 128) : (SEQ ? (a.M / sq_rows) * ((sq_rows - 1) / 256) : (a.M + BM - 1) / BM), tiles_n = (a.N / 256) * NS;
   static const bool res_persist = !getenv("MASKBIT_AMD_RES_PERSIST") || atoi(getenv("MASKBIT_AMD_RES_PERSIST")) != 0;   // A/B switch (experiments)
   if (EPI == EPI_RES_F32 && !res_persist) persistent = false;
   const int grid = persistent ? std::min(tiles_m * tiles_n, num_cu_cached()) : tiles_m * tiles_n;   // persistent: one workgroup per CU walks the tile list
@@ -834,10 +835,11 @@ static void launch_ht(hipStream_t s, const GemmArgs& a, bool persistent = true) 
 
 bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
   const int sqr = a.seq_rows ? a.seq_rows : 257;
-  if (a.seq_rows && (!a.pair_rows || (sqr - 1) % 128 || ((sqr - 1) / 128 & ((sqr - 1) / 128 - 1)))) return false;   // pair tiles only; 128-token tiles, a power of two per sequence
+  const int tok = a.pair_rows ? 128 : 256;                                                                  // tokens of a sequence tile
+  if (a.seq_rows && ((sqr - 1) % tok || ((sqr - 1) / tok & ((sqr - 1) / tok - 1)) || (!a.pair_rows && a.M % sqr))) return false;   // sequence tiles: whole tiles, a power of two per sequence
   if (a.pair_rows && (a.pair_rows % sqr || a.M != 2 * a.pair_rows || a.A2 || epi == EPI_GELU_F32)) return false;
   // (plain tiles may combine the mini-tiles with split activations: A2 / kw, K = 2 kw -- hi + lo LayerNorm outputs AND the weight correction)
-  if (a.nlo && (a.nlo > 2 || (a.pair_rows ? a.pair_rows % sqr : a.M % 257) || (a.kw ? a.kw : a.K) % 128 || (!a.pair_rows && a.nlo != 1) ||
+  if (a.nlo && (a.nlo > 2 || (a.pair_rows ? a.pair_rows % sqr : a.M % sqr) || (a.kw ? a.kw : a.K) % 128 || (!a.pair_rows && a.nlo != 1) ||
                 ((a.A2 || a.kw) && (a.pair_rows || !a.A2 || a.K != 2 * a.kw)) ||
                 !a.lo[0].A4 || !a.lo[0].W4 || !a.lo[0].a_scale || !a.lo[0].w_scale ||
                 (a.nlo == 2 && (!a.lo[1].A4 || !a.lo[1].W4 || !a.lo[1].a_scale || !a.lo[1].w_scale)) || (uint64_t)a.M * a.K * 2 >= (1ull << 32) ||
@@ -849,6 +851,8 @@ bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a) {
 
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
   bool persistent = true;
+  const int sqr = a.seq_rows ? a.seq_rows : 257;
+  const long seq_tiles = (long)(a.M / sqr) * ((sqr - 1) / 256);          // plain sequence tiles of this GEMM's rows
   if (mt >= 1000) { persistent = false; mt -= 1000; }   // A/B: one tile per workgroup
   if (mt != 6 && mt != 8 && mt != 257) {
     // pick the tile height that wastes fewer CU-rounds (one workgroup per CU)
@@ -858,8 +862,8 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
       return (double)((tiles + num_cu - 1) / num_cu) * 32 * m * (m == 8 ? 1.0 : 1.04);
     };
     mt = cost(8) <= cost(6) ? 8 : 6;
-    if (a.M % 257 == 0) {          // one tile per sequence: costs 272/256 of the MFMA work but leaves no ragged round
-      const long tiles = (long)(a.M / 257) * (a.N / 256);
+    if (a.M % sqr == 0) {          // sequence tiles: cost 272/256 of the MFMA work (257-token sequences) but leave no ragged round
+      const long tiles = (long)(a.M / sqr) * ((sqr - 1) / 256) * (a.N / 256);
       if ((double)((tiles + num_cu - 1) / num_cu) * 272 < cost(mt)) mt = 257;
     }
   }
@@ -870,8 +874,8 @@ void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt) {
       case EPI_RES_F32:
         if (a.pair_rows) launch_ht<8, EPI_RES_F32, 6, true, true>(s, a, persistent);
         // few sequences: quarter- / half-column tiles when whole tiles would leave three quarters / half of the CUs idle (bit-identical results: see the kernel)
-        else if ((long)(a.M / 257) * (a.N / 256) * 4 <= num_cu_cached() && g_col_split >= 4) launch_ht<8, EPI_RES_F32, 6, true, false, 4>(s, a, persistent);
-        else if ((long)(a.M / 257) * (a.N / 256) * 2 <= num_cu_cached() && g_col_split >= 2) launch_ht<8, EPI_RES_F32, 6, true, false, 2>(s, a, persistent);
+        else if (seq_tiles * (a.N / 256) * 4 <= num_cu_cached() && g_col_split >= 4) launch_ht<8, EPI_RES_F32, 6, true, false, 4>(s, a, persistent);
+        else if (seq_tiles * (a.N / 256) * 2 <= num_cu_cached() && g_col_split >= 2) launch_ht<8, EPI_RES_F32, 6, true, false, 2>(s, a, persistent);
         else launch_ht<8, EPI_RES_F32, 6, true>(s, a, persistent);
         break;
       default: break;

@@ -44,9 +44,9 @@ struct GemmArgs {
   // rows: out_c = f(A_c . W), out_u = f(A_c . W + A_delta . W) -- with the GELU epilogue the unconditional rows receive gelu(u) - gelu(c),
   // i.e. the next GEMM's difference operand.  See gemm_ht.hip and DESIGN.md "Precision".
   int pair_rows = 0;
-  // pair tiles: rows per sequence incl. the class token (0 = 257).  A pair tile is 128 tokens of one sequence pair, so any (seq_rows - 1) / 128 that is
-  // a power of two is served: 257 (256 x 256 images) and 1 025 (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144); the LAST tile of a pair
-  // stores the class rows.
+  // sequence tiles: rows per sequence incl. the class token (0 = 257).  A pair tile is 128 tokens of one sequence pair, a plain tile 256 tokens of one
+  // sequence, so any (seq_rows - 1) / 128 (/ 256) that is a power of two is served: 257 (256 x 256 images) and 1 025 (the 512 x 512 models,
+  // scripts/eval_maskbit.py:125,139-144); the LAST tile of a sequence (pair) stores the class row(s).
   int seq_rows = 0;
   // GELU epilogue of sequence-aligned tiles (optional): out4 / out4_scale receive e2m1 of the (conditional) OUTPUT values (row stride 2N bytes) and
   // their lane-ordered scale bytes -- the token operand of the next GEMM's weight-correction pass; class-token rows are left untouched.
@@ -56,7 +56,7 @@ struct GemmArgs {
   // K-elements (24 KiB of LDS behind the two K-tile parities), staged while the fp16 K-tiles run and multiplied in a fifth phase between them
   // (16 v_mfma_scale_f32_16x16x128_f8f6f4 per wave).  nlo = number of operand sets:
   //   pair tiles : lo[0] (, lo[1]) on the CONDITIONAL rows: K / 128 mini-tiles per set (one per two fp16 K-tiles with one set, one per K-tile with two);
-  //   plain tiles: lo[0] on both 128-row halves of the 257-row sequence tile (nlo = 1): 2 K / 128 mini-tiles, one per fp16 K-tile.
+  //   plain tiles: lo[0] on both 128-row halves of the 256-token sequence tile (nlo = 1): 2 K / 128 mini-tiles, one per fp16 K-tile.
   // Operands: A4 = e2m1 token operand, two values per byte, row stride 2 K bytes (first K / 2 used); W4 = e2m1 weight operand, mini-tile-packed
   // (w4_packed_offset; N K / 2 bytes); w_scale = the weights' E8M0 bytes in the kernel's lane order (entry ((n >> 6) * 16 + (n & 15)) * 4 +
   // ((n >> 4) & 3)); a_scale = the token operand's E8M0 bytes per (row, 64 K-elements) in LANE ORDER (fp4_scale_index: one dword per lane holds the
@@ -133,7 +133,7 @@ void transpose_f32(hipStream_t s, const float* src /*[rows,cols]*/, float* dst /
 
 // ---- multi-head self-attention over packed qkv [nb*N, 3d] -> out [nb*N, d] -----------------------
 void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, int heads,
-               uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);   // out4 / out4s (N = 257, head width 64): e2m1 of the outputs + lane-ordered scale
+               uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);   // out4 / out4s (N = 257 or (N - 1) % 64 == 0 beyond the one-block kernel's length; head width 64): e2m1 of the outputs + lane-ordered scale
                                                                       // bytes for the out-proj GEMM's mini-tile pass
 // "CFG pair" attention: sequences [0, P) are conditional, [P, 2P) their unconditional twins; one workgroup runs a (pair, head) -- conditional pass,
 // then the twin with the conditional output tiles kept in registers -- and writes out[r + P*N] = fp16(att_u - att_c), the difference operand of the

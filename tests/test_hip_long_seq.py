@@ -161,3 +161,32 @@ def test_guided_forward_1025_tokens_full_width_vs_oracle():
         assert torch.equal(one[0], lg[1]) and torch.equal(one[1], lg[4])
     assert m.saturation_count() == 0
     m.precision = -1
+
+
+@pytest.mark.timeout(900)
+def test_plain_forward_1025_tokens_precision_modes_full_width_vs_oracle():
+    """forward() of a full-width two-layer generator over 1024 + 1 tokens under the precision knob (round 5: the plain sequence tiles now serve 1 025-row
+    sequences as four 256-token tiles, so precision 2 means the same here as for the 257-token models): 1 = hi + lo LayerNorm outputs in FFN-up, 2 = + the
+    MX-fp4 weight-correction mini-tiles on every trunk GEMM (the streaming attention kernel writes the e2m1 copy of its outputs for the out-projection).
+    Each step moves the logits closer to the fp32 oracle; batch invariance bit for bit -- 1 sequence (quarter-column tiles), 3, and 17 (whole tiles)."""
+    cfg = O.GenCfg(bits=12, splits=2, hidden=1024, depth=2, heads=16, mlp=4096, seq=1024, nclass=1000)
+    sd = O.make_generator_weights(cfg, seed=78, head_gain=12.0)
+    m = _gen(cfg, sd)
+    g = torch.Generator().manual_seed(6)
+    t = torch.randint(0, 65, (3, 1024, 2), generator=g)
+    y = torch.tensor([7, 123, 998])
+    drop = torch.tensor([False, True, False])
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = O.lfq_bert_forward(sd, cfg, t, y, drop)
+    err = {}
+    for prec in (0, 1, 2):
+        m.precision = prec
+        out = m(t.to(DEV), y.to(DEV), drop.to(DEV))
+        err[prec] = float((out.cpu() - ref).norm() / ref.norm())
+        assert torch.isfinite(out).all()
+        assert torch.equal(m(t[1:2].to(DEV), y[1:2].to(DEV), drop[1:2].to(DEV)), out[1:2])
+        big = m(t.repeat(6, 1, 1)[:17].to(DEV), y.repeat(6)[:17].to(DEV), drop.repeat(6)[:17].to(DEV))
+        assert torch.equal(big[:3], out) and torch.equal(big[15:17], out[:2])
+    print(f"1025 tokens, plain forward: rel-Frobenius logit error single fp16 {err[0]:.2e}, hi + lo LayerNorm outputs {err[1]:.2e}, + weight correction {err[2]:.2e}")
+    assert err[1] < 0.995 * err[0] and err[2] < 0.75 * err[1]
+    assert m.saturation_count() == 0

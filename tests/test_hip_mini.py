@@ -82,25 +82,29 @@ def test_pair_gemm_with_mini_tile_passes(epi, pairs, N, K, nlo):
         assert e_corr < e_plain / 3
 
 
-@pytest.mark.parametrize("epi,nseq,N,K", [(0, 3, 768, 1024), (1, 4, 1024, 1024), (2, 2, 256, 2048), (2, 5, 1024, 4096)])
-def test_plain_gemm_with_weight_correction_mini_tiles(epi, nseq, N, K):
-    """Plain sequence tiles (the unguided forward, cfg_pair >= 2): both 128-row halves of every sequence take the operand set; with the GELU epilogue
-    the kernel also emits the e2m1 copy of its outputs + lane-ordered block scales for the next GEMM."""
+@pytest.mark.parametrize("epi,nseq,N,K,SQ", [(0, 3, 768, 1024, 257), (1, 4, 1024, 1024, 257), (2, 2, 256, 2048, 257), (2, 5, 1024, 4096, 257),
+                                             (0, 2, 768, 1024, 1025), (1, 1, 1024, 1024, 1025), (2, 1, 256, 2048, 1025), (2, 3, 1024, 1024, 1025), (2, 17, 1024, 1024, 1025)])
+def test_plain_gemm_with_weight_correction_mini_tiles(epi, nseq, N, K, SQ):
+    """Plain sequence tiles (the unguided forward, precision >= 2): both 128-row halves of every 256-token tile take the operand set; with the GELU epilogue
+    the kernel also emits the e2m1 copy of its outputs + lane-ordered block scales for the next GEMM.  SQ = 1025 (the 512 x 512 models, round 5): four tiles
+    per sequence, the class row computed and stored by the last one, 16 groups of 64 tokens in the scale arrays; the fp32 + residual cases also walk the
+    quarter- / half-column tiles (few sequences) and whole tiles (17 sequences)."""
     from maskbit_amd import _lib
     lib = _lib.load()
     torch.manual_seed(epi + nseq)
-    M = nseq * 257
+    M = nseq * SQ
+    G = (SQ - 1) // 64
     x = (torch.randn(M, K, device=DEV) * (0.3 + torch.rand(M, K // 64, device=DEV).repeat_interleave(64, 1) * 2)).half()
     W32, w4lo, wslo, wlo_dec = _weights(N, K, lib, lo=True)
     W = W32.half()
-    x4, xs, x4_dec = f4_encode_rows(x.double(), nseq)
+    x4, xs, x4_dec = f4_encode_rows(x.double(), nseq, seq_rows=SQ)
     bias = torch.randn(N, device=DEV) * 0.1
     res = torch.randn(M, N, device=DEV) if epi == 2 else None
     out32 = res.clone() if epi == 2 else None
     out16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16) if epi != 2 else None
     out4 = torch.zeros(M, 2 * N, device=DEV, dtype=torch.uint8) if epi == 1 else None
-    out4s = torch.zeros((N // 64) * nseq * 256 + 256, device=DEV, dtype=torch.uint8) if epi == 1 else None
-    gemm_mini(lib, epi, x, W, bias, out32, out32, out16, M, False, N, K, [(x4, xs, w4lo, wslo)], out4, out4s)
+    out4s = torch.zeros((N // 64) * nseq * G * 64 + 256, device=DEV, dtype=torch.uint8) if epi == 1 else None
+    gemm_mini(lib, epi, x, W, bias, out32, out32, out16, M, False, N, K, [(x4, xs, w4lo, wslo)], out4, out4s, seq_rows=0 if SQ == 257 else SQ)
     torch.cuda.synchronize()
     want = x.double() @ W.double().t() + x4_dec @ wlo_dec.t() + bias.double()
     if epi == 1:
@@ -114,9 +118,9 @@ def test_plain_gemm_with_weight_correction_mini_tiles(epi, nseq, N, K):
     assert float(err.max()) < tol, (float(err.max()), int(err.argmax()) // N, int(err.argmax()) % N)
     if epi == 1:                                                   # the e2m1 copy of the GELU outputs: a valid quantisation of them, scales where the consumer reads them
         rows = torch.arange(M)
-        seq, tok = rows // 257, rows % 257
-        keep = tok < 256
-        sb = torch.stack([out4s.cpu()[f4_scale_index(b, nseq, seq[keep], tok[keep])] for b in range(N // 64)], 1).double()      # [rows, blocks]
+        seq, tok = rows // SQ, rows % SQ
+        keep = tok < SQ - 1
+        sb = torch.stack([out4s.cpu()[f4_scale_index(b, nseq, seq[keep], tok[keep], G)] for b in range(N // 64)], 1).double()      # [rows, blocks]
         dec = (f4_decode(out4[keep.to(DEV)], N).reshape(-1, N // 64, 64) * (2.0 ** (sb - 127)).unsqueeze(-1)).reshape(-1, N)
         ref = want[keep.to(DEV)].cpu()
         amax = ref.reshape(-1, N // 64, 64).abs().amax(-1)
