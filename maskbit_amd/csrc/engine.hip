@@ -190,10 +190,14 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   //   >= 1: the LayerNorm output enters FFN-UP as an fp16 hi + lo pair (x_h16 + x_lo: that GEMM sweeps its weight twice, K = 2d).  Rounds 3-4 did the
   //         same in QKV; over configs[1]'s three reference runs + the trained-like one (348 160 positions) the QKV sweep buys nothing -- 153 mismatches
   //         with both, 158 with FFN-up alone, 192 with QKV alone, 195 with neither (profiles/raw/r05/xlo_mask.log) -- and costs 19-69 us per layer;
+  //         by layer range (FFN-up sweep; configs[1]'s three runs, 261 120 positions; raw/r05/xlo_layers.log): [0, 24) 144, [6, 24) 140, [12, 24) 147,
+  //         [18, 24) 145, [0, 12) 164, none 182 -- the late layers carry all of it, so the sweep runs in layers >= depth / 2 (~80 us per layer saved
+  //         in the first half at 64 sequences; the same rule as precision 3's activation-lo set in the guided forward);
   //   >= 2: all four trunk GEMMs also carry the MX-fp4 weight-correction mini-tiles on every row -- the fp16 rounding of the
   //         WEIGHTS is 80 % of the sampled-logit error variance here (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
   //         activation pairs, 0.0045 with the weight correction alone); both together: 5.3e-4 over configs[1]'s three reference runs.
   const bool xlo = c.precision >= 1;
+  auto xlo_layer = [&](int l) { return xlo && 2 * l + 1 >= c.depth; };   // (the second half of the layers: see above)
   h16* const xlo_ffn = xlo ? g->x_lo : nullptr;          // the LayerNorm in front of FFN-up writes lo halves (the one in front of QKV does not; the last one feeds the head)
   const bool wm = g->mini_ok && c.precision >= 2;   // (sequence tiles: 256 + 1 rows, or four tiles per 1024 + 1-row sequence)
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
@@ -210,7 +214,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     if (wm) ga.seq_rows = N;
     lo_set(ga, g->x4, g->x4s, widx);
     if (wm && epi == EPI_GELU_H16 && (g->wcorr_mask & 8)) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
-    if (xlo && (widx & 3) == 2) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }   // FFN-up only (see above)
+    if ((widx & 3) == 2 && xlo_layer(widx >> 2)) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }   // FFN-up only (see above)
     ga.sat = g->sat;
     gemm_rc |= gemm_tn(s, epi, ga, wm ? 257 : 0);
   };
@@ -244,7 +248,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       const bool re = !c.prenorm && l > 0;
       rgemm(g->att, L.wo, L.bo, d, 4 * l + 1, g->att4, g->att4s, re ? g->layers[l - 1].ln2g : nullptr, re ? g->layers[l - 1].ln2b : nullptr); }
     { ProfScope p("layernorm", s, true);
-      layernorm_rows(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, nullptr, g->x_h16, c.prenorm ? nullptr : g->ln_stats, M, d, xlo_ffn, f4x); }
+      layernorm_rows(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, nullptr, g->x_h16, c.prenorm ? nullptr : g->ln_stats, M, d, xlo_layer(l) ? xlo_ffn : nullptr, f4x); }
     { ProfScope p("gemm_ffn_up", s, true); xgemm(EPI_GELU_H16, L.w1, L.b1, g->h, f, 4 * l + 2); }
     { ProfScope p("gemm_ffn_down", s, true);
       rgemm(g->h, L.w2, L.b2, f, 4 * l + 3, g->h4, g->h4s, c.prenorm ? nullptr : L.ln1g, c.prenorm ? nullptr : L.ln1b); }
@@ -282,7 +286,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // layer range: [0, 24) 493, [12, 24) 531, [18, 24) 560, [6, 18) 579, [0, 12) 612, [0, 6) 627 -- the late layers carry the gain: the second half
   // keeps 70 % of it (5.3e-4 pooled, the worst single run 8.7e-4 against 8.3e-4) for half of the 84 us per layer.
   const bool alo = wmode && c.precision == 3;
-  auto alo_layer = [&](int l) { return alo && 2 * l >= c.depth; };
+  auto alo_layer = [&](int l) { return alo && 2 * l + 1 >= c.depth; };
   auto f4_for = [&](int consumer_layer, bool feeds_ffn = false) {   // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
     if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) {

@@ -11,8 +11,8 @@ GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C
           "configs[4] 14-bit / 256 steps / CFG 5.8": [R.RUN_CFG5, R.RUN_CFG5_S2, R.RUN_CFG5_S3, R.RUN_CFG5_S4],
           "trained-like weights (heavy tails, massive-activation channels): configs[2]": [R.RUN_C3_OUTLIER],
           "trained-like weights: configs[1]": [R.RUN_CFG1_OUTLIER],
-          "use_prenorm=True, configs[2]'s sampler (guided forward = plain forward over [cond | uncond])": [R.RUN_C3_PRENORM],
-          "1024 + 1 tokens (512 x 512 models), configs[2]'s sampler (guided forward = plain forward over [cond | uncond])": [R.RUN_C3_SEQ1024]}
+          "use_prenorm=True, configs[2]'s sampler": [R.RUN_C3_PRENORM],
+          "1024 + 1 tokens (512 x 512 models), configs[2]'s sampler": [R.RUN_C3_SEQ1024]}
 MODES = (("default", -1), ("differential only (precision 1)", 1))
 if os.environ.get("PARITY_MODES"):            # e.g. PARITY_MODES="default:-1,fp16:0"   (tag:LFQBert.precision)
     MODES = tuple((t.split(":")[0], int(t.split(":")[1])) for t in os.environ["PARITY_MODES"].split(","))
