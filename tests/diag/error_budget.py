@@ -146,8 +146,8 @@ F16 = dict(x="f16", att="f16", h="f16", qkv="f16", p="f16", wt="f16", wh="f16", 
 
 def cases(guided):
     c = [("single fp16, independent streams", {**F16, "pair": False}),
-         ("differential form, fp16 weights (cfg_pair 1)", dict(F16)),
-         ("+ exact trunk weights (ideal cfg_pair 2)", {**F16, "wt": "exact"}),
+         ("differential form, fp16 weights (precision 1)", dict(F16)),
+         ("+ exact trunk weights (the ideal precision 2)", {**F16, "wt": "exact"}),
          ("+ fp4 correction, 64-column block scales", {**F16, "wt": "corr4", "blk": 64}),
          ("+ fp4 correction, one scale per row", {**F16, "wt": "corr4", "blk": 0}),
          ("exact trunk weights + exact head weights", {**F16, "wt": "exact", "wh": "exact"}),

@@ -1,4 +1,4 @@
-"""The MX-fp4 mini-tile passes of the sequence-aligned trunk GEMM (gemm_ht.hip, XP = 6; mb_gen_cfg.cfg_pair 2 / 3): corrections for the fp16 rounding
+"""The MX-fp4 mini-tile passes of the sequence-aligned trunk GEMM (gemm_ht.hip, XP = 6; mb_gen_cfg.precision 2 / 3): corrections for the fp16 rounding
 of the weights (e2m1 of the operand VALUES against e2m1(W - fp16(W))) and of the LayerNorm outputs (e2m1 of their lo halves against e2m1(W)) as
 24 KiB mini-tiles multiplied between the fp16 K-tiles.  Checked against fp64 on the DECODED 4-bit operands -- what the kernel is asked to compute --
 for pair and plain tiles, one and two operand sets, every epilogue, the producers of the 4-bit operands (LayerNorm, GELU epilogue), and for
@@ -131,7 +131,7 @@ def test_plain_gemm_with_weight_correction_mini_tiles(epi, nseq, N, K, SQ):
 
 @pytest.mark.parametrize("epi,nseq,N,K", [(0, 3, 768, 1024), (1, 2, 1024, 1024)])
 def test_plain_gemm_split_activations_with_weight_correction_mini_tiles(epi, nseq, N, K):
-    """The plain forward's default for QKV / FFN-up (act_split 1 composed with cfg_pair >= 2; mb_gemm_mini_split): the fp16 sweep runs over the hi
+    """The plain forward's FFN-up of the late layers at precision >= 2 (mb_gemm_mini_split): the fp16 sweep runs over the hi
     AND the lo halves of the activations (K-tiles doubled) while the mini-tiles -- one per two fp16 K-tiles then, both row halves -- add the weight
     correction of the K columns: out = (x_hi + x_lo) . W^T + e2m1(x) . e2m1(W32 - W)^T + bias."""
     import ctypes as C
