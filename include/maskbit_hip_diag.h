@@ -55,6 +55,11 @@ int mb_layernorm_f4(const float* y, const float* gamma, const float* beta, float
  * fp16; rows of unconditional sequences = fp16(o_u - o_c), the difference operand of the out-proj pair GEMM (the conditional output tiles stay in
  * registers in between).  N <= 288: one head's K / V in LDS; longer sequences: the streaming kernel. */
 int mb_attention_pair(const void* qkv, void* out_h16, int pairs, int N, int d, int heads, mb_stream stream);
+/* The same launch as the engine issues it at precision >= 2: + out4 [2 pairs N, 2 d] (first d / 2 bytes of a row used) = e2m1 of the CONDITIONAL outputs, two
+ * values per byte, and out4_scale = one E8M0 byte per (row, head) in the lane order of the mini-tile passes (mb_kernels.h fp4_scale_index with (N - 1) / 64
+ * token groups per sequence, `pairs` sequences): the token operand of the out-projection's weight-correction pass.  Head width 64, N = 257 or
+ * (N - 1) % 64 == 0 beyond 288. */
+int mb_attention_pair_f4(const void* qkv, void* out_h16, void* out4, void* out4_scale, int pairs, int N, int d, int heads, mb_stream stream);
 /* Study knob of the weight-correction passes (precision >= 2): they run in trunk layers >= from_layer (default 0 = every layer; depth = none; guided
  * forward) and on the GEMMs of gemm_mask (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down; default 15; both forwards).  No subset keeps the default's
  * parity margin (profiles/r04_gemm_minitiles.md section 4): the product never calls this. */

@@ -47,6 +47,20 @@ __device__ long long* g_att_trace = nullptr;
 #define MB_ATRACE(k) do { } while (0)
 #endif
 
+// e2m1 of a lane's output tile o[4][4] (row q = lane & 15; values dh = 16 nt + 4 g + r, g = lane >> 4) * inv, scaled by `mul`, exchanged between the row's
+// four lane groups so that the lane ends up with bytes [8 (g & 1) + 16 (g >> 1), +8) of the row's 32-byte (64-value) block: dh tile nt's 8 bytes live in
+// lane group g = nt after the two swaps (v_permlane16_swap: odd / even lane rows; v_permlane32_swap: lane halves).  Every lane of the wave must call it.
+__device__ __forceinline__ uint2 fp4_row8(const f32x4 (&o)[4], float inv, float mul) {
+  uint32_t p[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) p[nt] = fp4_pack4(o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv, mul);
+  const auto sw = __builtin_amdgcn_permlane16_swap((p[0] & 0xffffu) | (p[2] << 16), (p[1] & 0xffffu) | (p[3] << 16), false, false);
+  const uint32_t q0 = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);      // 32-value group 0: this lane's 4 values | its neighbour's
+  const uint32_t q1 = __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u);      // 32-value group 1
+  const auto sx = __builtin_amdgcn_permlane32_swap(q0, q1, false, false);
+  return make_uint2(sx[0], sx[1]);
+}
+
 // AUX = 4 (CFG pair attention, mb_kernels.h attention_pair): one workgroup handles the conditional sequence of a (pair, head) and then its
 // unconditional twin, the conditional output tiles parked in registers in between, and stores fp16(o_u - o_c) for the twin: no extra traffic, one
 // launch, two workgroups per CU as before.  (Rounds 2-3 also had a two-launch form through fp32 rows in memory -- 119 against 88 us -- removed in
@@ -277,15 +291,17 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(o[nt][r] * inv));
-        am = rows_max(am);
+          for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(o[nt][r]));
+        am = rows_max(am) * inv;                                        // (== the maximum of the rounded products: inv > 0, rounding is monotonic)
         const float mul = fp4_scale_mul_nosat(am);
+        // a lane's four dh tiles are 2 bytes each (4 values): as 2-byte stores the copy cost 7-9 us of the launch (tools/att_f4_ab.py).  Two lane
+        // exchanges -- odd / even lane rows (dh tiles 2j <-> 2j + 1), then the lane halves -- give every lane 8 CONSECUTIVE bytes of the row's 32-byte
+        // block (the GELU epilogue's trick, gemm_ht.hip); all 64 lanes take part (the row guard is uniform over a row's four lane groups)
+        const uint2 pk8 = fp4_row8(o, inv, mul);
         if (q < 256) {                                                // (class-token rows take no part in the mini-tile passes)
           const size_t row = (size_t)sq * N + q;
           if (g == 0) out4s[fp4_scale_index(h, out4_nseq, sq, q)] = (uint8_t)fp4_scale_byte_nosat(am);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            *(uint16_t*)(out4 + row * 2 * d + (h * DH + nt * 16 + g * 4) / 2) = (uint16_t)fp4_pack4(o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv, mul);
+          *(uint2*)(out4 + row * 2 * d + (h * DH) / 2 + (g >> 1) * 16 + (g & 1) * 8) = pk8;
         }
       }
     }
@@ -454,15 +470,14 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(o[nt][r] * inv));
-      am = rows_max(am);
+        for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(o[nt][r]));
+      am = rows_max(am) * inv;
       const float mul = fp4_scale_mul_nosat(am);
+      const uint2 pk8 = fp4_row8(o, inv, mul);             // (8 consecutive bytes per lane: see attention_kernel)
       if (q < N - 1) {                                     // (class-token rows take no part in the mini-tile passes)
         const size_t row = (size_t)sq * N + q;
         if (g == 0) out4s[fp4_scale_index(h, out4_nseq, sq, q, (N - 1) >> 6)] = (uint8_t)fp4_scale_byte_nosat(am);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          *(uint16_t*)(out4 + row * 2 * d + (h * DH + nt * 16 + g * 4) / 2) = (uint16_t)fp4_pack4(o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv, mul);
+        *(uint2*)(out4 + row * 2 * d + (h * DH) / 2 + (g >> 1) * 16 + (g & 1) * 8) = pk8;
       }
     }
   }

@@ -500,6 +500,15 @@ int mb_attention_pair(const void* qkv, void* out_h16, int pairs, int N, int d, i
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
+int mb_attention_pair_f4(const void* qkv, void* out_h16, void* out4, void* out4_scale, int pairs, int N, int d, int heads, mb_stream stream) {
+  if (!qkv || !out_h16 || !out4 || !out4_scale || pairs <= 0 || N <= 0 || heads <= 0 || d % heads) return fail(-1, "mb_attention_pair_f4: bad arguments");
+  ProfScope p("attention", (hipStream_t)stream);
+  if (mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out_h16, pairs, N, d, heads, (uint8_t*)out4, (uint8_t*)out4_scale))
+    return fail(-3, "mb_attention_pair_f4: head width %d / N = %d tokens: no e2m1 copy for this shape", d / heads, N);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
 int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W, const float* bias, const float* residual, float* out_f32,
                       void* out_h16, int M, int N, int kw, int variant, mb_stream stream) {
   if (!A_hi || !A_lo || !W || !bias || epi < 0 || epi > 3 || kw <= 0 || kw % 64) return fail(-1, "mb_gemm_act_split: bad arguments");

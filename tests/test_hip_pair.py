@@ -119,3 +119,39 @@ def test_pair_attention_vs_fp32_reference(pairs, heads, d):
     assert err < 6e-4 * float(oc.abs().max()) and err < 2e-2 * float(diff.abs().max()), (err, float(diff.abs().max()), float(oc.abs().max()))
     with pytest.raises(RuntimeError):                                             # head widths other than 32 / 64 are refused (N > 288 runs the streaming pair kernel: test_hip_long_seq.py)
         _lib.check(lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), 1, N, d, d // 16, torch.cuda.current_stream().cuda_stream), "mb_attention_pair")
+
+
+@pytest.mark.parametrize("pairs,N", [(2, 257), (1, 1025)])
+def test_pair_attention_e2m1_copy_of_the_conditional_outputs(pairs, N):
+    """mb_attention_pair_f4 = the launch the engine issues at precision >= 2 (one-block kernel at N = 257, streaming kernel beyond): the fp16 rows are
+    bit for bit those of mb_attention_pair, and out4 / out4_scale hold a valid MX-fp4 quantisation of the CONDITIONAL outputs -- one E8M0 scale per (row,
+    head) = 64 values, chosen without saturation, in the lane order the out-projection's mini-tile pass reads; class-token rows take no part."""
+    from hip_helpers import f4_block_exponent, f4_decode, f4_scale_index
+    from maskbit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(N)
+    d, heads = 1024, 16
+    qc = torch.randn(pairs * N, 3 * d, device=DEV) * 0.7
+    qu = qc + torch.randn(pairs * N, 3 * d, device=DEV) * 0.02
+    qkv = torch.cat([qc, qu]).half().contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.full((2 * pairs * N, d), float("nan"), device=DEV, dtype=torch.float16)
+    _lib.check(lib.mb_attention_pair(qkv.data_ptr(), ref.data_ptr(), pairs, N, d, heads, st), "mb_attention_pair")
+    out = torch.full_like(ref, float("nan"))
+    G = (N - 1) // 64
+    out4 = torch.zeros(2 * pairs * N, 2 * d, device=DEV, dtype=torch.uint8)
+    out4s = torch.zeros(heads * pairs * G * 64 + 256, device=DEV, dtype=torch.uint8)
+    _lib.check(lib.mb_attention_pair_f4(qkv.data_ptr(), out.data_ptr(), out4.data_ptr(), out4s.data_ptr(), pairs, N, d, heads, st), "mb_attention_pair_f4")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    rows = torch.arange(pairs * N)
+    seq, tok = rows // N, rows % N
+    keep = tok < N - 1
+    sb = torch.stack([out4s.cpu()[f4_scale_index(h, pairs, seq[keep], tok[keep], G)] for h in range(heads)], 1).double()      # [rows, heads]
+    dec = (f4_decode(out4[: pairs * N][keep.to(DEV)], d).reshape(-1, heads, 64) * (2.0 ** (sb - 127)).unsqueeze(-1)).reshape(-1, d)
+    want = out[: pairs * N][keep.to(DEV)].double().cpu()                      # (the copy is taken from the fp32 tile; the fp16 rows are within 2^-11 of it)
+    amax = want.reshape(-1, heads, 64).abs().amax(-1)
+    E = f4_block_exponent(amax.clamp(min=1e-30))
+    assert float((sb != (E - 2).clamp(min=0).double()).double().mean()) < 5e-3          # (fp32 tile vs its fp16 rounding may straddle a binade)
+    assert float(((dec - want) ** 2).sum() / (want ** 2).sum()) < 0.02
+    assert int(out4[pairs * N:].count_nonzero()) == 0                       # nothing is written for the difference rows
