@@ -639,7 +639,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
       rc |= galloc(g, &g->w4lo[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4los[4 * l + 1], d);
       rc |= galloc(g, &g->w4lo[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4los[4 * l + 2], f);
       rc |= galloc(g, &g->w4lo[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4los[4 * l + 3], d);
-      if (c.precision == 3) {
+      if (c.precision == 3 && 2 * l + 1 >= c.depth) {          // (the activation-lo set runs in FFN-up of the late layers: gen_forward_pair_impl)
         rc |= galloc(g, &g->w4[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4s[4 * l + 2], f);
       }
     }
