@@ -126,6 +126,10 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # round 5: a FOURTH 14-bit / 256-step run (batch 4) so that the worst single run of configs[4] (8.7e-4 on _s2, batch 2) has company (round-4 review, item 4)
     "sample_full14_256_s4": (14, 183, 16.0, 4, CFG5_256, False, 4331, 12),
     "sample_full10_16_nocfg_s3": (10, 182, 12.0, 16, CFG1_16, False, 4330, 0),
+    # round 5, end: HELD-OUT runs.  Round 5 decided where the lo refinements run (which GEMM, which layers) on the runs above; these two were recorded after
+    # those decisions were frozen and took no part in them
+    "sample_full10_16_nocfg_s4": (10, 184, 16.0, 16, CFG1_16, False, 4332, 0),
+    "sample_full12_64_s4": (12, 185, 16.0, 8, FULL64, False, 4333, 4),
     "sample_full12_64_outlier": (12, 190, 12.0, 4, FULL64, False, 4326, 2, "outlier"),
     "sample_full10_16_nocfg_outlier": (10, 191, 12.0, 16, CFG1_16, False, 4327, 0, "outlier"),
     # the two generator variants whose guided forward does not run in differential form on the engine (it falls back to the plain forward over
