@@ -79,7 +79,7 @@ def test_other_bit_widths_tiny(bits, splits):
 def _vs_reference_run(name, modes):
     """Teacher-forced replay of one of the REAL reference's full-size runs (tests/golden/<name>.npz, oracle/make_golden.py RUNS) in the given
     engine modes (tag, LFQBert.precision) -> {tag: (mismatches, positions)}."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     g = R.load_run(name)
     gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
     noise = R.reference_noise(g, gen.device)
@@ -101,7 +101,7 @@ def test_baseline_config1_10bit_16steps_nocfg_vs_reference_runs():
     6.4e-4 / 4.6e-4 / 5.5e-4 = 5.5e-4 over all.  (Round 4 swept the lo halves in QKV as well: 5.2e-4 / 4.3e-4 / 6.4e-4 = 5.3e-4, the same within the
     counts' spread for 8-12 % of this configuration's time; no lo sweep at all: 8.2e-4 / 5.1e-4 / 7.7e-4 = 7.0e-4; single fp16 1.06e-3 / 7.1e-4;
     profiles/raw/r05/xlo_mask.log.)  Asserted: <= 7e-4 on each run and <= 6e-4 over all."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     tb = tt = 0
     for name in (R.RUN_CFG1, R.RUN_CFG1_S2, R.RUN_CFG1_S3):
         r = _vs_reference_run(name, [("product default", -1), ("hi + lo FFN-up operand alone (precision 1)", 1), ("single fp16", 0)])
@@ -120,7 +120,7 @@ def test_baseline_config5_14bit_256steps_vs_reference_runs():
     weights (precision 2) the first run measures 6.6e-4; the product default at 7 bits per group (precision 3: + the activation-lo mini-tiles of the
     LayerNorm outputs, since round 5 in FFN-up only: the QKV set measured no gain over the four runs) 4.8e-4 / 8.3e-4 / 4.4e-4 / 3.7e-4 = 4.9e-4
     over all; without the set 6.2e-4 over all and 1.05e-3 on the second run.  Asserted without allowance: <= 1e-3 on each run, <= 6e-4 over all."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     r = _vs_reference_run(R.RUN_CFG5, [("product default", -1), ("weight correction + activation-lo pass", 3),
                                        ("weight correction alone", 2), ("differential operands only", 1), ("single fp16", 0)])
     bad, tot = r["differential operands only"]
@@ -145,7 +145,7 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
     16 steps, no guidance) run by the REAL reference on such weights (oracle/make_golden.py RUNS: *_outlier), replayed in the product default.
     Per-(row, 64 columns) scales keep an outlier channel from costing the resolution of the rest of its row; the fp16 stores of the trunk never
     clamp (mb_gen_saturation_count)."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     for name, bound in ((R.RUN_C3_OUTLIER, 1e-3), (R.RUN_CFG1_OUTLIER, 1e-3)):
         g = R.load_run(name)
         gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
@@ -177,7 +177,7 @@ def test_generator_variants_full_width_vs_reference_runs(name, expect, bound):
       * 1024 + 1 tokens (the 512 x 512 models, scripts/eval_maskbit.py:125,139-144): since round 5 the differential form with the weight-correction
         mini-tiles here too (eight 128-token pair tiles per sequence pair, the streaming attention kernel in pair form); rounds 3-4 ran the plain forward
         over [cond | uncond] with hi + lo activation pairs (the e4m3 lo pass, retired in round 5) and measured 7.6e-4 (single fp16: 1.11e-3)."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     g = R.load_run(name)
     gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
     assert gen.resolved_precision() == expect
@@ -265,7 +265,7 @@ def test_baseline_config3_three_reference_runs_other_weights_noise_and_labels():
     (differential guidance + weight-correction mini-tiles) measures 5.6e-4 / 5.7e-4 / 5.4e-4: asserted <= 7e-4 on each run and <= 6e-4 over all, no
     statistical allowance.  The differential form alone (round 2's default) measures ~1e-3 over all: AT the bound, which is why it is not the
     default; asserted at what it measures."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     tot_all = {"product default": [0, 0], "differential only": [0, 0]}
     for name in ("sample_full12_64", R.RUN_C3_S2, R.RUN_C3_S3):
         g = R.load_run(name)
@@ -309,7 +309,7 @@ def test_held_out_reference_runs_default_precision():
     (profiles/r05_coverage.md).  These two runs -- configs[1] at batch 16 and configs[2] at batch 8, other weights / head gain / noise / labels -- were
     recorded AFTER those decisions were frozen and took no part in them: the product default must meet the north star's 1e-3 on each, and the 7e-4 the
     other runs' tests assert per run."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     for name in (R.RUN_CFG1_S4, R.RUN_C3_S4):
         r = _vs_reference_run(name, [("product default", -1), ("differential / hi + lo operands alone (precision 1)", 1)])
         bad, tot = r["product default"]

@@ -6,7 +6,7 @@ No oracle import: weights and noise are regenerated from seeds, expectations com
 import pytest
 import torch
 
-import parity_replay as R
+from maskbit_amd import parity_replay as R
 
 pytestmark = pytest.mark.gpu
 

@@ -142,7 +142,7 @@ def test_replay_embedded_in_the_timed_batch_counts_the_same_mismatches():
     """bench.py's parity figure at the size it times: the reference's 4-sample run (tests/golden/sample_full12_64.npz) replayed teacher-forced with
     its samples as rows 0, 21, 42, 63 of a 64-sample guided forward (other rows: random codes in the same mask state, random labels) counts, step by
     step, exactly the mismatches of the 4-sample replay -- in the product default and in the differential form alone."""
-    import parity_replay as R
+    from maskbit_amd import parity_replay as R
     g = R.load_full64()
     gen, _ = R.build_models(DEV, with_tokenizer=False)
     noise = R.reference_noise(g, gen.device)

@@ -5,7 +5,7 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import parity_replay as PR
+from maskbit_amd import parity_replay as PR
 from maskbit_amd.sampling import build_plan, run_chunked
 
 

@@ -12,7 +12,7 @@ def main():
     var, vals = sys.argv[1], sys.argv[2:4]
     rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     nfw = int(sys.argv[5]) if len(sys.argv) > 5 else 16
-    import parity_replay as PR
+    from maskbit_amd import parity_replay as PR
     gen, _ = PR.build_models(torch.device("cuda"), with_tokenizer=False)
     B = 64
     tok = torch.randint(0, 64, (B, 256, 2), device="cuda")

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def run(B):
     import torch
-    import parity_replay as PR
+    from maskbit_amd import parity_replay as PR
     from config_bench import tokenizer
     from maskbit_amd.sampling import build_plan, run_chunked
     dev = torch.device("cuda")
