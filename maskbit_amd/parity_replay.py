@@ -36,6 +36,7 @@ RUN_CFG5_S4 = "sample_full14_256_s4"     # round 5: ... and a fourth time (batch
 RUN_CFG1_S3 = "sample_full10_16_nocfg_s3"   # ... and configs[1] a third time
 RUN_CFG1_S4 = "sample_full10_16_nocfg_s4"   # round 5, end: HELD-OUT runs of configs[1] / configs[2], recorded after the round's coverage decisions
 RUN_C3_S4 = "sample_full12_64_s4"           # (which GEMM / which layers run the lo refinements) were frozen on the runs above
+RUN_CFG5_S5 = "sample_full14_256_s5"        # ... and of configs[4] (batch 4)
 RUN_C3_OUTLIER = "sample_full12_64_outlier"          # configs[2] / configs[1] on "trained-like" weights (synth._trained_like: heavy tails,
 RUN_CFG1_OUTLIER = "sample_full10_16_nocfg_outlier"  # massive-activation channels)
 RUN_C3_PRENORM = "sample_full12_64_prenorm"          # configs[2]'s sampler on the generator variants without a differential guided forward:

@@ -130,6 +130,7 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # those decisions were frozen and took no part in them
     "sample_full10_16_nocfg_s4": (10, 184, 16.0, 16, CFG1_16, False, 4332, 0),
     "sample_full12_64_s4": (12, 185, 16.0, 8, FULL64, False, 4333, 4),
+    "sample_full14_256_s5": (14, 186, 12.0, 4, CFG5_256, False, 4334, 10),       # (held out as well: configs[4], where precision 3's layer range was chosen)
     "sample_full12_64_outlier": (12, 190, 12.0, 4, FULL64, False, 4326, 2, "outlier"),
     "sample_full10_16_nocfg_outlier": (10, 191, 12.0, 16, CFG1_16, False, 4327, 0, "outlier"),
     # the two generator variants whose guided forward does not run in differential form on the engine (it falls back to the plain forward over

@@ -306,12 +306,12 @@ def test_parity_margin_over_weight_seeds_and_head_gain(wseed, gain):
 @pytest.mark.timeout(900)
 def test_held_out_reference_runs_default_precision():
     """Round 5 decided WHERE the lo refinements of the LayerNorm outputs run (FFN-up only, layers >= depth / 2) on the recorded runs of the reference
-    (profiles/r05_coverage.md).  These two runs -- configs[1] at batch 16 and configs[2] at batch 8, other weights / head gain / noise / labels -- were
+    (profiles/r05_coverage.md).  These runs -- configs[1] at batch 16, configs[2] at batch 8, configs[4] at batch 4; other weights / head gain / noise / labels -- were
     recorded AFTER those decisions were frozen and took no part in them: the product default must meet the north star's 1e-3 on each, and the 7e-4 the
     other runs' tests assert per run."""
     from maskbit_amd import parity_replay as R
-    for name in (R.RUN_CFG1_S4, R.RUN_C3_S4):
+    for name in (R.RUN_CFG1_S4, R.RUN_C3_S4, R.RUN_CFG5_S5):
         r = _vs_reference_run(name, [("product default", -1), ("differential / hi + lo operands alone (precision 1)", 1)])
         bad, tot = r["product default"]
-        assert tot >= 87040 and bad / tot <= 7e-4, (name, bad, tot)
+        assert tot >= 87040 and bad / tot <= (1e-3 if name == R.RUN_CFG5_S5 else 7e-4), (name, bad, tot)      # (configs[4]: the per-run bound of its other runs)
         assert bad < r["differential / hi + lo operands alone (precision 1)"][0]
