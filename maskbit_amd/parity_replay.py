@@ -38,6 +38,7 @@ RUN_CFG1_S4 = "sample_full10_16_nocfg_s4"   # round 5, end: HELD-OUT runs of con
 RUN_C3_S4 = "sample_full12_64_s4"           # (which GEMM / which layers run the lo refinements) were frozen on the runs above
 RUN_CFG5_S5 = "sample_full14_256_s5"        # ... and of configs[4] (batch 4)
 RUN_C3_OUTLIER = "sample_full12_64_outlier"          # configs[2] / configs[1] on "trained-like" weights (synth._trained_like: heavy tails,
+RUN_C3_OUTLIER_S2 = "sample_full12_64_outlier_s2"    # (round 5, end: a second trained-like 12-bit run, batch 8)
 RUN_CFG1_OUTLIER = "sample_full10_16_nocfg_outlier"  # massive-activation channels)
 RUN_C3_PRENORM = "sample_full12_64_prenorm"          # configs[2]'s sampler on the generator variants without a differential guided forward:
 RUN_C3_SEQ1024 = "sample_full12_64_seq1024"          # use_prenorm=True, and the 512 x 512 models' 1024 + 1 tokens

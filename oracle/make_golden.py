@@ -133,6 +133,7 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     "sample_full14_256_s5": (14, 186, 12.0, 4, CFG5_256, False, 4334, 10),       # (held out as well: configs[4], where precision 3's layer range was chosen)
     "sample_full12_64_outlier": (12, 190, 12.0, 4, FULL64, False, 4326, 2, "outlier"),
     "sample_full10_16_nocfg_outlier": (10, 191, 12.0, 16, CFG1_16, False, 4327, 0, "outlier"),
+    "sample_full12_64_outlier_s2": (12, 194, 16.0, 8, FULL64, False, 4335, 6, "outlier"),    # round 5, end: a second trained-like 12-bit run at twice the batch (the first: 7.2e-4 on 84 284 positions)
     # the two generator variants whose guided forward does not run in differential form on the engine (it falls back to the plain forward over
     # [cond | uncond]): use_prenorm=True (bert.py:49-59,106-123) and the 512 x 512 models' 1024 + 1 tokens (scripts/eval_maskbit.py:125,139-144)
     "sample_full12_64_prenorm": (12, 192, 12.0, 4, FULL64, False, 4328, 4, "gaussian", dict(prenorm=True)),

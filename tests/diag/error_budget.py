@@ -32,11 +32,13 @@ h16 = lambda t: t.to(torch.float16).to(torch.float32)
 E2M1 = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
 
 
-def q_e2m1(v, blk):
-    """e2m1 with one power-of-two scale per `blk` consecutive columns (0 = per row), scaled so that 3 < max <= 6 (mb_common.h fp4_nosat_exp)."""
+def q_e2m1(v, blk, skip=0):
+    """e2m1 with one power-of-two scale per `blk` consecutive columns (0 = per row), scaled so that 3 < max <= 6 (mb_common.h fp4_nosat_exp).
+    skip = n (study): the scale is taken from the (n + 1)-th largest magnitude of the block and the n larger ones saturate at 6 scale units -- what a
+    block with a massive-activation channel would need for the other 63 values to keep their resolution."""
     shp = v.shape
     w = v.reshape(-1, shp[-1]) if blk == 0 else v.reshape(-1, blk)
-    am = w.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    am = (w.abs().amax(-1, keepdim=True) if skip == 0 else w.abs().topk(skip + 1, dim=-1).values[:, -1:]).clamp_min(1e-30)
     e = torch.floor(torch.log2(am))
     mant = am / torch.exp2(e)
     e = e + (mant > 1.5).float()                     # amax * 2^-(e-2) in (3, 6]
@@ -73,9 +75,9 @@ class Emu:
         oc = F.linear(ac, W)
         if corr:
             if name not in self.wlo4:
-                self.wlo4[name] = q_e2m1(self.sd[name] - self.w16[name], 0)
+                self.wlo4[name] = q_e2m1(self.sd[name] - self.w16[name], self.o.get("wblk", 0))
             blk = self.o.get("blk", 64)
-            oc = oc + F.linear(q_e2m1(xc, blk), self.wlo4[name])
+            oc = oc + F.linear(xc if blk < 0 else q_e2m1(xc, blk, self.o.get("skip", 0)), self.wlo4[name])
         if xu is None:
             return oc + b, None
         if head:
@@ -150,6 +152,11 @@ def cases(guided):
          ("+ exact trunk weights (the ideal precision 2)", {**F16, "wt": "exact"}),
          ("+ fp4 correction, 64-column block scales", {**F16, "wt": "corr4", "blk": 64}),
          ("+ fp4 correction, one scale per row", {**F16, "wt": "corr4", "blk": 0}),
+         ("+ fp4 correction, 32-column block scales", {**F16, "wt": "corr4", "blk": 32}),
+         ("+ fp4 correction, 64-column, weights per 128", {**F16, "wt": "corr4", "blk": 64, "wblk": 128}),
+         ("+ fp4 correction, 64-column, scale skips top-1", {**F16, "wt": "corr4", "blk": 64, "skip": 1}),
+         ("+ fp4 correction, 32-column, skip top-1, w 128", {**F16, "wt": "corr4", "blk": 32, "skip": 1, "wblk": 128}),
+         ("+ fp4 correction, exact token operand", {**F16, "wt": "corr4", "blk": -1}),
          ("exact trunk weights + exact head weights", {**F16, "wt": "exact", "wh": "exact"}),
          ("exact weights, exact x", {**F16, "wt": "exact", "wh": "exact", "x": "exact"}),
          ("exact weights, exact att", {**F16, "wt": "exact", "wh": "exact", "att": "exact"}),
@@ -185,6 +192,8 @@ def main():
     S, B = g["steps"].shape[0], g["steps"].shape[1]
     guided_run = float(g["kw"]["guidance_scale"]) != 0.0
     steps = list(range(every // 2, S, every))
+    if os.environ.get("EB_STEPS"):                       # e.g. EB_STEPS=1,3,5,7: these steps only
+        steps = [int(t) for t in os.environ["EB_STEPS"].split(",")]
     C_ = g["C"]
     y = g["labels"]
     print(f"{name}: {S} steps, B = {B}, C = {C_}, steps used {steps}, scales {[round(scale[i], 2) for i in steps]}", flush=True)

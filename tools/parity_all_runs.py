@@ -12,7 +12,7 @@ GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C
           "HELD-OUT run (recorded after round 5's coverage decisions): configs[2]": [R.RUN_C3_S4],
           "HELD-OUT run: configs[1]": [R.RUN_CFG1_S4],
           "HELD-OUT run: configs[4]": [R.RUN_CFG5_S5],
-          "trained-like weights (heavy tails, massive-activation channels): configs[2]": [R.RUN_C3_OUTLIER],
+          "trained-like weights (heavy tails, massive-activation channels): configs[2]": [R.RUN_C3_OUTLIER, R.RUN_C3_OUTLIER_S2],
           "trained-like weights: configs[1]": [R.RUN_CFG1_OUTLIER],
           "use_prenorm=True, configs[2]'s sampler": [R.RUN_C3_PRENORM],
           "1024 + 1 tokens (512 x 512 models), configs[2]'s sampler": [R.RUN_C3_SEQ1024]}
