@@ -77,7 +77,8 @@ class Emu:
             if name not in self.wlo4:
                 self.wlo4[name] = q_e2m1(self.sd[name] - self.w16[name], self.o.get("wblk", 0))
             blk = self.o.get("blk", 64)
-            oc = oc + F.linear(xc if blk < 0 else q_e2m1(xc, blk, self.o.get("skip", 0)), self.wlo4[name])
+            skip = self.o.get("skip", 0) if (key == "x" or not self.o.get("skip_x_only")) else 0
+            oc = oc + F.linear(xc if blk < 0 else q_e2m1(xc, blk, skip), self.wlo4[name])
         if xu is None:
             return oc + b, None
         if head:
@@ -155,6 +156,8 @@ def cases(guided):
          ("+ fp4 correction, 32-column block scales", {**F16, "wt": "corr4", "blk": 32}),
          ("+ fp4 correction, 64-column, weights per 128", {**F16, "wt": "corr4", "blk": 64, "wblk": 128}),
          ("+ fp4 correction, 64-column, scale skips top-1", {**F16, "wt": "corr4", "blk": 64, "skip": 1}),
+         ("+ fp4 correction, 64-column, LayerNorm outputs skip top-1", {**F16, "wt": "corr4", "blk": 64, "skip": 1, "skip_x_only": True}),
+         ("+ fp4 correction, 64-column, LayerNorm outputs skip top-1, w 128", {**F16, "wt": "corr4", "blk": 64, "skip": 1, "skip_x_only": True, "wblk": 128}),
          ("+ fp4 correction, 32-column, skip top-1, w 128", {**F16, "wt": "corr4", "blk": 32, "skip": 1, "wblk": 128}),
          ("+ fp4 correction, exact token operand", {**F16, "wt": "corr4", "blk": -1}),
          ("exact trunk weights + exact head weights", {**F16, "wt": "exact", "wh": "exact"}),
