@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MB_ABI_VERSION 7
+#define MB_ABI_VERSION 8
 enum { MB_PREC_FP16 = 0, MB_PREC_DIFF = 1, MB_PREC_WCORR = 2, MB_PREC_ALO = 3 };
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
@@ -104,9 +104,8 @@ int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, cons
                    float* logits, int nb, mb_stream stream);
 /* The guided forward of sample() (sampling.py:83-88): tokens int64 [B,seq,m], labels int64 [B] -> logits fp32 [2B,seq,m,C], rows [0,B) the
  * conditional and [B,2B) the label-dropped forward of the same tokens.  With cfg.precision >= 1 the two streams run in differential form
- * (see mb_gen_cfg.precision).  `scale` is reserved (ignored: the precision of the forward does not depend on the guidance scale); pass the
- * step's scale or any number. */
-int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, mb_stream stream);
+ * (see mb_gen_cfg.precision); the precision of the forward does not depend on the guidance scale the caller combines the two halves with. */
+int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, mb_stream stream);
 /* The same forward with `return_attn=True` (bert.py:461, 505-508; nn.MultiheadAttention need_weights with head averaging,
  * bert.py:119,137): additionally attn fp32 [depth, nb, seq+1, seq+1], layer l's softmax weights averaged over the heads
  * (class token = last row / column).  Visualisation path, not used by sample(). */

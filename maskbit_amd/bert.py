@@ -209,10 +209,10 @@ class LFQBert(BaseModel):
 
 
     @torch.no_grad()
-    def forward_cfg(self, img_tokens: torch.Tensor, class_labels: torch.Tensor, scale: float = -1.0) -> torch.Tensor:
+    def forward_cfg(self, img_tokens: torch.Tensor, class_labels: torch.Tensor) -> torch.Tensor:
         """The guided forward of sample() (sampling.py:83-88) in one call: logits [2b, seq, m, C], rows [0, b) = model(tokens, labels, ~drop),
-        rows [b, 2b) = the label-dropped forward of the same tokens.  On the engine the two streams run in differential form (precision >= 1);
-        ``scale`` is the guidance scale the caller will combine them with (precision plan hint; negative = unknown)."""
+        rows [b, 2b) = the label-dropped forward of the same tokens.  On the engine the two streams run in differential form (precision >= 1),
+        whatever guidance scale the caller combines them with."""
         dev = self._require_cuda("forward_cfg")
         if img_tokens.dim() != 3 or img_tokens.shape[1] != self.seq_len or img_tokens.shape[2] != self.splits:
             raise ValueError(f"img_tokens must be [b, {self.seq_len}, {self.splits}], got {tuple(img_tokens.shape)}")
@@ -225,7 +225,7 @@ class LFQBert(BaseModel):
         logits = torch.empty((2 * b, self.seq_len, self.splits, self.effective_codebook_size), dtype=torch.float32, device=dev)
         h = self.engine(2 * b)
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().mb_gen_forward_cfg(h, toks.data_ptr(), labs.data_ptr(), logits.data_ptr(), b, float(scale),
+            _lib.check(_lib.load().mb_gen_forward_cfg(h, toks.data_ptr(), labs.data_ptr(), logits.data_ptr(), b,
                                                       torch.cuda.current_stream().cuda_stream), "mb_gen_forward_cfg")
         return logits
 

@@ -601,7 +601,7 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d,
 extern "C" int mb_debug_att_trace(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(mb::g_att_trace), &p, sizeof(p)); }
 #endif
 #if defined(MB_ATT_TRACE) || defined(MB_ATT_VARIANT)      // experimental builds of this file alone (tools/att_trace.py)
-extern "C" int mb_debug_attention_pair(const void* qkv, void* out, float* aux, int P, int N, int d, int heads, void* stream) {
+extern "C" int mb_debug_attention_pair(const void* qkv, void* out, int P, int N, int d, int heads, void* stream) {
   return mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out, P, N, d, heads, nullptr, nullptr);
 }
 #endif

@@ -197,9 +197,14 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
   //         WEIGHTS is 80 % of the sampled-logit error variance here (tests/diag/error_budget.py: rms 0.0082 single fp16, 0.0073 with hi + lo
   //         activation pairs, 0.0045 with the weight correction alone); both together: 5.3e-4 over configs[1]'s three reference runs.
   const bool xlo = c.precision >= 1;
-  auto xlo_layer = [&](int l) { return xlo && 2 * l + 1 >= c.depth; };   // (the second half of the layers: see above)
-  h16* const xlo_ffn = xlo ? g->x_lo : nullptr;          // the LayerNorm in front of FFN-up writes lo halves (the one in front of QKV does not; the last one feeds the head)
   const bool wm = g->mini_ok && c.precision >= 2;   // (sequence tiles: 256 + 1 rows, or four tiles per 1024 + 1-row sequence)
+  // Both coverage rules above (FFN-up only, late layers only) were measured WITH the weight correction on, on shapes the mini-tiles serve.  Shapes they
+  // do not serve (other widths, heads of 32, sequences other than 256 / 1024 tokens) have no weight correction to carry the margin: there the hi + lo
+  // LayerNorm outputs enter QKV and FFN-up of EVERY layer, as in rounds 3-4 (round-5 advice: the narrowed rule was a silent regression for them).
+  const bool xlo_all = xlo && !wm;
+  auto xlo_layer = [&](int l) { return xlo && (xlo_all || 2 * l + 1 >= c.depth); };   // (with the correction: the second half of the layers, see above)
+  h16* const xlo_ffn = xlo ? g->x_lo : nullptr;          // the LayerNorm in front of FFN-up writes lo halves (the one in front of QKV only without the correction; the last one feeds the head)
+  h16* const xlo_qkv = xlo_all ? g->x_lo : nullptr;
   // the LayerNorms write the MX-fp4 copy (+ scale bytes) only when a GEMM of THIS forward reads it (the buffers also exist for the pair forward)
   Fp4Rows f4x;
   if (wm && (g->wcorr_mask & 5)) { f4x.x4 = g->x4; f4x.x4s = g->x4s; f4x.nseq = nb; f4x.seq_rows = N; }
@@ -214,7 +219,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     if (wm) ga.seq_rows = N;
     lo_set(ga, g->x4, g->x4s, widx);
     if (wm && epi == EPI_GELU_H16 && (g->wcorr_mask & 8)) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
-    if ((widx & 3) == 2 && xlo_layer(widx >> 2)) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }   // FFN-up only (see above)
+    if (((widx & 3) == 2 || xlo_all) && xlo_layer(widx >> 2)) { ga.K = 2 * d; ga.A2 = g->x_lo; ga.kw = d; }   // FFN-up only with the correction (see above)
     ga.sat = g->sat;
     gemm_rc |= gemm_tn(s, epi, ga, wm ? 257 : 0);
   };
@@ -230,7 +235,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     ProfScope p("embed_ln", s, true);
     EmbedArgs e{tokens, labels, drop, g->w_in, g->b_in, g->class_emb, g->pos, g->ln0g, g->ln0b,
                 g->y_f32, g->x_h16, nb, c.seq, c.splits, g->gbits, d, c.nclass, g->tables};
-    e.x_lo = c.depth ? nullptr : g->x_lo;
+    e.x_lo = c.depth ? (c.prenorm ? nullptr : xlo_qkv) : g->x_lo;
     e.f4 = f4x;
     embed_ln(s, e);
   }
@@ -240,7 +245,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
     // fp16 GEMM operand and {mean, rstd}, the next residual GEMM re-derives the normalised rows in its epilogue and updates y_f32 in place (layer 0's
     // first residual is the embedding LayerNorm output, stored as is by embed_ln).  use_prenorm (bert.py:49-59, 106-123): x = x + Attn(LN(x));
     // x = x + FFN(LN(x)): the buffer holds x itself, every LayerNorm only produces the GEMM operand, the residual GEMMs add the buffer's own rows.
-    if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, nullptr, f4x); }
+    if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, L.ln1g, L.ln1b, 1e-12f, nullptr, g->x_h16, nullptr, M, d, xlo_qkv, f4x); }
     { ProfScope p("gemm_qkv", s, true); xgemm(EPI_H16, L.wqkv, L.bqkv, g->qkv, 3 * d, 4 * l); }
     { ProfScope p("attention", s, true); attention(s, g->qkv, g->att, nb, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
     attn_rc |= attn_maps(l);
@@ -254,7 +259,7 @@ int gen_forward_impl(mb_gen* g, const int64_t* tokens, const int64_t* labels, co
       rgemm(g->h, L.w2, L.b2, f, 4 * l + 3, g->h4, g->h4s, c.prenorm ? nullptr : L.ln1g, c.prenorm ? nullptr : L.ln1b); }
     if (!c.prenorm) { ProfScope p("layernorm", s, true);
       const bool last = l + 1 == c.depth;                  // the last one feeds the head: plain hi + lo rows
-      layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, last ? g->x_lo : nullptr, last ? Fp4Rows{} : f4x); }
+      layernorm_rows(s, g->y_f32, L.ln2g, L.ln2b, 1e-12f, nullptr, g->x_h16, g->ln_stats, M, d, last ? g->x_lo : xlo_qkv, last ? Fp4Rows{} : f4x); }
   }
   if (c.prenorm) { ProfScope p("layernorm", s, true); layernorm_rows(s, g->y_f32, g->lnag, g->lnab, 1e-12f, nullptr, g->x_h16, nullptr, M, d, g->x_lo); }   // norm_after_transformer
   gemm_rc |= head_gemms(g, logits, M, s);
@@ -277,8 +282,8 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   const int d = c.hidden, f = c.mlp, N = g->N, nb = 2 * B, M = nb * N, P = B * N;
   int rc = 0;
   // measured (profiles/r03_parity.md): the correction pass in layers >= depth / 2 alone buys about 60 % of the gain on the 12-bit runs for half of
-  // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- an option
-  // (mb_gen_set_wcorr_from), not the default
+  // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- a study knob
+  // (mb_gen_set_wcorr, include/maskbit_hip_diag.h), not the default
   const int wfrom = g->wcorr_from;
   // precision 3: + activation-lo mini-tiles of the LayerNorm outputs in FFN-UP of the layers >= depth / 2.  Round 4 ran the set in QKV and FFN-up of every
   // layer.  Over FOUR 14-bit / 256-step reference runs (1 002 744 positions; profiles/r05_coverage.md, raw/r05/alo_mask.log, alo_layers.log): both GEMMs,
@@ -384,10 +389,9 @@ int gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, const u
 }
 
 // Guided forward (sampling.py:83-88) over B samples: logits rows [0, B) conditional, [B, 2B) label-dropped.
-int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, hipStream_t s) {
+int gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, hipStream_t s) {
   const size_t P = (size_t)g->c.seq * g->c.splits;
   const bool pair = g->pair_ok && g->c.precision >= 1;
-  (void)scale;
   const bool wmode = pair && g->c.precision >= 2;       // weight-rounding correction pass (every step: weight rounding costs parity late in the run too)
   const int chunk = g->chunk_seqs / 2;                  // pairs per pass
   if (chunk < 1) return fail(-1, "engine holds %d sequences: too few for a guided forward", g->chunk_seqs);
@@ -671,6 +675,9 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   int wrows = 0, wcols = 0, sidx = -1;                 // GEMM weights: [rows, cols] and their output-scale slot
   int l = -1, sub = -1; char rest[96] = {0};
   std::string n(name);
+  // the embedding-table generator (Bert) has neither a bit projection nor an untied prediction layer: those keys belong to LFQBert checkpoints
+  if (c.embed_tables && (n.rfind("prediction_layer.", 0) == 0 || n.rfind("input_proj.", 0) == 0))
+    return fail(-2, "mb_gen_load: unknown checkpoint entry '%s' (embed_tables engine: tok_emb_list.* / bias.* instead)", name);
   if (sscanf(name, "transformer.layers.%d.%d.%95s", &l, &sub, rest) == 3) {
     if (l < 0 || l >= c.depth) return fail(-2, "layer index out of range in '%s'", name);
     mb_gen::Layer& L = g->layers[l];
@@ -765,10 +772,10 @@ int mb_gen_forward(mb_gen* g, const int64_t* tokens, const int64_t* labels, cons
   return gen_forward(g, tokens, labels, drop, logits, nb, (hipStream_t)stream);
 }
 
-int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, float scale, mb_stream stream) {
+int mb_gen_forward_cfg(mb_gen* g, const int64_t* tokens, const int64_t* labels, float* logits, int B, mb_stream stream) {
   if (!g || !tokens || !labels || !logits) return fail(-1, "mb_gen_forward_cfg: null argument");
   if (B <= 0 || 2 * B > g->max_seqs) return fail(-1, "mb_gen_forward_cfg: B=%d needs %d sequences, engine holds %d", B, 2 * B, g->max_seqs);
-  return gen_forward_cfg(g, tokens, labels, logits, B, scale, (hipStream_t)stream);
+  return gen_forward_cfg(g, tokens, labels, logits, B, (hipStream_t)stream);
 }
 
 int mb_gen_forward_attn(mb_gen* g, const int64_t* tokens, const int64_t* labels, const uint8_t* drop, float* logits, float* attn,
@@ -882,7 +889,7 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
     // is below float32's cos() resolution -- the unconditional logits do not enter the result (c + 0 (c - u) == c for finite logits), so that
     // forward is not run: the step is the plain conditional forward, bit for bit what the guided expression evaluates to.
     if (plan->use_guidance && plan->scale[i] != 0.0f) {
-      rc = gen_forward_cfg(g, cur, labels, g->logits, B, plan->scale[i], s);
+      rc = gen_forward_cfg(g, cur, labels, g->logits, B, s);
       lu = g->logits + (size_t)B * P * C;
       if (B <= g->chunk_seqs / 2) { g->cfg_labels_ready = labels; g->cfg_ready_B = B; }   // lab_cfg / drop_cfg stay valid for the rest of this call
     } else {

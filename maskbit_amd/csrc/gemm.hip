@@ -271,6 +271,7 @@ __global__ void split_kernel(const float* __restrict__ src, h16* __restrict__ ds
   }
 }
 void split_f32_to_h16_planes(hipStream_t s, const float* src, h16* hi, h16* lo, int N, int K, float* scale_out, unsigned* tmp) {
+  if (!hi || !lo) abort();                              // both planes are written unconditionally (callers own both buffers)
   const size_t n = (size_t)N * K;
   const int blocks = (int)min((size_t)2048, (n + 255) / 256);
   (void)hipMemsetAsync(tmp, 0, sizeof(unsigned), s);

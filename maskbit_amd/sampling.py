@@ -49,23 +49,26 @@ NOISE_CHUNK_BYTES = 1 << 30       # sample() / generate_uint8() draw and feed th
 OVERLAP_CHUNKS = 8                # ... and in at least this many chunks (+ a one-step head): the host draws chunk k+1 while the device runs chunk k
 
 
-class _FewCpuThreads:
-    """The host-side draws are a few small CPU tensor ops per step.  With the default intra-op pool of a many-core host (128 OpenMP threads on the
-    256-CPU MI355X boxes) every such op wakes the pool, whose workers then spin -- and the HIP runtime's own host threads starve: measured on
-    BASELINE configs[1] (16 steps, batch 16) 345 ms per run against 136 ms of device time, stalls of 70-180 ms landing on whatever host call came
-    next.  Inside this context the pool is held at one thread (the draws are far below any parallel grain that pays; torch's CPU generators
-    produce the same stream for any thread count) and restored afterwards."""
+SERIAL_DRAW_ELEMS = 16384      # below ATen's intra-op grain (32 768 elements): a CPU tensor op of this size runs on the calling thread alone
 
-    def __enter__(self):
-        self.n = torch.get_num_threads()
-        if self.n > 1:
-            torch.set_num_threads(1)
-        return self
 
-    def __exit__(self, *exc):
-        if self.n > 1:
-            torch.set_num_threads(self.n)
-        return False
+def _draw_conf_serial(gumbel, num_samples: int, n: int, m: int, steps, num_steps: int, randomize_temperature: float) -> torch.Tensor:
+    """The reference's per-step confidence noise (sampling.py:113-117: one ``Gumbel(0, 1).sample([B, n, m])`` from the CPU default generator, scaled by
+    randomize_temperature * (1 - progress)) for `steps`, drawn in row blocks of at most SERIAL_DRAW_ELEMS elements.
+    Why blocks: the draws are a few small CPU tensor ops per step; at batch 64 each is just above ATen's parallel grain, so with the default intra-op pool
+    of a many-core host (128 OpenMP threads on the 256-CPU MI355X boxes) every op wakes the pool, whose workers then spin -- and the HIP runtime's own host
+    threads starve: measured on BASELINE configs[1] (16 steps, batch 16) 345 ms per run against 136 ms of device time.  Rounds 3-5 held the pool at one
+    thread around the draws (``torch.set_num_threads``: visible to every host thread of the process, and inherited by threads created meanwhile); blocks
+    below the grain never enter the pool, so NO thread setting is touched.  Same stream: torch's CPU ``rand`` consumes the generator element by element
+    in order, so consecutive block draws are the one whole draw (tests/test_host_cpu.py compares the bits)."""
+    rows = max(1, SERIAL_DRAW_ELEMS // (n * m))
+    out = torch.empty((len(steps), num_samples, n, m), dtype=torch.float32)
+    for j, i in enumerate(steps):
+        progress = (i + 1) / num_steps
+        for r0 in range(0, num_samples, rows):
+            k = min(rows, num_samples - r0)
+            out[j, r0:r0 + k] = gumbel.sample((k, n, m)) * randomize_temperature * (1 - progress)      # (the reference's order of the two products)
+    return out
 
 
 _COPY_STREAMS = {}
@@ -105,12 +108,7 @@ def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, random
     for i in range(step_end - step_begin):
         exp_noise[i].exponential_(1)
     gumbel = torch.distributions.Gumbel(loc=0.0, scale=1.0)                     # python-float params => CPU draws
-    conf = []
-    with _FewCpuThreads():
-        for i in range(step_begin, step_end):
-            progress = (i + 1) / num_steps
-            conf.append(gumbel.sample((num_samples, n, m)) * randomize_temperature * (1 - progress))
-        conf = torch.stack(conf)
+    conf = _draw_conf_serial(gumbel, num_samples, n, m, range(step_begin, step_end), num_steps, randomize_temperature)
     return exp_noise, _to_device_early(conf, device)
 
 

@@ -48,11 +48,50 @@ def q_e2m1(v, blk, skip=0):
     return (torch.sign(w) * E2M1[idx] * sc).reshape(shp)
 
 
+E2M3 = torch.tensor([i * 0.125 for i in range(8)] + [1.0 + i * 0.125 for i in range(8)] + [2.0 + i * 0.25 for i in range(8)] + [4.0 + i * 0.5 for i in range(8)])
+
+
+def q_grid(v, blk, grid):
+    """Block-scaled quantisation onto `grid` (non-negative magnitudes, sign separate): one power-of-two scale per `blk` columns (0 = per row), the
+    largest magnitude of a block never saturates (scaled into (max / 2, max])."""
+    shp = v.shape
+    w = v.reshape(-1, shp[-1]) if blk == 0 else v.reshape(-1, blk)
+    am = w.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    gmax = float(grid[-1])
+    e = torch.ceil(torch.log2(am / gmax))              # am / 2^e in (gmax / 2, gmax]
+    sc = torch.exp2(e)
+    a = (w / sc).abs().clamp(max=gmax)
+    idx = torch.bucketize(a, (grid[1:] + grid[:-1]) / 2)
+    return (torch.sign(w) * grid[idx] * sc).reshape(shp)
+
+
+def q_e2m1_best(W):
+    """e2m1 of weight VALUES with the per-row scale that minimises the row's quantisation error (mb::w4_from_f32): no-saturation scale or one binade lower."""
+    a = q_e2m1(W, 0)
+    b = q_e2m1(W * 2, 0) / 2                             # not a different scale by itself (q_e2m1 rescales) -- kept for symmetry
+    w = W.reshape(-1, W.shape[-1])
+    am = w.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    e = torch.floor(torch.log2(am)); mant = am / torch.exp2(e); e = e + (mant > 1.5).float()
+    best, berr = None, None
+    for de in (0, -1):
+        sc = torch.exp2(e - 2 + de)
+        aa = (w / sc).abs().clamp(max=6.0)
+        idx = torch.bucketize(aa, (E2M1[1:] + E2M1[:-1]) / 2)
+        qq = torch.sign(w) * E2M1[idx] * sc
+        err = (qq - w).pow(2).sum(-1, keepdim=True)
+        if best is None: best, berr = qq, err
+        else:
+            take = err < berr
+            best = torch.where(take, qq, best); berr = torch.where(take, err, berr)
+    return best.reshape(W.shape)
+
+
 class Emu:
     def __init__(self, sd, cfg, o):
         self.sd, self.cfg, self.o = sd, cfg, o
         self.w16 = {k: h16(v) for k, v in sd.items() if v.dim() == 2}
         self.wlo4 = {}
+        self.w4 = {}
 
     def rnd(self, key, t):
         return h16(t) if self.o[key] == "f16" else t
@@ -67,7 +106,7 @@ class Emu:
         """One Linear over the conditional rows xc and (guided) the unconditional rows xu -> (out_c, out_u)."""
         W = self.weight(name, head)
         b = self.sd[bias]
-        corr = (not head) and self.o["wt"] == "corr4"
+        corr = (not head) and self.o["wt"] in ("corr4", "corr6")
         if head:
             ac = xc
         else:
@@ -75,10 +114,48 @@ class Emu:
         oc = F.linear(ac, W)
         if corr:
             if name not in self.wlo4:
-                self.wlo4[name] = q_e2m1(self.sd[name] - self.w16[name], self.o.get("wblk", 0))
+                err = self.sd[name] - self.w16[name]
+                if self.o["wt"] == "corr6":                                  # e2m3 weight-error operand (study)
+                    self.wlo4[name] = q_grid(err, self.o.get("wblk", 0), E2M3)
+                else:
+                    q1 = q_e2m1(err, self.o.get("wblk", 0))
+                    if self.o.get("wlevels", 1) == 2:                         # second e2m1 set on what the first one left (study)
+                        q1 = q1 + q_e2m1(err - q1, self.o.get("wblk", 0))
+                    self.wlo4[name] = q1
             blk = self.o.get("blk", 64)
             skip = self.o.get("skip", 0) if (key == "x" or not self.o.get("skip_x_only")) else 0
-            oc = oc + F.linear(xc if blk < 0 else q_e2m1(xc, blk, skip), self.wlo4[name])
+            ntop = self.o.get("tok_top", 0) if (key in self.o.get("tok_top_keys", ("x",))) else 0
+            xs = xc
+            if ntop:                                                          # study: the n largest channels leave the e2m1 token operand (their block scales
+                sel = xc.abs().reshape(-1, xc.shape[-1]).mean(0).topk(ntop).indices   # then serve the other values) and meet the EXACT weight error in an fp16 K-tile
+                xs = xc.clone(); xs[..., sel] = 0.0
+                oc = oc + F.linear(h16(xc[..., sel]), (self.sd[name] - self.w16[name])[:, sel])
+            xq = xs if blk < 0 else (q_grid(xs, blk, E2M3) if self.o.get("tok6") else q_e2m1(xs, blk, skip))
+            oc = oc + F.linear(xq, self.wlo4[name])
+        # activation-lo corrections on the conditional rows (study, round 6): what the fp16 rounding of this operand leaves, multiplied by ...
+        alo = (self.o.get("alo") or {}).get(key) if not head else None
+        if alo and self.o[key] == "f16":
+            lo = xc - h16(xc)
+            if alo == "f16":                                                  # ... the fp16 weight (a full second sweep)
+                oc = oc + F.linear(h16(lo), W)
+            elif alo == "e2m1":                                               # ... e2m1 of the weight values, lo as e2m1 with 64-column scales (a mini-tile set)
+                if name not in self.w4:
+                    self.w4[name] = q_e2m1_best(self.w16[name]) if not self.o.get("w4blk") else q_e2m1(self.w16[name], self.o["w4blk"])
+                ntop = self.o.get("tok_top", 0) if (key in self.o.get("tok_top_keys", ("x",))) else 0
+                if ntop:                                                      # the same channels' lo halves meet the fp16 weight in that K-tile
+                    sel = xc.abs().reshape(-1, xc.shape[-1]).mean(0).topk(ntop).indices
+                    los = lo.clone(); los[..., sel] = 0.0
+                    oc = oc + F.linear(h16(lo[..., sel]), W[:, sel]) + F.linear(q_e2m1(los, 64), self.w4[name])
+                else:
+                    oc = oc + F.linear(q_e2m1(lo, 64), self.w4[name])
+            elif alo == "e2m3":                                               # ... both operands e2m3 (FP6 at the FP4 rate)
+                if name not in self.w4:
+                    self.w4[name] = q_grid(self.w16[name], 0, E2M3)
+                oc = oc + F.linear(q_grid(lo, 64, E2M3), self.w4[name])
+            elif alo.startswith("top"):                                       # ... fp16 weights on the `n` channels with the largest mean |x| (outlier K-tile)
+                n = int(alo[3:])
+                sel = xc.abs().reshape(-1, xc.shape[-1]).mean(0).topk(n).indices
+                oc = oc + F.linear(h16(lo[..., sel]), W[:, sel])
         if xu is None:
             return oc + b, None
         if head:
@@ -180,7 +257,67 @@ def cases(guided):
     return c
 
 
+def cases_r6(guided):
+    """Round 6: what closes the heavy-tailed runs.  ENG = the engine's default as built (precision 2): fp16 operands, differential form, MX-fp4 weight
+    correction with 64-column token scales, head effectively exact (hi + lo inputs x hi + lo weights)."""
+    ENG = {**F16, "wt": "corr4", "blk": 64, "wh": "exact"}
+    A = lambda **kw: {"alo": kw}
+    c = [("engine default (corr4, exact head)", dict(ENG)),
+         ("exact trunk weights, exact head", {**ENG, "wt": "exact"}),
+         ("corr4 two levels", {**ENG, "wlevels": 2}),
+         ("corr6 weight error (e2m3)", {**ENG, "wt": "corr6"}),
+         ("corr6 weight error, e2m3 tokens", {**ENG, "wt": "corr6", "tok6": True}),
+         ("alo x e2m1", {**ENG, **A(x="e2m1")}),
+         ("alo x top64", {**ENG, **A(x="top64")}),
+         ("alo x f16", {**ENG, **A(x="f16")}),
+         ("alo att e2m1", {**ENG, **A(att="e2m1")}),
+         ("alo att f16", {**ENG, **A(att="f16")}),
+         ("alo h e2m1", {**ENG, **A(h="e2m1")}),
+         ("alo h f16", {**ENG, **A(h="f16")}),
+         ("alo x att h e2m1", {**ENG, **A(x="e2m1", att="e2m1", h="e2m1")}),
+         ("alo x att h e2m3", {**ENG, **A(x="e2m3", att="e2m3", h="e2m3")}),
+         ("alo x att h f16", {**ENG, **A(x="f16", att="f16", h="f16")}),
+         ("alo x att h e2m1 + corr4 two levels", {**ENG, "wlevels": 2, **A(x="e2m1", att="e2m1", h="e2m1")}),
+         ("alo x att h e2m1 + corr6", {**ENG, "wt": "corr6", **A(x="e2m1", att="e2m1", h="e2m1")}),
+         ("alo x att h f16 + exact weights", {**ENG, "wt": "exact", **A(x="f16", att="f16", h="f16")}),
+         ("alo x att h f16 + exact weights + exact qkv p", {**ENG, "wt": "exact", "qkv": "exact", "p": "exact", **A(x="f16", att="f16", h="f16")})]
+    if os.environ.get("EB_SET") == "2":
+        X3 = A(x="e2m1", att="e2m1", h="e2m1")
+        c = [("engine default (corr4, exact head)", dict(ENG)),
+             ("tok6 only (e2m3 tokens, e2m1 weight error)", {**ENG, "tok6": True}),
+             ("x top8 out of the token operand", {**ENG, "tok_top": 8}),
+             ("x top32 out of the token operand", {**ENG, "tok_top": 32}),
+             ("x att h top32 out of the token operand", {**ENG, "tok_top": 32, "tok_top_keys": ("x", "att", "h")}),
+             ("32-column token scales", {**ENG, "blk": 32}),
+             ("alo x att h e2m1", {**ENG, **X3}),
+             ("alo x att h e2m1, x top8", {**ENG, **X3, "tok_top": 8}),
+             ("alo x att h e2m1, x top32", {**ENG, **X3, "tok_top": 32}),
+             ("alo x att h e2m1, x att h top32", {**ENG, **X3, "tok_top": 32, "tok_top_keys": ("x", "att", "h")}),
+             ("alo x att h e2m1, 32-column token scales", {**ENG, **X3, "blk": 32}),
+             ("alo x att h e2m1, x top32, weights per 128", {**ENG, **X3, "tok_top": 32, "wblk": 128}),
+             ("alo x att h e2m1, x top32, weights per 32", {**ENG, **X3, "tok_top": 32, "wblk": 32})]
+    if os.environ.get("EB_SET") == "3":
+        X3 = A(x="e2m1", att="e2m1", h="e2m1")
+        c = [("engine default (corr4, exact head)", dict(ENG)),
+             ("weights per 32", {**ENG, "wblk": 32}),
+             ("weights per 128", {**ENG, "wblk": 128}),
+             ("alo x att h e2m1", {**ENG, **X3}),
+             ("alo x att h e2m1, weights per 128", {**ENG, **X3, "wblk": 128}),
+             ("alo x att h e2m1, weights per 32", {**ENG, **X3, "wblk": 32}),
+             ("alo x att h e2m1, weights per 32, W values per 32", {**ENG, **X3, "wblk": 32, "w4blk": 32}),
+             ("alo x att h e2m1, x top8, weights per 32", {**ENG, **X3, "tok_top": 8, "wblk": 32}),
+             ("alo x att h e2m1, x top8, weights per 32, W values per 32", {**ENG, **X3, "tok_top": 8, "wblk": 32, "w4blk": 32}),
+             ("alo x att h e2m1, x top32, weights per 32, W values per 32", {**ENG, **X3, "tok_top": 32, "wblk": 32, "w4blk": 32}),
+             ("alo x e2m1 only, x top8, weights per 32, W values per 32", {**ENG, **A(x="e2m1"), "tok_top": 8, "wblk": 32, "w4blk": 32}),
+             ("no alo, x top8, weights per 32", {**ENG, "tok_top": 8, "wblk": 32}),
+             ]
+    return c
+
+
 def main():
+    if os.environ.get("EB_STUDY") == "r6":
+        global cases
+        cases = cases_r6
     torch.set_num_threads(int(os.environ.get("THREADS", "8")))
     name = sys.argv[1] if len(sys.argv) > 1 else R.RUN_CFG5
     every = int(sys.argv[2]) if len(sys.argv) > 2 else 16

@@ -39,7 +39,7 @@ def _replay(lib, _lib, cfg, model, rec, B, labels, kw):
     for i, r in enumerate(rec):
         tin = r.tokens_in.to(DEV).contiguous()
         if cfgd:
-            lg = model.forward_cfg(tin, labels.to(DEV), r.scale)          # the guided forward of the loop
+            lg = model.forward_cfg(tin, labels.to(DEV))          # the guided forward of the loop
             lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
         else:
             lc, lu = model(tin, labels.to(DEV), torch.zeros(B, dtype=torch.bool, device=DEV)), None
@@ -235,7 +235,7 @@ def _full_length_run(bits, num_steps, B, kw, seed):
     stream = torch.cuda.current_stream().cuda_stream
     for i in range(num_steps):
         if gs != 0.0 and plan[0][i] != 0.0:                 # (where the annealed scale is exactly 0 the loop runs the conditional forward alone: c + 0 (c - u) == c)
-            lg = model.forward_cfg(tok, labels, plan[0][i])
+            lg = model.forward_cfg(tok, labels)
             lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
         else:
             lc, lu = model(tok, labels, torch.zeros(B, dtype=torch.bool, device=DEV)), None

@@ -55,7 +55,7 @@ def test_generator_plain_forward_precision_modes_full12_and_tiny():
     FFN-up as an fp16 hi + lo pair (the GEMM-input rounding is 13 % of the error variance); 2 = + the MX-fp4 weight-correction mini-tiles on every
     trunk GEMM (the weights' rounding is most of the rest).  Each step moves the logits closer to the reference's fp32 golden; batch invariance holds
     bit for bit in every mode; switching the mode on a live model rebuilds the engine.  The tiny model (128-square GEMM kernel, no pair / mini tiles)
-    runs modes >= 1 with hi + lo LayerNorm outputs alone."""
+    runs modes >= 1 with hi + lo LayerNorm outputs alone -- in QKV and FFN-up of every layer (no weight correction there to carry the margin)."""
     z = load_golden("gen_full12.npz")
     cfg = O.GenCfg(bits=12, splits=2)
     sd = O.make_generator_weights(cfg, seed=int(z["seed"]), head_gain=float(z["head_gain"]))
@@ -87,7 +87,7 @@ def test_generator_plain_forward_precision_modes_full12_and_tiny():
     mt.precision = 1
     a1 = rel_fro(mt(t, y, d), rt)
     print(f"tiny: {a0:.2e} -> {a1:.2e}")
-    assert a1 < 2e-3 and a1 < 1.02 * a0
+    assert a1 < 2e-3 and a1 < 0.97 * a0                           # hi + lo LayerNorm outputs in QKV and FFN-up of every layer: a strict improvement
 
 
 def test_generator_batch_invariance_and_determinism():

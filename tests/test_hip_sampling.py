@@ -84,7 +84,7 @@ def test_teacher_forced_token_parity_full_size():
         bad = tot = 0
         for r in rec:
             tin = r.tokens_in.to(DEV).contiguous()
-            lg = m.forward_cfg(tin, y.to(DEV), r.scale)                  # the guided forward of the loop
+            lg = m.forward_cfg(tin, y.to(DEV))                  # the guided forward of the loop
             lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
             assert float((lc.cpu() - r.logits_c).abs().mean()) < 0.03
             tout, pred = torch.empty_like(tin), torch.empty_like(tin)

@@ -35,15 +35,15 @@ def test_guided_forward_batch_invariance_full_size(bits, pair):
     tok = torch.randint(0, C_ + 1, (64, 256, 2), generator=g)
     tok[torch.rand(64, 256, 2, generator=g) < 0.5] = C_             # half of the positions masked
     tok, y = tok.to(DEV), torch.randint(0, 1000, (64,), generator=g).to(DEV)
-    full = m.forward_cfg(tok, y, 5.0)
+    full = m.forward_cfg(tok, y)
     assert torch.isfinite(full).all() and full.shape[0] == 128
-    assert torch.equal(m.forward_cfg(tok, y, 5.0), full)            # deterministic at the timed size
+    assert torch.equal(m.forward_cfg(tok, y), full)            # deterministic at the timed size
     for b in (1, 4, 31, 32):
-        part = m.forward_cfg(tok[:b], y[:b], 5.0)
+        part = m.forward_cfg(tok[:b], y[:b])
         assert torch.equal(part[:b], full[:b]), f"conditional logits differ at B = {b}"
         assert torch.equal(part[b:], full[64:64 + b]), f"label-dropped logits differ at B = {b}"
     # a pair in the middle of the batch, moved to the front of a smaller one
-    part = m.forward_cfg(tok[40:45], y[40:45], 5.0)
+    part = m.forward_cfg(tok[40:45], y[40:45])
     assert torch.equal(part[:5], full[40:45]) and torch.equal(part[5:], full[104:109])
     assert m.saturation_count() == 0
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mb_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.mb_abi_version() == _lib.ABI_VERSION == 8
     assert isinstance(lib.mb_last_error(), bytes)
 
 
@@ -171,15 +171,33 @@ def test_eval_harness_host_pieces():
     assert torch.equal(lab[:1000].sort().values, torch.arange(1000, dtype=torch.int32))
 
 
-def test_host_noise_draws_restore_the_thread_pool_and_keep_the_stream():
-    """draw_noise holds torch's intra-op pool at one thread while it draws (profiles/r03_parity.md section 4) and restores it; the CPU stream is the
-    one the reference consumes (one Gumbel draw of [B, n, m] per step from the default generator)."""
+def test_host_noise_draws_leave_the_thread_pool_alone_and_keep_the_stream():
+    """draw_noise draws the confidence noise in row blocks below ATen's intra-op grain (profiles/r03_parity.md section 4: the pool of a many-core host
+    starves the HIP runtime's threads): no thread setting of the process is touched -- not on the calling thread, not transiently, not for threads
+    created meanwhile -- and the CPU stream is the one the reference consumes (one Gumbel draw of [B, n, m] per step from the default generator), at a
+    batch that takes several blocks per step too."""
+    import threading
     import torch
-    from maskbit_amd.sampling import _FewCpuThreads, draw_noise
+    from maskbit_amd import sampling as S
+    from maskbit_amd.sampling import draw_noise
+    assert not hasattr(S, "_FewCpuThreads")
     before = torch.get_num_threads()
-    with _FewCpuThreads():
-        assert torch.get_num_threads() == 1
-    assert torch.get_num_threads() == before
+    seen, stop = [], threading.Event()
+
+    def watch():                                                    # another host thread, created and polling while the draws run
+        while not stop.is_set():
+            seen.append(torch.get_num_threads())
+    torch.manual_seed(5)
+    w = threading.Thread(target=watch)
+    w.start()
+    _, big = draw_noise(70, 256, 2, 64, 3, 4.5, torch.device("cpu"))          # 70 samples: three row blocks per step
+    stop.set(); w.join()
+    assert torch.get_num_threads() == before and seen and set(seen) == {before}
+    torch.manual_seed(5)
+    for i in range(3):
+        torch.empty(70 * 512, 64).exponential_(1)
+    g = torch.distributions.Gumbel(0.0, 1.0)
+    assert torch.equal(big, torch.stack([g.sample((70, 256, 2)) * 4.5 * (1 - (i + 1) / 3) for i in range(3)]))
     torch.manual_seed(11)
     _, conf = draw_noise(2, 256, 2, 64, 3, 4.5, torch.device("cpu"))
     assert torch.get_num_threads() == before

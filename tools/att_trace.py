@@ -45,15 +45,14 @@ def run():
     lib = _lib.load()
     lib.mb_debug_att_trace.restype = C.c_int; lib.mb_debug_att_trace.argtypes = [C.c_void_p]
     lib.mb_debug_attention_pair.restype = C.c_int
-    lib.mb_debug_attention_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.mb_debug_attention_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     dev = torch.device("cuda")
     torch.manual_seed(0)
     P, N, d, heads = (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 257, 1024, 16
     qkv = (torch.randn(2 * P * N, 3 * d, device=dev) * 0.5).half()
     out = torch.empty(2 * P * N, d, device=dev, dtype=torch.float16)
-    aux = torch.empty(P * N, d, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    fn = lambda: lib.mb_debug_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), P, N, d, heads, st)
+    fn = lambda: lib.mb_debug_attention_pair(qkv.data_ptr(), out.data_ptr(), P, N, d, heads, st)
     plib = C.CDLL(os.path.join(ROOT, "maskbit_amd", "libmaskbit_hip.so"))           # the product library, for the uninstrumented time
     plib.mb_attention_pair.restype = C.c_int
     plib.mb_attention_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -84,8 +83,8 @@ def run():
     for path in sorted(glob.glob(os.path.join(AB, "libatt_var_*.so"))):
         vlib = C.CDLL(path)
         vlib.mb_debug_attention_pair.restype = C.c_int
-        vlib.mb_debug_attention_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        vfn = lambda: vlib.mb_debug_attention_pair(qkv.data_ptr(), out.data_ptr(), aux.data_ptr(), P, N, d, heads, st)
+        vlib.mb_debug_attention_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        vfn = lambda: vlib.mb_debug_attention_pair(qkv.data_ptr(), out.data_ptr(), P, N, d, heads, st)
         if ref is None:
             pfn(); torch.cuda.synchronize(); ref = out.clone()
         out.zero_()

@@ -13,10 +13,10 @@ def main():
     for B in sizes:
         tok = torch.randint(0, 64, (B, 256, 2), device="cuda")
         y = torch.randint(0, 1000, (B,), device="cuda")
-        for _ in range(3): gen.forward_cfg(tok, y, 3.0)
+        for _ in range(3): gen.forward_cfg(tok, y)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 12
-        for _ in range(n): gen.forward_cfg(tok, y, 3.0)
+        for _ in range(n): gen.forward_cfg(tok, y)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n * 1e3
         print(f"B = {B:3d} pairs: {dt:8.3f} ms per guided forward = {dt / B * 1e3:7.1f} us per pair", flush=True)

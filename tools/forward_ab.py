@@ -19,14 +19,14 @@ def main():
     y = torch.randint(0, 1000, (B,), device="cuda")
     for v in vals:
         os.environ[var] = v
-        for _ in range(3): gen.forward_cfg(tok, y, 3.0)
+        for _ in range(3): gen.forward_cfg(tok, y)
     torch.cuda.synchronize()
     acc = {v: [] for v in vals}
     for r in range(rounds):
         for v in (vals if r % 2 == 0 else vals[::-1]):
             os.environ[var] = v
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(nfw): gen.forward_cfg(tok, y, 3.0)
+            for _ in range(nfw): gen.forward_cfg(tok, y)
             torch.cuda.synchronize()
             acc[v].append((time.perf_counter() - t0) / nfw * 1e3)
     for v in vals:
