@@ -138,7 +138,43 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # [cond | uncond]): use_prenorm=True (bert.py:49-59,106-123) and the 512 x 512 models' 1024 + 1 tokens (scripts/eval_maskbit.py:125,139-144)
     "sample_full12_64_prenorm": (12, 192, 12.0, 4, FULL64, False, 4328, 4, "gaussian", dict(prenorm=True)),
     "sample_full12_64_seq1024": (12, 193, 12.0, 2, FULL64, False, 4329, 6, "gaussian", dict(seq=1024)),
+    # round 6: the demo's call site (demo_utils.py:139-157 with configs/demo/demo.yaml: the 14-bit generator, guidance ON with
+    # guidance_annealing="none" -- the full scale from step 0 on, where every other recorded run anneals it in from 0 --, scale_pow=1.0, arccos schedule)
+    "sample_full14_demo": (14, 196, 12.0, 4, None, False, 4337, 5),
 }
+# sampler arguments of demo_utils.sample (demo_utils.py:139-157); guidance scale / temperature / steps are the notebook's arguments: sample()'s own defaults, 64 steps
+DEMO64 = dict(num_steps=64, guidance_scale=3.0, guidance_annealing="none", scale_pow=1.0, randomize_temperature=4.5, mask_schedule_strategy="arccos")
+RUNS["sample_full14_demo"] = RUNS["sample_full14_demo"][:4] + (DEMO64,) + RUNS["sample_full14_demo"][5:]
+# tiny end-to-end sample() fixtures (per-step tokens + image): the three sampler settings of round 1 and (round 6) the demo's: guidance on, annealing "none"
+TINY_RUNS = {
+    "sample_tiny_cfg": dict(num_steps=8, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0,
+                            randomize_temperature=8.2, mask_schedule_strategy="arccos"),
+    "sample_tiny_nocfg": dict(num_steps=6, guidance_scale=0.0, guidance_annealing="none", scale_pow=4.0,
+                              randomize_temperature=4.5, mask_schedule_strategy="linear"),
+    "sample_tiny_linear_anneal": dict(num_steps=5, guidance_scale=3.0, guidance_annealing="linear", scale_pow=1.0,
+                                      randomize_temperature=2.0, mask_schedule_strategy="cosine",
+                                      use_sampling_annealing=True),
+    "sample_tiny_none_cfg": dict(num_steps=6, guidance_scale=3.0, guidance_annealing="none", scale_pow=1.0,
+                                 randomize_temperature=4.5, mask_schedule_strategy="arccos"),
+}
+
+
+def tiny_runs(LFQBert, ConvVQModel, ref_sample, names):
+    """The reference's sample() on the tiny generator / tokenizer of gen_tiny.npz / tok_tiny.npz (same seeds), one fixture per sampler setting."""
+    gen = build_ref_gen(LFQBert, TINY_GEN, O.make_generator_weights(TINY_GEN, seed=11, head_gain=40.0))
+    tok = build_ref_tok(ConvVQModel, TINY_TOK, O.make_tokenizer_weights(TINY_TOK, seed=21, with_encoder=True))
+    for name in names:
+        kw = TINY_RUNS[name]
+        B = 3
+        y = torch.tensor([1, 4, 8])
+        torch.manual_seed(1234)
+        image, steps = ref_sample(gen, tok, num_samples=B, labels=y.clone(), softmax_temperature=1.0, mask_token=64,
+                                  patch_size=16, codebook_size=4096, codebook_splits=2, **kw)
+        u8 = (torch.clamp(image, 0.0, 1.0) * 255.0).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), labels=y.numpy(), seed=1234,
+                            steps=torch.stack(steps).numpy(), image=image.numpy(), image_u8=u8.numpy(),
+                            kw_keys=np.array(list(kw.keys())), kw_vals=np.array([str(v) for v in kw.values()]))
+        print(name, "final mask tokens left:", int((steps[-1] == 64).sum()))
 
 
 def full_run(LFQBert, ConvVQModel, ref_sample, name: str, seed: int = 1234):
@@ -199,7 +235,9 @@ def main():
     torch.set_num_threads(8)
     LFQBert, ConvVQModel, ref_sample, ref_ratio, ref_combine, ref_split = _import_reference()
     picked = [n for n in RUNS if n in sys.argv[1:]] + (["sample_full12_64"] if "full64" in sys.argv[1:] else [])
-    if picked:                                          # only the (minutes-long) full-size free-running runs named on the command line
+    picked_tiny = [n for n in TINY_RUNS if n in sys.argv[1:]]
+    if picked or picked_tiny:                           # only the runs named on the command line (the full-size free-running ones take minutes)
+        tiny_runs(LFQBert, ConvVQModel, ref_sample, picked_tiny)
         for n in picked:
             full_run(LFQBert, ConvVQModel, ref_sample, n)
         return
@@ -231,25 +269,7 @@ def main():
     print("tok_tiny image", tuple(img.shape), float(img.mean()), float(img.std()))
 
     # ---- 3. tiny end-to-end sample(): per-step tokens + image, with CFG cosine and without --
-    for name, kw in {
-        "sample_tiny_cfg": dict(num_steps=8, guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0,
-                                randomize_temperature=8.2, mask_schedule_strategy="arccos"),
-        "sample_tiny_nocfg": dict(num_steps=6, guidance_scale=0.0, guidance_annealing="none", scale_pow=4.0,
-                                  randomize_temperature=4.5, mask_schedule_strategy="linear"),
-        "sample_tiny_linear_anneal": dict(num_steps=5, guidance_scale=3.0, guidance_annealing="linear", scale_pow=1.0,
-                                          randomize_temperature=2.0, mask_schedule_strategy="cosine",
-                                          use_sampling_annealing=True),
-    }.items():
-        B = 3
-        y = torch.tensor([1, 4, 8])
-        torch.manual_seed(1234)
-        image, steps = ref_sample(gen, tok, num_samples=B, labels=y.clone(), softmax_temperature=1.0, mask_token=64,
-                                  patch_size=16, codebook_size=4096, codebook_splits=2, **kw)
-        u8 = (torch.clamp(image, 0.0, 1.0) * 255.0).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8)
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), labels=y.numpy(), seed=1234,
-                            steps=torch.stack(steps).numpy(), image=image.numpy(), image_u8=u8.numpy(),
-                            kw_keys=np.array(list(kw.keys())), kw_vals=np.array([str(v) for v in kw.values()]))
-        print(name, "final mask tokens left:", int((steps[-1] == 64).sum()))
+    tiny_runs(LFQBert, ConvVQModel, ref_sample, list(TINY_RUNS))
 
     # ---- 4. schedule tables + helpers ------------------------------------------------------
     sched = {}

@@ -196,6 +196,21 @@ def test_generator_variants_full_width_vs_reference_runs(name, expect, bound):
     assert bad / tot <= bound
 
 
+@pytest.mark.timeout(900)
+def test_demo_call_site_14bit_vs_reference_run():
+    """The demo's call of sample() (demo_utils.py:139-157 with configs/demo/demo.yaml): the 14-bit generator, guidance ON with guidance_annealing="none"
+    and scale_pow=1.0 -- the full scale from step 0 on, while every position is still masked, where every other recorded run anneals it in from 0 (so
+    no step of this run takes the conditional-only shortcut) --, arccos schedule, 64 steps; a full-size run of the REAL reference (oracle/make_golden.py
+    RUNS sample_full14_demo, batch 4: 84 284 sampled positions), teacher-forced in the product default."""
+    from maskbit_amd import parity_replay as R
+    g = R.load_run(R.RUN_DEMO14)
+    assert g["kw"]["guidance_annealing"] == "none" and float(g["kw"]["scale_pow"]) == 1.0 and float(g["kw"]["guidance_scale"]) == 3.0 and g["bits"] == 14
+    assert all(s == 3.0 for s in R.plan_of(g)[0])
+    r = _vs_reference_run(R.RUN_DEMO14, [("product default", -1), ("single fp16", 0)])
+    bad, tot = r["product default"]
+    assert tot == 84284 and bad / tot <= 1e-3 and bad < r["single fp16"][0]
+
+
 def _full_length_run(bits, num_steps, B, kw, seed):
     """A complete free-running mb_sample of a BASELINE configuration at full size and full length, checked through the size-independent
     properties of the loop (sampling.py:81-131): the run is deterministic; it equals, bit for bit, the step-by-step composition

@@ -146,6 +146,8 @@ def _oracle_steps(num_steps, **kw):
     dict(guidance_scale=7.1, guidance_annealing="cosine", scale_pow=3.0, randomize_temperature=8.2, mask_schedule_strategy="arccos"),
     dict(guidance_scale=0.0, randomize_temperature=4.5, mask_schedule_strategy="linear"),
     dict(guidance_scale=3.0, guidance_annealing="linear", randomize_temperature=2.0, mask_schedule_strategy="cosine", use_sampling_annealing=True),
+    # the demo's call site (demo_utils.py:139-157): guidance on with annealing "none" -- the full scale at every step, step 0 included
+    dict(guidance_scale=3.0, guidance_annealing="none", scale_pow=1.0, randomize_temperature=4.5, mask_schedule_strategy="arccos"),
 ])
 def test_sample_step_bit_exact_vs_oracle(kw):
     from maskbit_amd import _lib

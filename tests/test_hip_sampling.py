@@ -53,6 +53,50 @@ def test_loop_replays_reference_run_tiny():
     assert float((img.cpu() - ref_img).abs().max()) < 0.02
 
 
+def test_demo_call_site_replays_reference_run_tiny():
+    """The demo's call of sample() (demo_utils.py:139-157: guidance ON with guidance_annealing="none", scale_pow=1.0, arccos schedule) on the tiny
+    fixture recorded from the real reference (oracle/make_golden.py sample_tiny_none_cfg): the full guidance scale acts from step 0 on, so every
+    step of the run is a guided one (no zero-scale step takes the conditional-only shortcut).  Free-running with the reference's noise, as above,
+    plus the teacher-forced count over the run's sampled positions."""
+    from maskbit_amd import _lib
+    from maskbit_amd.sampling import build_plan, run_loop
+    z = load_golden("sample_tiny_none_cfg.npz")
+    kw = dict(zip([str(k) for k in z["kw_keys"]], [str(v) for v in z["kw_vals"]]))
+    assert kw["guidance_annealing"] == "none" and float(kw["guidance_scale"]) == 3.0 and float(kw["scale_pow"]) == 1.0
+    N = int(kw["num_steps"])
+    _, _, gm, tm = tiny_models()
+    q, c = cpu_noise(int(z["seed"]), 3, N, float(kw["randomize_temperature"]))
+    plan = build_plan(N, 512, 3.0, "none", 1.0, 1.0, False, kw["mask_schedule_strategy"])
+    assert plan[0] == [3.0] * N
+    y = torch.from_numpy(z["labels"])
+    img, u8, steps, codes = run_loop(gm, tm, y, plan, q.to(DEV), c.to(DEV), want_u8=True)
+    ref_steps = torch.from_numpy(z["steps"])
+    assert token_mismatch(steps[0].cpu(), ref_steps[0]) < 5e-3 and token_mismatch(steps.cpu(), ref_steps) < 2e-2
+    # teacher-forced: every step from the reference's own masked-token state.  The tiny fixtures hold the per-step predictions only; the oracle's
+    # recorded run (same seed, same draw order: bit-exact with the fixture, asserted here and in tests/test_oracle_golden.py) supplies state and noise
+    lib = _lib.load()
+    gsd = golden_weights(load_golden("gen_tiny.npz"))
+    rec = []
+    torch.manual_seed(int(z["seed"]))
+    O.sample_loop(lambda tk, yy, dd: O.lfq_bert_forward(gsd, TINY_GEN, tk, yy, dd), 3, y, num_steps=N, guidance_scale=3.0, guidance_annealing="none",
+                  scale_pow=1.0, randomize_temperature=float(kw["randomize_temperature"]), mask_schedule_strategy=kw["mask_schedule_strategy"],
+                  mask_token=64, codebook_splits=2, record=rec)
+    bad = tot = 0
+    for i, r in enumerate(rec):
+        assert torch.equal(r.pred, ref_steps[i]) and r.scale == 3.0
+        d_in = r.tokens_in.to(DEV).contiguous()
+        lg = gm.forward_cfg(d_in, y.to(DEV))
+        lc, lu = lg[:3].contiguous(), lg[3:].contiguous()
+        tout, pred = torch.empty_like(d_in), torch.empty_like(d_in)
+        _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr(), plan[0][i], plan[1][i], r.exp_noise.to(DEV).contiguous().data_ptr(),
+                                      r.conf_noise.to(DEV).contiguous().data_ptr(), plan[2][i], d_in.data_ptr(), tout.data_ptr(), pred.data_ptr(),
+                                      3, 256, 2, 64, torch.cuda.current_stream().cuda_stream))
+        msk = r.tokens_in == 64
+        bad += int((pred.cpu() != ref_steps[i])[msk].sum()); tot += int(msk.sum())
+    print(f"demo call site, tiny: teacher-forced {bad}/{tot}")
+    assert bad / tot < 1e-2                                           # (head gain 40: very flip-prone; the full-size demo run is in test_hip_configs.py)
+
+
 @pytest.mark.timeout(900)
 def test_teacher_forced_token_parity_full_size():
     """The parity figure of merit (north star: bit-token mismatch <= 1e-3 vs the fp32 reference).

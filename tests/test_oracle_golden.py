@@ -66,7 +66,7 @@ def test_decode_and_encode_tiny():
     assert (rec - torch.from_numpy(z["recon"])).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("name", ["sample_tiny_cfg", "sample_tiny_nocfg", "sample_tiny_linear_anneal"])
+@pytest.mark.parametrize("name", ["sample_tiny_cfg", "sample_tiny_nocfg", "sample_tiny_linear_anneal", "sample_tiny_none_cfg"])   # (the last: the demo's call site, demo_utils.py:139-157)
 def test_sample_loop_bit_exact(name):
     """Same seed, same RNG draw order -> the per-step tokens of the reference, bit for bit."""
     z = load_golden(name + ".npz")
