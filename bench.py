@@ -104,6 +104,53 @@ def cpu_baseline():
             "host_cpus": os.cpu_count()}
 
 
+def measured_traffic(dom: str, mode: str, avg_launch_us=None):
+    """HBM traffic of the dominant trunk GEMM from the hardware counters, measured by THIS run: after the timed region, rocprofv3 --pmc sub-passes
+    (counters need their own passes: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots") over
+    tools/pair_one.py, which issues that GEMM exactly as the guided forward of the timed region does (64 sequence pairs, pair tiles, the timed mode's
+    mini-tile operand sets), 3 launches per pass.  -> {bytes_per_launch, algorithmic_bytes, ratio, mfma_busy, ...} or (None, reason).
+    bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) KiB: the gfx950 correction of the guide's HBM section (FETCH_SIZE reports half of wide coalesced
+    streams; Infinity-Cache hits are counted too, so this is traffic INTO the L2s, an upper bound of HBM traffic).  mfma_busy =
+    SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): the share of the launch during which a SIMD's matrix pipe is busy."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary as P
+    shape = dom.replace("gemm_", "")
+    mini = {"strict": 1, "diff": 0, "fp16": 0}.get(mode, 0)
+    env = dict(os.environ, PAIR_ONE_MINI=str(mini), TMPDIR="/tmp")
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="mb_pmc_", dir="/tmp")
+    try:
+        for grp in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+            d = os.path.join(tmp, grp.split()[0])
+            cmd = [exe, "--pmc", *grp.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pair_one.py"), shape, "3"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            c = P.gemm_counters(d)
+            if r.returncode != 0 or grp.split()[0] not in c:
+                return None, f"rocprofv3 --pmc {grp}: exit {r.returncode}, counters {sorted(c)}: {r.stdout.decode(errors='replace')[-300:]}"
+            got.update(c)
+    except Exception as e:                               # noqa: BLE001  (context only: never costs the headline line)
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    by = P.hbm_bytes(got["FETCH_SIZE"][0], got["WRITE_SIZE"][0])
+    alg = P.algorithmic_bytes(shape, mini)
+    out = {"bytes_per_launch": by, "algorithmic_bytes": alg, "ratio": by / alg,
+           "mfma_busy": (got["SQ_VALU_MFMA_BUSY_CYCLES"][0] / 1024.0) / (got["GRBM_GUI_ACTIVE"][0] / 8.0) if "GRBM_GUI_ACTIVE" in got and got["GRBM_GUI_ACTIVE"][0] else None,
+           "launches_per_pass": got["FETCH_SIZE"][1], "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
+           "how": f"rocprofv3 --pmc sub-passes of this bench run over tools/pair_one.py {shape} (PAIR_ONE_MINI={mini}); (2 FETCH_SIZE + WRITE_SIZE) KiB, "
+                  "the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md; Infinity-Cache hits included"}
+    if avg_launch_us:
+        out["implied_gb_per_s"] = by / (avg_launch_us * 1e-6) / 1e9
+    return out, None
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run on
     127.0.0.1) and pass their output through; rank 0 prints the JSON line."""
@@ -252,6 +299,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra (untimed-region) measurements: parity replay and the other precision mode")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc sub-passes that measure roofline.traffic (N = 1 only; about a minute)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -395,10 +443,15 @@ def main():
             achieved = gemm_flops[dom] / (ms / calls * 1e-3) / 1e12
             fam_flops = sum(gemm_flops[k] * prof[k][0] for k in gemm_flops if k in prof)
             fam_ms = sum(prof[k][1] for k in gemm_flops if k in prof)
-            # `traffic` (HBM bytes per launch from the PMC counters) cannot be measured inside a timing run -- counters need their own rocprofv3 --pmc
-            # passes -- so it is null here; the last committed counter pass of the same kernel in the same mode is quoted beside it as a REFERENCE.
+            # `traffic` (HBM bytes per launch from the PMC counters) cannot be collected inside a timing run -- counters need their own rocprofv3 --pmc
+            # passes -- so it is measured AFTER the timed region by sub-passes of this same run (measured_traffic; N = 1, rocprofv3 on PATH); the last
+            # committed counter pass of the same kernel in the same mode is quoted beside it as a REFERENCE either way.
+            traffic, traffic_why = (None, "skipped (--no-traffic, N > 1 or a non-default batch)")
+            if world == 1 and not args.no_traffic and B == B_PER_GPU:
+                torch.cuda.synchronize()
+                traffic, traffic_why = measured_traffic(dom, args.mode, ms / calls * 1e3)
             traffic_ref = None
-            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+            for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if B == B_PER_GPU and pmc.get("_mode", "").split(" ")[0] == args.mode:
@@ -410,7 +463,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": f"gemm_ht_kernel ({dom}: M={M}, N={4096 if dom == 'gemm_ffn_up' else (3072 if dom == 'gemm_qkv' else 1024)}, "
                                                    f"K={4096 if dom == 'gemm_ffn_down' else 1024})",
                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                        "traffic": None, "traffic_reference": traffic_ref,
+                        "traffic": traffic, "traffic_unmeasured_because": traffic_why, "traffic_reference": traffic_ref,
                         "flops_per_launch": gemm_flops[dom], "avg_launch_us": ms / calls * 1e3,
                         "gemm_family_tflops": fam_flops / (fam_ms * 1e-3) / 1e12,
                         # executed sequence-forwards per image: two per guided step, one where the annealed scale is exactly 0 (the loop skips the

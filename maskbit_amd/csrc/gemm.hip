@@ -187,65 +187,63 @@ void cast_f32_to_h16(hipStream_t s, const float* src, h16* dst, size_t n) {
 }
 
 
-// ---- e2m1 copy of a weight for the fp4 correction pass: one workgroup per weight row.  The row's power-of-two scale 2^r is the best of three
-// candidates around 2.2 / rms (measured optimum for Gaussian rows: quantisation error ~1.5 % of the row's energy) by summed squared error.
+// ---- e2m1 copies of a weight for the mini-tile passes (gemm_ht.hip): one workgroup per weight row, one power-of-two scale per (row, 128 columns) =
+// per (row, mini-tile): thread t holds columns [4 t, 4 t + 4) of a 1024-column sweep, so a 128-column block is the 32 lanes of a half wave.
+__device__ __forceinline__ float half_wave_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// VALUES: e2m1(fp16(W) * 2^r), r = the best of three candidates around 2.2 / rms of the block (measured optimum for Gaussian blocks: quantisation error
+// ~1.5 % of the block's energy) by summed squared error -- the largest elements may saturate when that serves the rest.
 __global__ __launch_bounds__(256) void w4_kernel(const float* __restrict__ W, uint8_t* __restrict__ out, int N, int K, uint8_t* __restrict__ scale_out) {
-  __shared__ float red[4][4];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = blockIdx.x, tid = threadIdx.x;
   const float* w = W + (size_t)n * K;
-  auto block_sum = [&](float v, int slot) {
-    v = wave_sum(v);
-    if (lane == 0) red[slot][wv] = v;
-    __syncthreads();
-    const float t = (red[slot][0] + red[slot][1]) + (red[slot][2] + red[slot][3]);
-    __syncthreads();
-    return t;
-  };
-  float ss = 0.f;
-  for (int k = tid; k < K; k += 256) { const float v = (float)(h16)w[k]; ss += v * v; }
-  const float rms = sqrtf(block_sum(ss, 0) / (float)K);
-  int r0 = 0;
-  if (rms > 0.f && rms < 3.0e38f) r0 = (int)rintf(log2f(2.2f / rms));
-  r0 = max(-100, min(100, r0));
-  float err[3] = {0.f, 0.f, 0.f};
   const float F4V[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
-  for (int k = tid; k < K; k += 256) {
-    const float v = (float)(h16)w[k];                                   // the fp16 engine multiplies by fp16(W): quantise THAT value
+  for (int k = tid * 4; k < K; k += 1024) {
+    const float4 v4 = *(const float4*)(w + k);
+    const float v[4] = {(float)(h16)v4.x, (float)(h16)v4.y, (float)(h16)v4.z, (float)(h16)v4.w};   // the fp16 engine multiplies by fp16(W): quantise THAT value
+    const float rms = sqrtf(half_wave_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) / 128.0f);
+    int r0 = 0;
+    if (rms > 0.f && rms < 3.0e38f) r0 = (int)rintf(log2f(2.2f / rms));
+    r0 = max(-100, min(100, r0));
+    float err[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float m = ldexpf(1.0f, r0 - 1 + c);
-      const float q = F4V[fp4_code(v * m) & 7];
-      const float d = fabsf(v) * m - q;
-      err[c] += d * d / (m * m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float q = F4V[fp4_code(v[e] * m) & 7];
+        const float d = fabsf(v[e]) * m - q;
+        err[c] += d * d / (m * m);
+      }
+      err[c] = half_wave_sum(err[c]);
     }
-  }
-  float e0 = block_sum(err[0], 1), e1 = block_sum(err[1], 2), e2 = block_sum(err[2], 3);
-  const int best = (e1 <= e0 && e1 <= e2) ? 1 : (e0 <= e2 ? 0 : 2);
-  const int r = r0 - 1 + best;
-  const float m = ldexpf(1.0f, r);
-  if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)max(0, min(254, 127 - r));
-  for (int k = tid * 4; k < K; k += 1024) {
-    const float4 v = *(const float4*)(w + k);
-    *(uint16_t*)(out + w4_packed_offset(n, k, K)) = (uint16_t)fp4_pack4((float)(h16)v.x, (float)(h16)v.y, (float)(h16)v.z, (float)(h16)v.w, m);
+    const int best = (err[1] <= err[0] && err[1] <= err[2]) ? 1 : (err[0] <= err[2] ? 0 : 2);
+    const int r = r0 - 1 + best;
+    if ((tid & 31) == 0) scale_out[w4_scale_index(n, k >> 7, K)] = (uint8_t)max(0, min(254, 127 - r));
+    *(uint16_t*)(out + w4_packed_offset(n, k, K)) = (uint16_t)fp4_pack4(v[0], v[1], v[2], v[3], ldexpf(1.0f, r));
   }
 }
 
-// e2m1 copy of a weight's fp16 rounding error (one workgroup per row), for the weight-correction pass of the differential CFG forward
+// fp16 ROUNDING ERRORS: e2m1((W - fp16(W)) * 2^r), r from the block's largest |error| without saturation (a clipped error is a systematic one on exactly
+// the products that dominate).  Per (row, 128 columns) since round 6: an error is +-ulp(W) / 2, so on heavy-tailed weights one large weight per row used to
+// set the scale of all its columns (9 % of the error energy left against 3 % on Gaussian rows, profiles/r05_parity.md; emulated gain of the block scales
+// on the sampled logits' top-2 gap: -10 % by themselves, -30 % next to the activation-lo sets, tests/diag/error_budget.py EB_STUDY=r6).
 __global__ __launch_bounds__(256) void w4lo_kernel(const float* __restrict__ W, uint8_t* __restrict__ out, int N, int K, uint8_t* __restrict__ scale_out) {
-  __shared__ float red[4];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = blockIdx.x, tid = threadIdx.x;
   const float* w = W + (size_t)n * K;
-  float mx = 0.f;
-  for (int k = tid; k < K; k += 256) mx = fmaxf(mx, fabsf(w[k] - (float)(h16)w[k]));
-  mx = wave_max(mx);
-  if (lane == 0) red[wv] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float mul = fp4_scale_mul_nosat(mx);
-  if (tid == 0) scale_out[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)] = (uint8_t)fp4_scale_byte_nosat(mx);
   for (int k = tid * 4; k < K; k += 1024) {
     const float4 v = *(const float4*)(w + k);
-    *(uint16_t*)(out + w4_packed_offset(n, k, K)) = (uint16_t)fp4_pack4(v.x - (float)(h16)v.x, v.y - (float)(h16)v.y, v.z - (float)(h16)v.z, v.w - (float)(h16)v.w, mul);
+    const float e0 = v.x - (float)(h16)v.x, e1 = v.y - (float)(h16)v.y, e2 = v.z - (float)(h16)v.z, e3 = v.w - (float)(h16)v.w;
+    const float mx = half_wave_max(fmaxf(fmaxf(fabsf(e0), fabsf(e1)), fmaxf(fabsf(e2), fabsf(e3))));
+    if ((tid & 31) == 0) scale_out[w4_scale_index(n, k >> 7, K)] = (uint8_t)fp4_scale_byte_nosat(mx);
+    *(uint16_t*)(out + w4_packed_offset(n, k, K)) = (uint16_t)fp4_pack4(e0, e1, e2, e3, fp4_scale_mul_nosat(mx));
   }
 }
 

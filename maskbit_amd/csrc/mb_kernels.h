@@ -58,8 +58,9 @@ struct GemmArgs {
   //   pair tiles : lo[0] (, lo[1]) on the CONDITIONAL rows: K / 128 mini-tiles per set (one per two fp16 K-tiles with one set, one per K-tile with two);
   //   plain tiles: lo[0] on both 128-row halves of the 256-token sequence tile (nlo = 1): 2 K / 128 mini-tiles, one per fp16 K-tile.
   // Operands: A4 = e2m1 token operand, two values per byte, row stride 2 K bytes (first K / 2 used); W4 = e2m1 weight operand, mini-tile-packed
-  // (w4_packed_offset; N K / 2 bytes); w_scale = the weights' E8M0 bytes in the kernel's lane order (entry ((n >> 6) * 16 + (n & 15)) * 4 +
-  // ((n >> 4) & 3)); a_scale = the token operand's E8M0 bytes per (row, 64 K-elements) in LANE ORDER (fp4_scale_index: one dword per lane holds the
+  // (w4_packed_offset; N K / 2 bytes); w_scale = the weights' E8M0 bytes, ONE PER (weight row, 128 K-elements) = per (row, mini-tile), in the kernel's
+  // lane order (w4_scale_index: a lane's dword of mini-tile j holds the bytes of its four n-tiles; N K / 128 bytes -- round 6; rounds 2-5 had one byte
+  // per weight row: on heavy-tailed weights a row's largest rounding error then took the resolution of all its other columns); a_scale = the token operand's E8M0 bytes per (row, 64 K-elements) in LANE ORDER (fp4_scale_index: one dword per lane holds the
   // scales of its four m-tiles).  Class-token rows take no part in these passes.
   struct LoSet { const uint8_t* A4; const uint8_t* a_scale; const uint8_t* W4; const uint8_t* w_scale; };
   LoSet lo[2] = {};
@@ -75,6 +76,12 @@ __host__ __device__ inline size_t w4_packed_offset(int n, int k, int K) {
   const int r = n & 15, c = (k & 127) >> 5;
   return ((size_t)(n >> 4) * (K >> 7) + (k >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 1) & 3)) << 4) + ((k & 31) >> 1);
 }
+// byte index of the E8M0 scale of (weight row n, K-elements [128 j, 128 j + 128)) in the lane-ordered weight scale arrays of the mini-tile passes
+// (GemmArgs.lo w_scale; K % 128 == 0, N % 64 == 0): dword ((n >> 6) * (K / 128) + j) * 16 + (n & 15) -- what lane (n & 15) of the wave column (n >> 6)
+// loads for mini-tile j --, byte (n >> 4) & 3 = its n-tile
+__host__ __device__ inline size_t w4_scale_index(int n, int j, int K) {
+  return (((size_t)(n >> 6) * (K >> 7) + j) * 16 + (n & 15)) * 4 + ((n >> 4) & 3);
+}
 // byte index of the scale of (token row r of sequence seq, 64-column block blk) in the lane-ordered scale arrays of the mini-tile passes
 // (groups = 64-token groups per sequence: 4 for the 256-token models, 16 for the 1024-token ones of 512 x 512 images)
 __host__ __device__ inline size_t fp4_scale_index(int blk, int nseq, int seq, int r, int groups = 4) {
@@ -85,10 +92,10 @@ bool gemm_ht_supported(GemmEpi epi, const GemmArgs& a);
 void gemm_ht(hipStream_t s, GemmEpi epi, const GemmArgs& a, int mt);
 void set_cu_count(int n);   // persistent grids are sized for n CUs (0 = the device's count): for launches on CU-masked streams
 
-// e2m1 copy of a weight for the mini-tile passes: e2m1(fp16(W[n]) * 2^r_n) in the mini-tile-packed layout (w4_packed_offset; N K / 2 bytes), r_n
-// per row chosen to minimise the row's quantisation error; scale_out in the kernel's lane order (GemmArgs.lo w_scale).  N % 16 == 0, K % 128 == 0.
+// e2m1 copy of a weight for the mini-tile passes: e2m1(fp16(W[n][k]) * 2^r) in the mini-tile-packed layout (w4_packed_offset; N K / 2 bytes), r per
+// (row, 128 columns) chosen to minimise the block's quantisation error; scale_out [N K / 128] in the kernel's lane order (w4_scale_index).  N % 64 == 0, K % 128 == 0.
 void w4_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);
-// the same layout for the weight's fp16 ROUNDING ERROR: e2m1((W[n] - fp16(W[n])) * 2^r_n), r_n from the row's largest |error| (fp4_scale_mul)
+// the same layout for the weight's fp16 ROUNDING ERROR: e2m1((W - fp16(W)) * 2^r), r from the (row, 128-column) block's largest |error| (no saturation)
 void w4lo_from_f32(hipStream_t s, const float* src, uint8_t* dst4, int N, int K, uint8_t* scale_out);
 
 // e2m1 copies written by the row-wise producers for the trunk GEMMs' mini-tile passes (GemmArgs.lo): the rows' VALUES (x4, with the
