@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define MB_ABI_VERSION 8
-enum { MB_PREC_FP16 = 0, MB_PREC_DIFF = 1, MB_PREC_WCORR = 2, MB_PREC_ALO = 3 };
+enum { MB_PREC_FP16 = 0, MB_PREC_DIFF = 1, MB_PREC_WCORR = 2, MB_PREC_ALO = 3, MB_PREC_ALO_ALL = 4 };
 
 typedef struct mb_gen mb_gen; /* generator engine  (modeling/bert.py LFQBert)            */
 typedef struct mb_dec mb_dec; /* tokenizer decoder (modeling/conv_vqgan.py ConvVQModel)  */
@@ -51,8 +51,11 @@ typedef struct {
    *   MB_PREC_WCORR 2  + MX-fp4 mini-tile correction of the fp16 rounding of all four trunk WEIGHTS (gemm_ht.hip XP = 6), guided and plain (5.5e-4).
    *   MB_PREC_ALO   3  + the same kind of pass for the rounding of the conditional LayerNorm outputs in FFN-up of the guided forward (what the
    *                    7-bit-per-group codebooks need: 4.9e-4 over four 14-bit / 256-step runs, every run <= 8.3e-4; without it one run is at 1.05e-3).
-   * Modes 1-3 need seq in {256, 1024}, hidden in {768, 1024}, mlp % 256 == 0 (2 / 3 also hidden / heads = 64); other shapes run mode 0 with hi + lo
-   * LayerNorm outputs.  The host's default is 2, or 3 from 7 bits per group on (LFQBert.resolved_precision). */
+   *   MB_PREC_ALO_ALL 4 + that pass on ALL FOUR trunk GEMMs of EVERY layer of the guided forward -- the lo halves of the LayerNorm outputs (QKV, FFN-up), of
+   *                    the attention outputs (out-proj) and of the FFN hiddens (FFN-down) -- and the zero-scale steps of a guided run through the
+   *                    guided forward as well: what heavy-tailed ("trained-like") weights with massive-activation channels need (round 6).
+   * Modes 1-4 need seq in {256, 1024}, hidden in {768, 1024}, mlp % 256 == 0 (2-4 also hidden / heads = 64); other shapes run mode 0 with hi + lo
+   * LayerNorm outputs.  The host's default is 2, 3 from 7 bits per group on, 4 for heavy-tailed checkpoints (LFQBert.resolved_precision). */
   int precision;
 } mb_gen_cfg;
 
@@ -83,7 +86,8 @@ typedef struct {
    * step_tokens pointers of a call hold the steps of ITS chunk (chunk-relative), the arrays above the whole run.  A chunk is accepted only as the
    * exact continuation of the run in progress on that handle (same B, num_steps, use_guidance; step_begin = the previous chunk's step_end): a
    * generator handle is NOT re-entrant while a chunked run is in progress -- two interleaved runs need two handles.
-   * Steps whose scale[i] is exactly 0 run the conditional forward alone (c + 0 (c - u) == c: the unconditional forward cannot change the result). */
+   * Steps whose scale[i] is exactly 0 run the conditional forward alone (c + 0 (c - u) == c: the unconditional forward cannot change the result; at
+   * precision 4 they run the guided forward, whose conditional half is the more precise one). */
   int step_begin, step_end;
 } mb_sample_plan;
 

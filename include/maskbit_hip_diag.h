@@ -29,17 +29,19 @@ int mb_gemm_act_split(int epi, const void* A_hi, const void* A_lo, const void* W
 /* "CFG pair" GEMM (mb_gen_cfg.precision >= 1): rows [0, pair_rows) of A / out are conditional, [pair_rows, 2 pair_rows) their unconditional twins whose
  * A rows hold the difference operand; out_c = f(A_c.W), out_u = f(A_c.W + A_delta.W) (GELU epilogue: the u rows receive gelu(u) - gelu(c)).
  * mb_gemm_mini: a sequence-aligned GEMM (rows % 257 == 0; pair != 0: a pair GEMM over `rows` conditional rows) with nlo MX-fp4 mini-tile passes:
- * lo = nlo x {A4, a_scale, W4, w_scale} device pointers (operand layouts: mb_kernels.h GemmArgs.lo; the token scales in lane order,
+ * lo = nlo x {A4, a_scale, W4, w_scale} device pointers (operand layouts: mb_kernels.h GemmArgs.lo; w_scale = N K / 128 bytes as mb_w4_from_f32 writes them; the token scales in lane order,
  * index (((blk * nseq + seq) * 4 + (r >> 6)) * 64 + (r & 15) * 4 + ((r >> 4) & 3) for token r of sequence seq).  out4 / out4_scale (GELU epilogue,
  * optional): e2m1 of the (conditional) outputs + their lane-ordered scales. */
 int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
                  void* out4_scale, int rows, int pair, int N, int K, int nlo, const void* const* lo, mb_stream stream);
 /* ... the pair form for sequences of seq_rows rows incl. the class token (0 = 257; 1 025 = the 512 x 512 models: eight 128-token pair tiles per sequence
- * pair, (seq_rows - 1) / 64 token groups in the lane-ordered scale arrays). */
+ * pair, (seq_rows - 1) / 64 token groups in the lane-ordered scale arrays).  out4l / out4l_scale (GELU epilogue, optional, with out4; precision 4): the same e2m1
+ * copy for the fp16 LO HALVES v - fp16(v) of the (conditional) outputs. */
 int mb_gemm_mini_seq(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
-                     void* out4_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream);
-/* e2m1 operands of the mini-tile passes: of the fp16 weight values (per-row scales minimising the row's quantisation error) and of the weight's fp16
- * rounding error W - fp16(W); row stride 2K bytes (first K / 2 used), scale bytes in the kernel's lane order; N % 64 == 0. */
+                     void* out4_scale, void* out4l, void* out4l_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream);
+/* e2m1 operands of the mini-tile passes: of the fp16 weight values (scales minimising the quantisation error) and of the weight's fp16 rounding error
+ * W - fp16(W); dst4 = N K / 2 bytes mini-tile-packed (mb_kernels.h w4_packed_offset), scale_out = N K / 128 bytes -- one E8M0 byte per (weight row, 128
+ * K-elements) -- in the kernel's lane order (w4_scale_index: byte ((((n >> 6) * (K / 128) + j) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)); N % 64 == 0, K % 128 == 0. */
 int mb_w4_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
 int mb_w4lo_from_f32(const float* W, int N, int K, void* dst4, void* scale_out, mb_stream stream);
 /* LayerNorm that also writes the e2m1 copies of its output rows: values (x4 / x4_scale) and / or fp16 lo halves (xl4 / xl4_scale); M % 257 == 0,
@@ -59,7 +61,8 @@ int mb_attention_pair(const void* qkv, void* out_h16, int pairs, int N, int d, i
  * values per byte, and out4_scale = one E8M0 byte per (row, head) in the lane order of the mini-tile passes (mb_kernels.h fp4_scale_index with (N - 1) / 64
  * token groups per sequence, `pairs` sequences): the token operand of the out-projection's weight-correction pass.  Head width 64, N = 257 or
  * (N - 1) % 64 == 0 beyond 288. */
-int mb_attention_pair_f4(const void* qkv, void* out_h16, void* out4, void* out4_scale, int pairs, int N, int d, int heads, mb_stream stream);
+/* out4l / out4l_scale (optional, both or neither; precision 4): the same for the fp16 lo halves o_c - fp16(o_c) of the conditional outputs. */
+int mb_attention_pair_f4(const void* qkv, void* out_h16, void* out4, void* out4_scale, void* out4l, void* out4l_scale, int pairs, int N, int d, int heads, mb_stream stream);
 /* Study knob of the weight-correction passes (precision >= 2): they run in trunk layers >= from_layer (default 0 = every layer; depth = none; guided
  * forward) and on the GEMMs of gemm_mask (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down; default 15; both forwards).  No subset keeps the default's
  * parity margin (profiles/r04_gemm_minitiles.md section 4): the product never calls this. */

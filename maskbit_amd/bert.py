@@ -25,8 +25,18 @@ from .base_model import BaseModel, ParamSpec
 #   PREC_DIFF  1  classifier-free guidance in differential form; plain forwards with the LayerNorm outputs as fp16 hi + lo pairs (~1.0e-3: AT the bound)
 #   PREC_WCORR 2  + MX-fp4 weight-correction mini-tiles on every trunk GEMM, guided and plain (5.5e-4 over three reference runs of configs[2]; 5.3e-4 on configs[1])
 #   PREC_ALO   3  + activation-lo mini-tiles for the LayerNorm outputs feeding FFN-up in the guided forward (4.9e-4 over four 14-bit / 256-step runs)
-# -1 = auto: 2, or 3 from 7 bits per group on, degraded to what the shape allows (resolved_precision()).
-PREC_AUTO, PREC_FP16, PREC_DIFF, PREC_WCORR, PREC_ALO = -1, 0, 1, 2, 3
+#   PREC_ALO_ALL 4 + activation-lo mini-tiles on all four trunk GEMMs of every layer (LayerNorm outputs, attention outputs, FFN hiddens): heavy-tailed checkpoints
+# -1 = auto: 2, or 3 from 7 bits per group on, or 4 when the checkpoint's statistics ask for it (weight_statistics()), degraded to what the shape allows
+# (resolved_precision()).
+PREC_AUTO, PREC_FP16, PREC_DIFF, PREC_WCORR, PREC_ALO, PREC_ALO_ALL = -1, 0, 1, 2, 3, 4
+# Load-time escalation rule of the auto mode (round 6).  What the default modes are sensitive to, and Gaussian-like weights do not show: (a) HEAVY-TAILED
+# Linear weights -- an fp16 rounding error is +-ulp(w) / 2, so a few large weights per row set the scale of the e2m1 weight-error operand for the rest
+# (residual 9 % of the error energy at kurtosis 10.9 against 3 % at 3); measured as the pooled kurtosis of the trunk's Linear weights standardised per
+# row; (b) MASSIVE-ACTIVATION channels -- LayerNorm outputs sqrt(gamma^2 + beta^2) many times the typical channel's: they take the resolution of their
+# 64-column block in every e2m1 token operand.  A Gaussian / trunc-normal init measures 2.9-3.0 and 1.0-1.1; the trained-like family of maskbit_amd/synth.py
+# 10.9 and ~16; the thresholds sit where a Student-t_8 weight distribution (kurtosis 4.5) or one channel at 6x the median would.
+ESCALATE_KURTOSIS = 4.5
+ESCALATE_CHANNEL_RATIO = 6.0
 DEFAULT_PRECISION = PREC_AUTO
 DEFAULT_WCORR_MASK = 15
 
@@ -100,6 +110,7 @@ class LFQBert(BaseModel):
         # ... and which GEMMs of a layer carry them: 1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down (15 = all, the default)
         self.wcorr_mask = int(os.environ.get("MASKBIT_AMD_WMASK", str(DEFAULT_WCORR_MASK)))
         self._engine_split = None
+        self._wstats = None               # (weight signature, statistics) of the last weight_statistics() call
         if not self.embed_tables:
             self._attach("bits_to_indices", (2 ** torch.arange(group_bits)).to(torch.int32), buffer=True)
         self._build(_generator_specs(hidden_dim, mlp_dim, depth, self.seq_len, self.bits, nclass,
@@ -113,11 +124,38 @@ class LFQBert(BaseModel):
     def _engine_create(self, capacity: int):
         cfg = _lib.GenCfg(self.bits, self.splits, self.hidden_dim, self.heads, self.depth, self.mlp_dim, self.seq_len, self.nclass,
                           int(self.use_prenorm), int(self.embed_tables), self.resolved_precision())
-        self._engine_split = int(self.precision)
+        self._engine_split = self.resolved_precision()
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
         self._engine_wfrom = None
         return h
+
+    @torch.no_grad()
+    def weight_statistics(self) -> dict:
+        """Statistics of the CHECKPOINT the auto precision mode escalates on (cached per weight signature): ``kurtosis`` = pooled fourth moment of the trunk's
+        Linear weights (in_proj, out_proj, net.0, net.2 of every layer) standardised per output row (a Gaussian's: 3); ``channel_ratio`` = the largest
+        LayerNorm output channel magnitude sqrt(gamma^2 + beta^2) over the median channel's, maximised over the trunk's LayerNorms."""
+        sig = self._weight_signature()
+        if self._wstats is not None and self._wstats[0] == sig:
+            return self._wstats[1]
+        sd = self.state_dict(keep_vars=True)
+        m4 = n = 0.0
+        ratio = 1.0
+        for k, t in sd.items():
+            if not (t.is_floating_point() and k.startswith("transformer.layers.")):
+                continue
+            w = t.detach().float()
+            if w.dim() == 2:
+                z = w - w.mean(1, keepdim=True)
+                z = z / z.pow(2).mean(1, keepdim=True).clamp_min(1e-30).sqrt()
+                m4 += float(z.pow(4).sum()); n += z.numel()
+            elif k.endswith("norm.weight"):
+                mag = (w.pow(2) + sd[k[:-6] + "bias"].detach().float().pow(2)).sqrt()
+                ratio = max(ratio, float(mag.max() / mag.median().clamp_min(1e-30)))
+        stats = {"kurtosis": m4 / max(n, 1.0), "channel_ratio": ratio}
+        stats["heavy_tailed"] = stats["kurtosis"] > ESCALATE_KURTOSIS or stats["channel_ratio"] > ESCALATE_CHANNEL_RATIO
+        self._wstats = (sig, stats)
+        return stats
 
     def resolved_precision(self) -> int:
         """The precision mode handed to the engine.  The default (-1) means "meet the <= 1e-3 token mismatch with margin": the fp16 rounding of the trunk
@@ -126,12 +164,17 @@ class LFQBert(BaseModel):
         plain forwards with the LayerNorm outputs as fp16 hi + lo pairs as well.  Measured (profiles/r04_parity.md, r05): 12-bit / 64 steps 5.5e-4 over
         three reference runs, 10-bit / 16 steps / no guidance 5.3e-4, 14-bit / 256 steps 5.5e-4, the 1024 + 1-token models 5.6e-4.  Shapes the mini-tile
         kernels do not serve fall back to the differential form alone, shapes the pair tiles do not serve to independent streams (with hi + lo LayerNorm
-        outputs: the engine keeps those for every requested precision >= 1)."""
+        outputs: the engine keeps those for every requested precision >= 1).
+        Round 6: the default ESCALATES to PREC_ALO_ALL from the checkpoint's own statistics (weight_statistics(): heavy-tailed Linear weights or
+        massive-activation channels) -- on such weights the lower modes sit at or over the bound (two trained-like 12-bit runs 7.2e-4 / 1.06e-3 at
+        precision 2; profiles/r06_parity.md for precision 4)."""
         capable = pair_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.use_prenorm)
         mini = mini_capable(self.seq_len, self.hidden_dim, self.mlp_dim, self.heads)
         prec = int(self.precision)
         if prec < 0:
             prec = PREC_ALO if self.bits // self.splits >= 7 else PREC_WCORR
+            if capable and mini and self.weight_statistics()["heavy_tailed"]:
+                prec = PREC_ALO_ALL
         if prec >= PREC_WCORR and not (capable and mini):
             prec = PREC_DIFF
         return prec
@@ -145,8 +188,8 @@ class LFQBert(BaseModel):
 
     def engine(self, min_seqs: int):
         """Device engine able to hold ``min_seqs`` sequences (CFG needs 2 x batch)."""
-        if self._engine is not None and self._engine_split != int(self.precision):
-            self._drop_engine()                                    # precision mode changed: rebuild and repack
+        if self._engine is not None and self._engine_split != self.resolved_precision():
+            self._drop_engine()                                    # precision mode changed (the knob, or new weights under the auto rule): rebuild and repack
         have = self._engine_key[1] if self._engine_key else 0
         h = self._ensure_engine(max(min_seqs, have, 16))
         wf = (max(0, min(int(self.wcorr_from), self.depth)), int(self.wcorr_mask) & 15)

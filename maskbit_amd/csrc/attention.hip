@@ -61,6 +61,31 @@ __device__ __forceinline__ uint2 fp4_row8(const f32x4 (&o)[4], float inv, float 
   return make_uint2(sx[0], sx[1]);
 }
 
+// the same 8 bytes for the fp16 LO HALVES v - fp16(v) of the normalised outputs v = o * inv (precision 4: the out-proj GEMM's activation-lo pass); lo holds
+// them on entry
+__device__ __forceinline__ uint2 fp4_row8_vals(const f32x4 (&lo)[4], float mul) {
+  uint32_t p[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) p[nt] = fp4_pack4(lo[nt][0], lo[nt][1], lo[nt][2], lo[nt][3], mul);
+  const auto sw = __builtin_amdgcn_permlane16_swap((p[0] & 0xffffu) | (p[2] << 16), (p[1] & 0xffffu) | (p[3] << 16), false, false);
+  const uint32_t q0 = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);
+  const uint32_t q1 = __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u);
+  const auto sx = __builtin_amdgcn_permlane32_swap(q0, q1, false, false);
+  return make_uint2(sx[0], sx[1]);
+}
+// e2m1 copy of the lo halves of one (row, head) block held as o[nt][r] * inv: scale byte + 8 bytes of this lane (all 64 lanes take part)
+__device__ __forceinline__ uint2 fp4_lo_block(const f32x4 (&o)[4], float inv, uint32_t& sbyte) {
+  f32x4 lo[4];
+  float am = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float v = o[nt][r] * inv; lo[nt][r] = v - (float)to_h(v); am = fmaxf(am, fabsf(lo[nt][r])); }
+  am = rows_max(am);
+  sbyte = fp4_scale_byte_nosat(am);
+  return fp4_row8_vals(lo, fp4_scale_mul_nosat(am));
+}
+
 // AUX = 4 (CFG pair attention, mb_kernels.h attention_pair): one workgroup handles the conditional sequence of a (pair, head) and then its
 // unconditional twin, the conditional output tiles parked in registers in between, and stores fp16(o_u - o_c) for the twin: no extra traffic, one
 // launch, two workgroups per CU as before.  (Rounds 2-3 also had a two-launch form through fp32 rows in memory -- 119 against 88 us -- removed in
@@ -69,7 +94,8 @@ __device__ __forceinline__ uint2 fp4_row8(const f32x4 (&o)[4], float inv, float 
 template <int DH, int AUX = 0>
 __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __restrict__ qkv, h16* __restrict__ out,
                                                           int N, int d, int heads, float scale_log2e, int sq_off = 0,
-                                                          uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0) {
+                                                          uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0,
+                                                          uint8_t* __restrict__ out4l = nullptr, uint8_t* __restrict__ out4ls = nullptr) {
   // out4 / out4s (AUX 4: conditional sequences; AUX 5: the plain forward, every sequence; optional): e2m1 of the output VALUES (row stride 2d
   // bytes) with one E8M0 scale byte per (row, head) in the lane-ordered layout of the GEMM's mini-tile passes (GemmArgs.lo; out4_nseq sequences),
   // DH = 64, N = 257 -- the token operand of the out-proj GEMM's weight-correction pass
@@ -298,10 +324,17 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void attention_kernel(const h16* __
         // exchanges -- odd / even lane rows (dh tiles 2j <-> 2j + 1), then the lane halves -- give every lane 8 CONSECUTIVE bytes of the row's 32-byte
         // block (the GELU epilogue's trick, gemm_ht.hip); all 64 lanes take part (the row guard is uniform over a row's four lane groups)
         const uint2 pk8 = fp4_row8(o, inv, mul);
+        uint32_t lob = 0;
+        uint2 lo8 = make_uint2(0u, 0u);
+        if (out4l) lo8 = fp4_lo_block(o, inv, lob);                   // (uniform branch: every lane of the wave takes part in the exchanges)
         if (q < 256) {                                                // (class-token rows take no part in the mini-tile passes)
           const size_t row = (size_t)sq * N + q;
           if (g == 0) out4s[fp4_scale_index(h, out4_nseq, sq, q)] = (uint8_t)fp4_scale_byte_nosat(am);
           *(uint2*)(out4 + row * 2 * d + (h * DH) / 2 + (g >> 1) * 16 + (g & 1) * 8) = pk8;
+          if (out4l) {
+            if (g == 0) out4ls[fp4_scale_index(h, out4_nseq, sq, q)] = (uint8_t)lob;
+            *(uint2*)(out4l + row * 2 * d + (h * DH) / 2 + (g >> 1) * 16 + (g & 1) * 8) = lo8;
+          }
         }
       }
     }
@@ -336,7 +369,8 @@ constexpr int ATTL_KB = 128;             // keys per block
 template <int DH, bool PAIRM = false>
 __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __restrict__ qkv, h16* __restrict__ out,
                                                                int N, int d, int heads, int nchunk, float scale_log2e, int sq_off = 0,
-                                                               uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0) {
+                                                               uint8_t* __restrict__ out4 = nullptr, uint8_t* __restrict__ out4s = nullptr, int out4_nseq = 0,
+                                                               uint8_t* __restrict__ out4l = nullptr, uint8_t* __restrict__ out4ls = nullptr) {
   constexpr int ROW = DH * 2, SL = DH / 8, KS = DH / 32, NT = DH / 16, RPI = 64 / SL;
   constexpr int BLK_BYTES = ATTL_KB * ROW;                 // one operand block
   constexpr int NINST = ATTL_KB / RPI;                     // DMA instructions per operand block (16 or 8)
@@ -474,10 +508,17 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const h16* __res
       am = rows_max(am) * inv;
       const float mul = fp4_scale_mul_nosat(am);
       const uint2 pk8 = fp4_row8(o, inv, mul);             // (8 consecutive bytes per lane: see attention_kernel)
+      uint32_t lob = 0;
+      uint2 lo8 = make_uint2(0u, 0u);
+      if (out4l) lo8 = fp4_lo_block(o, inv, lob);
       if (q < N - 1) {                                     // (class-token rows take no part in the mini-tile passes)
         const size_t row = (size_t)sq * N + q;
         if (g == 0) out4s[fp4_scale_index(h, out4_nseq, sq, q, (N - 1) >> 6)] = (uint8_t)fp4_scale_byte_nosat(am);
         *(uint2*)(out4 + row * 2 * d + (h * DH) / 2 + (g >> 1) * 16 + (g & 1) * 8) = pk8;
+        if (out4l) {
+          if (g == 0) out4ls[fp4_scale_index(h, out4_nseq, sq, q, (N - 1) >> 6)] = (uint8_t)lob;
+          *(uint2*)(out4l + row * 2 * d + (h * DH) / 2 + (g >> 1) * 16 + (g & 1) * 8) = lo8;
+        }
       }
     }
   }
@@ -575,22 +616,23 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
   else hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, qkv, out, N, d, heads, scale_log2e);
 }
 
-int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d, int heads, uint8_t* out4, uint8_t* out4s) {
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d, int heads, uint8_t* out4, uint8_t* out4s, uint8_t* out4l, uint8_t* out4ls) {
   const int dh = d / heads;
   if (dh != 64 && dh != 32) return -1;
+  if ((out4l || out4ls) && (!out4 || !out4s || !out4l || !out4ls)) return -1;   // the lo copy rides with the value copy
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   if (N > ATT_NP) {                                           // the 1024 + 1-token models: streaming kernel, both streams of a pair in one workgroup
     if (out4 && (dh != 64 || (N - 1) % 64)) return -1;
     const int nchunk = ((N + 15) / 16 + 3) / 4;
     dim3 grid(P * heads * nchunk), block(256);
-    if (dh == 64) hipLaunchKernelGGL((attention_long_kernel<64, true>), grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e, P, out4, out4s, P);
+    if (dh == 64) hipLaunchKernelGGL((attention_long_kernel<64, true>), grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e, P, out4, out4s, P, out4l, out4ls);
     else hipLaunchKernelGGL((attention_long_kernel<32, true>), grid, block, 0, s, qkv, out, N, d, heads, nchunk, scale_log2e, P);
     return 0;
   }
   dim3 grid(P * heads), block(64 * ATT_NW);
   if ((out4 || out4s) && (dh != 64 || N != 257)) return -1;   // the fp4 output exists for head dimension 64 and 257-token sequences
   // one workgroup per (pair, head): conditional pass, then the twin; conditional outputs parked in registers
-  if (dh == 64) hipLaunchKernelGGL((attention_kernel<64, 4>), grid, block, 0, s, qkv, out, N, d, heads, scale_log2e, P, out4, out4s, P);
+  if (dh == 64) hipLaunchKernelGGL((attention_kernel<64, 4>), grid, block, 0, s, qkv, out, N, d, heads, scale_log2e, P, out4, out4s, P, out4l, out4ls);
   else hipLaunchKernelGGL((attention_kernel<32, 4>), grid, block, 0, s, qkv, out, N, d, heads, scale_log2e, P);
   return 0;
 }

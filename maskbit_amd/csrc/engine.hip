@@ -120,7 +120,7 @@ struct mb_gen {
   // in the guided forward's FFN-up GEMM: xl4 / xl4s = e2m1 of their lo halves, w4 / w4s = e2m1 of the (fp16) weight net.0.
   bool pair_ok = false, mini_ok = false;
   uint8_t *x4 = nullptr, *x4s = nullptr, *xl4 = nullptr, *xl4s = nullptr;
-  std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {-, -, 1, -}]: net.0 only
+  std::vector<uint8_t*> w4, w4s;                                                         // [4 * layer + {qkv, o, 1, 2}]: precision 3: net.0 of the late layers only; precision 4: all
   float* logits_tmp = nullptr;                          // guided forwards over more pairs than one pass holds
   // The two head GEMMs run hi + lo inputs against hi + lo WEIGHTS in every mode (GemmArgs.W2: three sweeps): their rounding reaches the logits
   // un-averaged -- fp16 head weights alone were a quarter of the sampled-logit error variance left after the trunk's weight correction
@@ -131,6 +131,7 @@ struct mb_gen {
   unsigned* sat = nullptr;                              // lanes of the QKV / FFN-up epilogues that clamped a fp16 store (mb_gen_saturation_count)
   std::vector<uint8_t*> w4lo, w4los;                                                     // [4 * layer + {qkv, o, 1, 2}]
   uint8_t *att4 = nullptr, *att4s = nullptr, *h4 = nullptr, *h4s = nullptr;              // e2m1 of the conditional attention outputs / FFN hiddens + block scales
+  uint8_t *attl4 = nullptr, *attl4s = nullptr, *hl4 = nullptr, *hl4s = nullptr;          // precision 4: e2m1 of their fp16 LO HALVES (activation-lo sets of out-proj / FFN-down)
   // loop state for mb_sample
   // the run mb_sample is in the middle of (step chunks): samples, total steps, guidance flag, the step the next chunk must begin with (-1: no run)
   int loop_B = 0, loop_steps = 0, loop_guided = 0, loop_next = -1;
@@ -290,19 +291,26 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // all layers 496 mismatches; FFN-up alone 491-493; QKV alone 555; neither 625 -- the QKV set buys nothing and cost 34 us per layer.  FFN-up set by
   // layer range: [0, 24) 493, [12, 24) 531, [18, 24) 560, [6, 18) 579, [0, 12) 612, [0, 6) 627 -- the late layers carry the gain: the second half
   // keeps 70 % of it (5.3e-4 pooled, the worst single run 8.7e-4 against 8.3e-4) for half of the 84 us per layer.
+  // precision 4 (round 6; what heavy-tailed checkpoints need, DESIGN.md "Precision"): the activation-lo set on ALL FOUR trunk GEMMs of EVERY layer -- the
+  // lo halves of the LayerNorm outputs (QKV, FFN-up), of the attention outputs (out-proj) and of the FFN hiddens (FFN-down), each as e2m1 with
+  // per-(row, 64 columns) scales against e2m1 of the fp16 weight.  With exact weights the fp16 rounding of those three operands alone costs 7e-4 of
+  // token mismatch on the early steps of a trained-like run (a third each); emulated on that run (tests/diag/error_budget.py EB_STUDY=r6): rms error
+  // of the sampled logits' top-2 gap 0.0062 -> 0.0031 with the three sets (and the per-(row, 128 columns) weight-error scales).
+  const bool alo_all = wmode && c.precision >= 4;
   const bool alo = wmode && c.precision == 3;
-  auto alo_layer = [&](int l) { return alo && 2 * l + 1 >= c.depth; };
+  auto alo_layer = [&](int l) { return alo_all || (alo && 2 * l + 1 >= c.depth); };
   auto f4_for = [&](int consumer_layer, bool feeds_ffn = false) {   // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
     if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) {
       f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; f.seq_rows = N;
-      if (feeds_ffn && alo_layer(consumer_layer)) { f.xl4 = g->xl4; f.xl4s = g->xl4s; }        // (the lo halves' e2m1 copy: only the LayerNorm in front of such an FFN-up)
+      if (alo_all || (feeds_ffn && alo_layer(consumer_layer))) { f.xl4 = g->xl4; f.xl4s = g->xl4s; }   // (the lo halves' e2m1 copy: precision 3 only the LayerNorm in front of such an FFN-up)
     }
     return f;
   };
-  // lo: 0 = fp16 only, 1 = weight-correction mini-tiles (a4 / a4s = e2m1 of the conditional operand values), 2 = + the activation-lo set (x only)
+  // lo: 0 = fp16 only, 1 = weight-correction mini-tiles (a4 / a4s = e2m1 of the conditional operand values), 2 = + the activation-lo set (al4 / al4s = e2m1
+  // of the operand's lo halves, against e2m1 of the fp16 weight)
   auto pgemm = [&](GemmEpi epi, const h16* A, const h16* W, const float* bias, h16* out16, float* res, int Nout, int K, int widx, int lo,
-                   const uint8_t* a4 = nullptr, const uint8_t* a4s = nullptr) {
+                   const uint8_t* a4 = nullptr, const uint8_t* a4s = nullptr, const uint8_t* al4 = nullptr, const uint8_t* al4s = nullptr) {
     GemmArgs ga{A, W, bias, res, res, out16, M, Nout, K, 0};
     ga.pair_rows = P;
     ga.seq_rows = N;
@@ -310,7 +318,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     if (lo && !((g->wcorr_mask >> (widx & 3)) & 1)) lo = 0;
     if (lo) {
       ga.nlo = lo; ga.lo[0] = {a4, a4s, g->w4lo[widx], g->w4los[widx]};
-      if (lo == 2) ga.lo[1] = {g->xl4, g->xl4s, g->w4[widx], g->w4s[widx]};
+      if (lo == 2) ga.lo[1] = {al4, al4s, g->w4[widx], g->w4s[widx]};
     }
     return ga;
   };
@@ -336,12 +344,14 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     const bool wl = wmode && l >= wfrom;
     const int xlo_mode = wl ? (alo_layer(l) ? 2 : 1) : 0;
     { ProfScope p("gemm_qkv", s, true);
-      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wl ? 1 : 0, g->x4, g->x4s);
+      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wl ? (alo_all ? 2 : 1) : 0, g->x4, g->x4s, g->xl4, g->xl4s);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
     const bool wo4 = wl && (g->wcorr_mask & 2), wh4 = wl && (g->wcorr_mask & 8);
-    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr); }
+    const bool lo_o = wo4 && alo_all, lo_h = wh4 && alo_all;      // precision 4: the producers also write the lo halves' e2m1 copies
+    { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr,
+                                                              lo_o ? g->attl4 : nullptr, lo_o ? g->attl4s : nullptr); }
     { ProfScope p("gemm_attn_out", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? 1 : 0, g->att4, g->att4s);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? (alo_all ? 2 : 1) : 0, g->att4, g->att4s, g->attl4, g->attl4s);
       if (l > 0 && !c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     // post-norm: LayerNorm 1 follows the attention block; pre-norm: LayerNorm 2 precedes the FFN (same place in the launch order, other parameters;
@@ -349,11 +359,12 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
     { ProfScope p("layernorm", s, true);
       rc |= layernorm_pair(s, g->y_f32, c.prenorm ? L.ln2g : L.ln1g, c.prenorm ? L.ln2b : L.ln1b, 1e-12f, g->x_h16, c.prenorm ? nullptr : g->ln_stats, P, d, f4_for(l, true)); }
     { ProfScope p("gemm_ffn_up", s, true);
-      GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, xlo_mode, g->x4, g->x4s);
+      GemmArgs ga = pgemm(EPI_GELU_H16, g->x_h16, L.w1, L.b1, g->h, nullptr, f, d, 4 * l + 2, xlo_mode, g->x4, g->x4s, g->xl4, g->xl4s);
       if (wh4) { ga.out4 = g->h4; ga.out4_scale = g->h4s; }
+      if (lo_h) { ga.out4l = g->hl4; ga.out4l_scale = g->hl4s; }
       rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
     { ProfScope p("gemm_ffn_down", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? 1 : 0, g->h4, g->h4s);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? (alo_all ? 2 : 1) : 0, g->h4, g->h4s, g->hl4, g->hl4s);
       if (!c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     { ProfScope p("layernorm", s, true);
@@ -461,10 +472,11 @@ int mb_gemm_ex(int epi, const void* A, const void* W, const float* bias, const f
 }
 int mb_gemm_mini(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
                  void* out4_scale, int rows, int pair, int N, int K, int nlo, const void* const* lo /* nlo x {A4, a_scale, W4, w_scale} */, mb_stream stream) {
-  return mb_gemm_mini_seq(epi, A, W, bias, residual, out_f32, out_h16, out4, out4_scale, rows, pair, 0, N, K, nlo, lo, stream);
+  return mb_gemm_mini_seq(epi, A, W, bias, residual, out_f32, out_h16, out4, out4_scale, nullptr, nullptr, rows, pair, 0, N, K, nlo, lo, stream);
 }
 int mb_gemm_mini_seq(int epi, const void* A, const void* W, const float* bias, const float* residual, float* out_f32, void* out_h16, void* out4,
-                     void* out4_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream) {
+                     void* out4_scale, void* out4l, void* out4l_scale, int rows, int pair, int seq_rows, int N, int K, int nlo, const void* const* lo, mb_stream stream) {
+  if ((out4l || out4l_scale) && (!out4l || !out4l_scale || !out4 || !out4_scale)) return fail(-1, "mb_gemm_mini_seq: the lo copy (out4l / out4l_scale) rides with the value copy (out4 / out4_scale)");
   if (!A || !W || !bias || epi < 0 || epi > 2 || rows <= 0 || K <= 0 || K % 64 || nlo < 0 || nlo > 2 || (nlo && !lo)) return fail(-1, "mb_gemm_mini: bad arguments");
   mb::GemmArgs a{(const h16*)A, (const h16*)W, bias, residual, out_f32, (h16*)out_h16, pair ? 2 * rows : rows, N, K, 0};
   if (pair) a.pair_rows = rows;
@@ -472,6 +484,7 @@ int mb_gemm_mini_seq(int epi, const void* A, const void* W, const float* bias, c
   a.nlo = nlo;
   for (int i = 0; i < nlo; ++i) a.lo[i] = {(const uint8_t*)lo[4 * i], (const uint8_t*)lo[4 * i + 1], (const uint8_t*)lo[4 * i + 2], (const uint8_t*)lo[4 * i + 3]};
   a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale;
+  a.out4l = (uint8_t*)out4l; a.out4l_scale = (uint8_t*)out4l_scale;
   if ((!seq_rows && a.M % 257) || !mb::gemm_ht_supported((mb::GemmEpi)epi, a)) return fail(-3, "mb_gemm_mini: shape not supported by the sequence-aligned tiles");
   ProfScope p("gemm_diag", (hipStream_t)stream);
   if (mb::gemm_tn((hipStream_t)stream, (mb::GemmEpi)epi, a, 257)) return fail(-3, "mb_gemm_mini: shape refused");
@@ -504,10 +517,10 @@ int mb_attention_pair(const void* qkv, void* out_h16, int pairs, int N, int d, i
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
-int mb_attention_pair_f4(const void* qkv, void* out_h16, void* out4, void* out4_scale, int pairs, int N, int d, int heads, mb_stream stream) {
-  if (!qkv || !out_h16 || !out4 || !out4_scale || pairs <= 0 || N <= 0 || heads <= 0 || d % heads) return fail(-1, "mb_attention_pair_f4: bad arguments");
+int mb_attention_pair_f4(const void* qkv, void* out_h16, void* out4, void* out4_scale, void* out4l, void* out4l_scale, int pairs, int N, int d, int heads, mb_stream stream) {
+  if (!qkv || !out_h16 || !out4 || !out4_scale || (!out4l) != (!out4l_scale) || pairs <= 0 || N <= 0 || heads <= 0 || d % heads) return fail(-1, "mb_attention_pair_f4: bad arguments");
   ProfScope p("attention", (hipStream_t)stream);
-  if (mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out_h16, pairs, N, d, heads, (uint8_t*)out4, (uint8_t*)out4_scale))
+  if (mb::attention_pair((hipStream_t)stream, (const h16*)qkv, (h16*)out_h16, pairs, N, d, heads, (uint8_t*)out4, (uint8_t*)out4_scale, (uint8_t*)out4l, (uint8_t*)out4l_scale))
     return fail(-3, "mb_attention_pair_f4: head width %d / N = %d tokens: no e2m1 copy for this shape", d / heads, N);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-11, "kernel launch failed: %s", hipGetErrorString(e));
@@ -585,7 +598,7 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   if (C > 4096 || (c.splits * C) % 4) return fail(-1, "unsupported group codebook size %d (the fused step kernel holds up to 4096 codes per group)", C);
   if ((c.prenorm != 0 && c.prenorm != 1) || (c.embed_tables != 0 && c.embed_tables != 1)) return fail(-1, "prenorm / embed_tables must be 0 or 1");
   if (c.embed_tables && c.splits > 8) return fail(-1, "embed_tables supports up to 8 token groups");
-  if (c.precision < 0 || c.precision > 3) return fail(-1, "precision must be 0 .. 3 (MB_PREC_FP16 / _DIFF / _WCORR / _ALO)");
+  if (c.precision < 0 || c.precision > 4) return fail(-1, "precision must be 0 .. 4 (MB_PREC_FP16 / _DIFF / _WCORR / _ALO / _ALO_ALL)");
   mb_gen* g = new mb_gen();
   g->c = c; g->max_seqs = max_seqs; g->N = c.seq + 1; g->gbits = c.bits / c.splits; g->C = C;
   (void)hipGetDevice(&g->device);
@@ -629,7 +642,15 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
     rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->att4, M * 2 * d); rc |= galloc(g, &g->att4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->h4, M * 2 * f); rc |= galloc(g, &g->h4s, (f / 64) * ns + 256);
-    if (c.precision == 3) { rc |= galloc(g, &g->xl4, M * 2 * d); rc |= galloc(g, &g->xl4s, (d / 64) * ns + 256); }
+    if (c.precision >= 3) { rc |= galloc(g, &g->xl4, M * 2 * d); rc |= galloc(g, &g->xl4s, (d / 64) * ns + 256); }
+    if (c.precision >= 4) {
+      rc |= galloc(g, &g->attl4, M * 2 * d); rc |= galloc(g, &g->attl4s, (d / 64) * ns + 256);
+      rc |= galloc(g, &g->hl4, M * 2 * f); rc |= galloc(g, &g->hl4s, (f / 64) * ns + 256);
+      if (!rc) {
+        (void)hipMemset(g->attl4, 0, M * 2 * d); (void)hipMemset(g->attl4s, 0, (d / 64) * ns + 256);
+        (void)hipMemset(g->hl4, 0, M * 2 * f); (void)hipMemset(g->hl4s, 0, (f / 64) * ns + 256);
+      }
+    }
     if (!rc) {
       (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, (d / 64) * ns + 256);
       (void)hipMemset(g->att4, 0, M * 2 * d); (void)hipMemset(g->att4s, 0, (d / 64) * ns + 256);
@@ -639,12 +660,18 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
     g->w4lo.assign((size_t)4 * c.depth, nullptr); g->w4los.assign((size_t)4 * c.depth, nullptr);
     g->w4.assign((size_t)4 * c.depth, nullptr); g->w4s.assign((size_t)4 * c.depth, nullptr);
     for (int l = 0; l < c.depth; ++l) {
-      rc |= galloc(g, &g->w4lo[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4los[4 * l], 3 * d);          // (mini-tile-packed: half a byte per weight)
-      rc |= galloc(g, &g->w4lo[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4los[4 * l + 1], d);
-      rc |= galloc(g, &g->w4lo[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4los[4 * l + 2], f);
-      rc |= galloc(g, &g->w4lo[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4los[4 * l + 3], d);
-      if (c.precision == 3 && 2 * l + 1 >= c.depth) {          // (the activation-lo set runs in FFN-up of the late layers: gen_forward_pair_impl)
-        rc |= galloc(g, &g->w4[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4s[4 * l + 2], f);
+      // (mini-tile-packed: half a byte per weight; one scale byte per (weight row, 128 columns))
+      rc |= galloc(g, &g->w4lo[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4los[4 * l], 3 * d * d / 128);
+      rc |= galloc(g, &g->w4lo[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4los[4 * l + 1], d * d / 128);
+      rc |= galloc(g, &g->w4lo[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4los[4 * l + 2], f * d / 128);
+      rc |= galloc(g, &g->w4lo[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4los[4 * l + 3], d * f / 128);
+      if ((c.precision == 3 && 2 * l + 1 >= c.depth) || c.precision >= 4) {   // (precision 3: the activation-lo set runs in FFN-up of the late layers: gen_forward_pair_impl)
+        rc |= galloc(g, &g->w4[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4s[4 * l + 2], f * d / 128);
+      }
+      if (c.precision >= 4) {                                     // ... precision 4: on all four GEMMs of every layer
+        rc |= galloc(g, &g->w4[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4s[4 * l], 3 * d * d / 128);
+        rc |= galloc(g, &g->w4[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4s[4 * l + 1], d * d / 128);
+        rc |= galloc(g, &g->w4[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4s[4 * l + 3], d * f / 128);
       }
     }
   }
@@ -888,7 +915,9 @@ int mb_sample(mb_gen* g, mb_dec* d, const mb_sample_plan* plan, const int64_t* l
     // sampling.py:98-99 combines c + s_i (c - u).  Where the annealed scale s_i is exactly 0 -- the first steps of the cosine schedule: (i / N)^p pi
     // is below float32's cos() resolution -- the unconditional logits do not enter the result (c + 0 (c - u) == c for finite logits), so that
     // forward is not run: the step is the plain conditional forward, bit for bit what the guided expression evaluates to.
-    if (plan->use_guidance && plan->scale[i] != 0.0f) {
+    // (precision 4: the guided forward is also the MORE PRECISE conditional forward -- its pair tiles carry the activation-lo sets, the plain tiles do not --
+    // and the first, almost fully masked steps are where near-ties flip: the zero-scale steps run it too; its unconditional half is then multiplied by 0)
+    if (plan->use_guidance && (plan->scale[i] != 0.0f || (g->pair_ok && c.precision >= 4))) {
       rc = gen_forward_cfg(g, cur, labels, g->logits, B, s);
       lu = g->logits + (size_t)B * P * C;
       if (B <= g->chunk_seqs / 2) { g->cfg_labels_ready = labels; g->cfg_ready_B = B; }   // lab_cfg / drop_cfg stay valid for the rest of this call

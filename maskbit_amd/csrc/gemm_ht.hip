@@ -252,10 +252,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
     if constexpr (!PAIR) return ((((uint32_t)(2 * jj + (lo_ >> 5)) * nseq + p.seq) << tps_sh) << 8) + gq * 64 + (lo_ & 15) * 4;   // (grp_bytes = 256 TPS)
     return ((uint32_t)(2 * jj + (lo_ >> 5)) * nseq + p.seq) * grp_bytes + gq * 64 + (lo_ & 15) * 4;
   };
-  int mwsc0 = 0, mwsc1 = 0, mxs = 0;                    // MINI: weight scale dwords of the (two) operand sets, the current mini's token scale dword
-  auto mini_scale_issue = [&](const Plan& p, int j) {    // inline asm: counted by the K loop's own vmcnt wait, which the register is tied through
-    const uint8_t* base = a.lo[PAIR ? (j >= nmk ? 1 : 0) : 0].a_scale;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(mxs) : "v"(mini_scale_off(p, j)), "s"(base) : "memory");
+  // the weight operand's scale dword of this lane for mini j: the bytes of its four n-tiles for K-elements [128 jj, 128 jj + 128) (w4_scale_index; one scale
+  // per (weight row, mini-tile) since round 6 -- rounds 2-5 held one dword per operand set for the whole K loop)
+  auto mini_wscale_off = [&](const Plan& p, int j) -> uint32_t {
+    const int ps = j >= nmk ? 1 : 0, jj = j - ps * nmk;
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
+    return (uint32_t)((((p.n0 >> 6) + wn) * nmk + jj) * 64 + (lo_ & 15) * 4);
+  };
+  int mws = 0, mxs = 0;                                 // MINI: the current mini's weight / token scale dwords
+  auto mini_scale_issue = [&](const Plan& p, int j) {    // inline asm: counted by the K loop's own vmcnt wait, which the registers are tied through
+    const int ps = PAIR ? (j >= nmk ? 1 : 0) : 0;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(mxs) : "v"(mini_scale_off(p, j)), "s"(a.lo[ps].a_scale) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(mws) : "v"(mini_wscale_off(p, j)), "s"(a.lo[ps].w_scale) : "memory");
   };
   // all of K-tiles 0 and 1 of a tile (both LDS parities must be free)
   // (nk >= 2 is a precondition of this kernel: gemm_ht_supported)
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #define MB_MINI_ONE(AH, N, I)                                                                       \
   acc[N][(AH) * MH + (I)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                        \
       __builtin_shufflevector(mwb[N], mwb[N], 0, 1, 2, 3, -1, -1, -1, -1), __builtin_shufflevector(mxa[I], mxa[I], 0, 1, 2, 3, -1, -1, -1, -1), \
-      acc[N][(AH) * MH + (I)], 4, 4, N, mws, I, mxs);
+      acc[N][(AH) * MH + (I)], 4, 4, N, mwsel, I, mxs);
 #define MB_MINI_MMA_QN(AH)                                                                          \
   MB_MINI_ONE(AH, 0, 0) MB_MINI_ONE(AH, 0, 1) MB_MINI_ONE(AH, 0, 2) MB_MINI_ONE(AH, 0, 3)           \
   _Pragma("unroll") for (int i = 0; i < MH; ++i) asm volatile("" : "+v"(acc[0][(AH) * MH + i]));
@@ -333,14 +341,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   make_plan(vb, cur);
   auto scales_load = [&](const Plan& p) {             // plain loads; scales_pack() after a vmcnt(0) that the loaded registers are tied through
     int lo_ = lane; asm volatile("" : "+v"(lo_));
-    const int r15 = lo_ & 15;
-    mwsc0 = ((const int*)a.lo[0].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
-    if (PAIR && a.nlo > 1) mwsc1 = ((const int*)a.lo[1].w_scale)[((p.n0 >> 6) + wn) * 16 + r15];
+    (void)lo_;
+    mws = *(const int*)(a.lo[0].w_scale + mini_wscale_off(p, 0));          // (mini 0 of a tile comes with the prologue)
     mxs = *(const int*)(a.lo[0].a_scale + mini_scale_off(p, 0));
   };
   auto scales_pack = [&]() {
-    if constexpr (MINI && PAIR) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwsc0), "+v"(mwsc1), "+v"(mxs) :: "memory"); asm volatile("" : "+v"(mwsc0), "+v"(mwsc1)); return; }
-    if constexpr (MINI) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwsc0), "+v"(mxs) :: "memory"); asm volatile("" : "+v"(mwsc0)); return; }
+    if constexpr (MINI) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mws), "+v"(mxs) :: "memory"); return; }
   };
   if constexpr (MINI) scales_load(cur);
   prologue(cur);
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
 #define MB_MINI_X_READ(...) __VA_ARGS__
 #endif
 #ifdef MB_MINI_NO_MMA
-#define MB_MINI_X_MMA(...) asm volatile("" :: "v"(mwb[0]), "v"(mwb[1]), "v"(mwb[2]), "v"(mwb[3]), "v"(mxa[0]), "v"(mxa[1]), "v"(mxa[2]), "v"(mxa[3]), "v"(mws), "v"(mxs));
+#define MB_MINI_X_MMA(...) asm volatile("" :: "v"(mwb[0]), "v"(mwb[1]), "v"(mwb[2]), "v"(mwb[3]), "v"(mxa[0]), "v"(mxa[1]), "v"(mxa[2]), "v"(mxa[3]), "v"(mwsel), "v"(mxs));
 #else
 #define MB_MINI_X_MMA(...) __VA_ARGS__
 #endif
@@ -432,15 +438,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           if constexpr (QN)                              /* (quarter-column tiles: A0, (X,) B0 of K-tile t+2 stay in flight: 3 / 4 instructions) */ \
             asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(4)\n\ts_branch 3f\n" \
                          "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(3)\n3:" \
-                         : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
+                         : "+v"(mxs), "+v"(mws) : [w] "s"(wsel) : "memory", "scc"); \
           else if constexpr (HN)                         /* (half-column tiles: 4 / 5 instructions) */ \
             asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(5)\n\ts_branch 3f\n" \
                          "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(4)\n3:" \
-                         : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
+                         : "+v"(mxs), "+v"(mws) : [w] "s"(wsel) : "memory", "scc"); \
           else \
           asm volatile("s_cmp_eq_u32 %[w], 0\n\ts_cbranch_scc1 1f\n\ts_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(7)\n\ts_branch 3f\n" \
                        "1:\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(6)\n3:" \
-                       : "+v"(mxs) : [w] "s"(wsel) : "memory", "scc"); \
+                       : "+v"(mxs), "+v"(mws) : [w] "s"(wsel) : "memory", "scc"); \
         } else if (n2) {                                 /* A0, B1, (X,) B0 of K-tile t+2 may stay in flight */ \
           if (SEQ && wave == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
@@ -451,7 +457,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       if constexpr (MINI) { \
         if (MB_MINI_PHASE_ON && (mini_every || (t & 1))) { \
           const int mj = mini_every ? t : (t >> 1); \
-          const int mps = __builtin_amdgcn_readfirstlane(mj >= nmk ? 1 : 0); \
           int lo_ = lane; \
           asm volatile("" : "+v"(lo_)); \
           const int mfo = (lo_ & 15) * 64 + (((lo_ >> 4) ^ ((lo_ >> 1) & 3)) * 16); \
@@ -460,14 +465,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           MB_MINI_X_READ( \
           _Pragma("unroll") for (int n = 0; n < NTW; ++n) mwb[n] = *(const i32x4*)(mbuf + MINI_A + (wn * (64 / NS) + n * 16) * 64 + mfo); \
           _Pragma("unroll") for (int i = 0; i < 4; ++i) mxa[i] = *(const i32x4*)(mbuf + (wm * 64 + i * 16) * 64 + mfo); ) \
-          const int mws = HN ? (int)((uint32_t)mwsc0 >> ((32 / NS) * cur.hb)) : ((PAIR && mps) ? mwsc1 : mwsc0); \
+          const int mwsel = HN ? (int)((uint32_t)mws >> ((32 / NS) * cur.hb)) : mws;   /* (column-split tiles: the bytes of this tile's n-tiles) */ \
           MB_SYNC_L() \
           MB_MINI_X_MMA(if constexpr (QN) { MB_MINI_MMA_QN(MAH) } else if constexpr (HN) { MB_MINI_MMA_HN(MAH) } else { MB_MINI_MMA(MAH) }) \
           /* (v_mfma_scale results must not be read by a VALU copy too early, see the class-row blocks above) */ \
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
           MB_MMA_END \
         } \
-        if constexpr (PAIR) asm volatile("" :: "v"(mwsc0), "v"(mwsc1)); else asm volatile("" :: "v"(mwsc0)); \
       } \
     }
     {
@@ -611,9 +615,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
         const uint32_t blk = (uint32_t)(n0 >> 6) + wn;
         const uint32_t nsq = (uint32_t)(PAIR ? a.pair_rows : a.M) / (uint32_t)SQ;
         const uint32_t ngrp = (uint32_t)TPS * (PAIR ? 2 : 4);
+        // a lane's four n-tiles are 2 bytes each (4 columns): as 2-byte stores they cost 13.6 us of a 372 us FFN-up launch (A/B, MB_NO_OUT4_STORE).
+        // Two lane exchanges give every lane 8 CONSECUTIVE bytes of the row's 32-byte block instead: the odd / even lane-row swap of the fp16
+        // stores (n-tiles 2pr <-> 2pr + 1: a lane then holds 8 columns of one n-tile), then the lane halves (g <-> g ^ 2: the neighbouring 8 columns)
+        auto emit4 = [&](uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint8_t* dst, uint32_t row, [[maybe_unused]] float mul) {
+          const auto sw = __builtin_amdgcn_permlane16_swap((p0 & 0xffffu) | (p2 << 16), (p1 & 0xffffu) | (p3 << 16), false, false);
+          const uint32_t q0 = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);      // 32-column group 0: this lane's 4 columns | its neighbour's
+          const uint32_t q1 = __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u);      // 32-column group 1
+          const auto sx = __builtin_amdgcn_permlane32_swap(q0, q1, false, false);    // lanes < 32: group 0 of lanes g, g + 2; lanes >= 32: group 1 of g - 2, g
+#ifdef MB_NO_OUT4_STORE                                     /* experiment (timing only): what the stores of the e2m1 copy cost */
+          if (mul == 12345.0f)
+#endif
+          *(uint2*)(dst + (size_t)row * 2 * a.N + ((n0 + wn * 64) >> 1) + (ge >> 1) * 16 + (ge & 1) * 8) = make_uint2(sx[0], sx[1]);
+        };
 #pragma unroll
         for (int hh = 0; hh < (PAIR ? 1 : 2); ++hh) {
-          uint32_t sc4 = 0;
+          uint32_t sc4 = 0, sl4 = 0;
 #pragma unroll
           for (int ii = 0; ii < MH; ++ii) {
             const int i = hh * MH + ii;
@@ -626,22 +643,26 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
             const float mul = fp4_scale_mul_nosat(am);
             const uint32_t row = (uint32_t)row_of(i);
             sc4 |= fp4_scale_byte_nosat(am) << (8 * ii);
-            // a lane's four n-tiles are 2 bytes each (4 columns): as 2-byte stores they cost 13.6 us of a 372 us FFN-up launch (A/B, MB_NO_OUT4_STORE).
-            // Two lane exchanges give every lane 8 CONSECUTIVE bytes of the row's 32-byte block instead: the odd / even lane-row swap of the fp16
-            // stores (n-tiles 2pr <-> 2pr + 1: a lane then holds 8 columns of one n-tile), then the lane halves (g <-> g ^ 2: the neighbouring 8 columns)
-            const uint32_t p0 = fp4_pack4(acc[0][i][0], acc[0][i][1], acc[0][i][2], acc[0][i][3], mul), p1 = fp4_pack4(acc[1][i][0], acc[1][i][1], acc[1][i][2], acc[1][i][3], mul);
-            const uint32_t p2 = fp4_pack4(acc[2][i][0], acc[2][i][1], acc[2][i][2], acc[2][i][3], mul), p3 = fp4_pack4(acc[3][i][0], acc[3][i][1], acc[3][i][2], acc[3][i][3], mul);
-            const auto sw = __builtin_amdgcn_permlane16_swap((p0 & 0xffffu) | (p2 << 16), (p1 & 0xffffu) | (p3 << 16), false, false);
-            const uint32_t q0 = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);      // 32-column group 0: this lane's 4 columns | its neighbour's
-            const uint32_t q1 = __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u);      // 32-column group 1
-            const auto sx = __builtin_amdgcn_permlane32_swap(q0, q1, false, false);    // lanes < 32: group 0 of lanes g, g + 2; lanes >= 32: group 1 of g - 2, g
-#ifdef MB_NO_OUT4_STORE                                     /* experiment (timing only): what the stores of the e2m1 copy cost */
-            if (mul == 12345.0f)
-#endif
-            *(uint2*)(a.out4 + (size_t)row * 2 * a.N + ((n0 + wn * 64) >> 1) + (ge >> 1) * 16 + (ge & 1) * 8) = make_uint2(sx[0], sx[1]);
+            emit4(fp4_pack4(acc[0][i][0], acc[0][i][1], acc[0][i][2], acc[0][i][3], mul), fp4_pack4(acc[1][i][0], acc[1][i][1], acc[1][i][2], acc[1][i][3], mul),
+                  fp4_pack4(acc[2][i][0], acc[2][i][1], acc[2][i][2], acc[2][i][3], mul), fp4_pack4(acc[3][i][0], acc[3][i][1], acc[3][i][2], acc[3][i][3], mul),
+                  a.out4, row, mul);
+            if (a.out4l) {                                   // (precision 4) the fp16 lo halves of the same values: what the fp16 store below rounds away
+              f32x4 l[4];
+              float aml = 0.f;
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { l[nt][e] = acc[nt][i][e] - (float)to_h(acc[nt][i][e]); aml = fmaxf(aml, fabsf(l[nt][e])); }
+              aml = rows_max(aml);
+              const float mull = fp4_scale_mul_nosat(aml);
+              sl4 |= fp4_scale_byte_nosat(aml) << (8 * ii);
+              emit4(fp4_pack4(l[0][0], l[0][1], l[0][2], l[0][3], mull), fp4_pack4(l[1][0], l[1][1], l[1][2], l[1][3], mull),
+                    fp4_pack4(l[2][0], l[2][1], l[2][2], l[2][3], mull), fp4_pack4(l[3][0], l[3][1], l[3][2], l[3][3], mull), a.out4l, row, mull);
+            }
           }
           const uint32_t gq = PAIR ? (uint32_t)tq * 2 + wm : (uint32_t)tq * 4 + wm * 2 + hh;
           if (ge == 0) ((uint32_t*)a.out4_scale)[((blk * nsq + (uint32_t)cur.seq) * ngrp + gq) * 16 + l15e] = sc4;
+          if (ge == 0 && a.out4l) ((uint32_t*)a.out4l_scale)[((blk * nsq + (uint32_t)cur.seq) * ngrp + gq) * 16 + l15e] = sl4;
         }
       }
     }

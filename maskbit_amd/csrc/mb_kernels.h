@@ -52,6 +52,10 @@ struct GemmArgs {
   // their lane-ordered scale bytes -- the token operand of the next GEMM's weight-correction pass; class-token rows are left untouched.
   uint8_t* out4 = nullptr;
   uint8_t* out4_scale = nullptr;
+  // ... and (optional, with out4; precision 4) out4l / out4l_scale: the same for the fp16 LO HALVES v - fp16(v) of those outputs, the token operand of the
+  // next GEMM's activation-lo pass
+  uint8_t* out4l = nullptr;
+  uint8_t* out4l_scale = nullptr;
   // MX-fp4 MINI-TILE correction passes (sequence-aligned half-tile kernel, K % 128 == 0): mini-tiles of 128 token rows x 256 weight rows x 128
   // K-elements (24 KiB of LDS behind the two K-tile parities), staged while the fp16 K-tiles run and multiplied in a fifth phase between them
   // (16 v_mfma_scale_f32_16x16x128_f8f6f4 per wave).  nlo = number of operand sets:
@@ -146,7 +150,9 @@ void attention(hipStream_t s, const h16* qkv, h16* out, int nb, int N, int d, in
 // then the twin with the conditional output tiles kept in registers -- and writes out[r + P*N] = fp16(att_u - att_c), the difference operand of the
 // out-proj pair GEMM.  N <= 288: K / V of a head in LDS; longer sequences (the 1024 + 1-token models): the streaming kernel in pair form.
 // out4 / out4s (head dimension 64 only): e2m1 of the conditional output values, row stride 2d bytes, + lane-ordered E8M0 scale bytes (GemmArgs.lo)
-int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d, int heads, uint8_t* out4 = nullptr, uint8_t* out4s = nullptr);
+// out4l / out4ls (optional, with out4; precision 4): the same for the fp16 lo halves o_c - fp16(o_c) of the conditional outputs (the out-proj GEMM's activation-lo pass)
+int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d, int heads, uint8_t* out4 = nullptr, uint8_t* out4s = nullptr,
+                   uint8_t* out4l = nullptr, uint8_t* out4ls = nullptr);
 // head-averaged attention weights [nb, N, N] fp32 of one layer (return_attn=True); -1 if the shape is not supported
 int attention_probs(hipStream_t s, const h16* qkv, float* out, int nb, int N, int d, int heads);
 

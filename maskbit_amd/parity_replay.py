@@ -166,7 +166,7 @@ def teacher_forced(gen, g=None, noise=None, batch: int = 0):
             tall = tall.contiguous()
         else:
             tall, y_all = tin, y
-        if float(g["kw"]["guidance_scale"]) != 0.0 and scale[i] != 0.0:
+        if float(g["kw"]["guidance_scale"]) != 0.0 and (scale[i] != 0.0 or gen.resolved_precision() >= 4):   # (precision 4: mb_sample runs the zero-scale steps through the guided forward too)
             lg = gen.forward_cfg(tall, y_all)              # the guided forward of the loop (cond | label-dropped); as in mb_sample, the steps whose
                                                                      # annealed scale is exactly 0 run the conditional forward alone (c + 0 (c - u) == c)
             lc, lu = lg[:NB][rows].contiguous(), lg[NB:][rows].contiguous()

@@ -37,7 +37,7 @@ def token_mismatch(a: torch.Tensor, b: torch.Tensor, where=None) -> float:
     return float(ne.float().mean())
 
 
-def gemm_mini(lib, epi, A, W, bias, res, out32, out16, rows, pair, N, K, lo_sets=(), out4=None, out4s=None, seq_rows=0):
+def gemm_mini(lib, epi, A, W, bias, res, out32, out16, rows, pair, N, K, lo_sets=(), out4=None, out4s=None, seq_rows=0, out4l=None, out4ls=None):
     """mb_gemm_mini / mb_gemm_mini_seq (include/maskbit_hip_diag.h): a sequence-aligned (pair) GEMM with len(lo_sets) MX-fp4 mini-tile passes; a set =
     (A4, a_scale, W4, w_scale) tensors; seq_rows: rows per sequence of a pair GEMM (0 = 257)."""
     import ctypes as C
@@ -45,8 +45,8 @@ def gemm_mini(lib, epi, A, W, bias, res, out32, out16, rows, pair, N, K, lo_sets
     ptr = lambda t: t.data_ptr() if t is not None else None
     flat = [t.data_ptr() for s in lo_sets for t in s]
     arr = (C.c_void_p * max(1, len(flat)))(*flat)
-    if seq_rows:
-        _lib.check(lib.mb_gemm_mini_seq(epi, ptr(A), ptr(W), ptr(bias), ptr(res), ptr(out32), ptr(out16), ptr(out4), ptr(out4s), rows, int(pair), seq_rows, N, K,
+    if seq_rows or out4l is not None:
+        _lib.check(lib.mb_gemm_mini_seq(epi, ptr(A), ptr(W), ptr(bias), ptr(res), ptr(out32), ptr(out16), ptr(out4), ptr(out4s), ptr(out4l), ptr(out4ls), rows, int(pair), seq_rows, N, K,
                                         len(lo_sets), arr, torch.cuda.current_stream().cuda_stream), "mb_gemm_mini_seq")
         return
     _lib.check(lib.mb_gemm_mini(epi, ptr(A), ptr(W), ptr(bias), ptr(res), ptr(out32), ptr(out16), ptr(out4), ptr(out4s), rows, int(pair), N, K,
@@ -112,12 +112,12 @@ def f4_encode_rows(v: torch.Tensor, nseq: int, dev="cuda", seq_rows: int = 257):
 
 def w4_decode(w4: torch.Tensor, wsb: torch.Tensor, N: int, K: int) -> torch.Tensor:
     """e2m1 weight operand in the mini-tile-packed layout (mb_kernels.h w4_packed_offset: [N / 16][K / 128] chunks of 16 rows x 64 B, the 16-byte
-    pieces of a row swizzled with (row >> 1) & 3) + its lane-ordered per-row scale bytes (mb_w4_from_f32 / mb_w4lo_from_f32) -> float64 [N, K] on
-    the device of w4."""
-    n = torch.arange(N, device=wsb.device)
-    row = wsb[((n >> 6) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)].to(torch.float64)
+    pieces of a row swizzled with (row >> 1) & 3) + its lane-ordered scale bytes, one per (weight row, 128 K-elements) (w4_scale_index; mb_w4_from_f32 /
+    mb_w4lo_from_f32) -> float64 [N, K] on the device of w4."""
+    n, j = torch.meshgrid(torch.arange(N, device=wsb.device), torch.arange(K // 128, device=wsb.device), indexing="ij")
+    blk = wsb[(((n >> 6) * (K // 128) + j) * 16 + (n & 15)) * 4 + ((n >> 4) & 3)].to(torch.float64)          # [N, K / 128]
     nn, kk = torch.meshgrid(torch.arange(N), torch.arange(0, K, 2), indexing="ij")         # byte of elements (k, k + 1)
     r, c = nn & 15, (kk & 127) >> 5
     off = ((nn >> 4) * (K >> 7) + (kk >> 7)) * 1024 + r * 64 + ((c ^ ((r >> 1) & 3)) << 4) + ((kk & 31) >> 1)
     rowmajor = w4.reshape(-1).cpu()[off.reshape(-1)].reshape(N, K // 2)
-    return f4_decode(rowmajor, K).to(w4.device) * (2.0 ** (row - 127)).reshape(N, 1)
+    return f4_decode(rowmajor, K).to(w4.device) * (2.0 ** (blk - 127)).repeat_interleave(128, 1)

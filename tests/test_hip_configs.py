@@ -146,17 +146,18 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
     Per-(row, 64 columns) scales keep an outlier channel from costing the resolution of the rest of its row; the fp16 stores of the trunk never
     clamp (mb_gen_saturation_count)."""
     from maskbit_amd import parity_replay as R
-    # KNOWN GAP (round 5, end): the second 12-bit trained-like run (batch 8, head gain 16) measures 179 / 168 568 = 1.06e-3 -- OVER the north star's 1e-3 on
-    # this one run (single fp16: 2.19e-3; the two 12-bit trained-like runs pooled: 240 / 252 852 = 9.5e-4).  79 of the 179 fall in the first quarter of the
-    # run, where nearly every token is still masked and the logits are nearly tied; tests/diag/error_budget.py on those steps: with EXACT weights the
-    # fp16 rounding of the activations alone (x, attention outputs, FFN hiddens: a third each) gives 7e-4 there.  Asserted at what is measured, not hidden.
+    # Round 5 closed with a KNOWN GAP here: the second 12-bit trained-like run measured 179 / 168 568 = 1.06e-3 at precision 2 -- over the north star's
+    # 1e-3 -- and was asserted at 1.2e-3.  Round 6: the auto mode escalates such checkpoints from their own statistics (LFQBert.weight_statistics: pooled
+    # row kurtosis 10.9, a LayerNorm channel at ~16x the median) to precision 4 -- activation-lo mini-tiles on every trunk GEMM, weight-error scales per
+    # (row, 128 columns) -- and EVERY run is asserted at the north star's 1e-3 again (precision 2 printed beside it as context).
     pooled = [0, 0]
-    for name, bound in ((R.RUN_C3_OUTLIER, 1e-3), (R.RUN_C3_OUTLIER_S2, 1.2e-3), (R.RUN_CFG1_OUTLIER, 1e-3)):
+    for name, bound in ((R.RUN_C3_OUTLIER, 1e-3), (R.RUN_C3_OUTLIER_S2, 1e-3), (R.RUN_CFG1_OUTLIER, 1e-3)):
         g = R.load_run(name)
         gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
+        assert gen.weight_statistics()["heavy_tailed"] and gen.resolved_precision() == 4
         noise = R.reference_noise(g, gen.device)
         out = {}
-        for tag, prec in (("product default", -1), ("single fp16", 0)):
+        for tag, prec in (("product default", -1), ("precision 2 (round 5's default here)", 2), ("single fp16", 0)):
             gen.precision = prec
             bad, tot, per, _ = R.teacher_forced(gen, g, noise)
             out[tag] = (bad, tot)
@@ -166,7 +167,7 @@ def test_trained_like_weights_heavy_tails_and_massive_activation_channels():
         assert sat == 0
         bad, tot = out["product default"]
         assert bad / tot <= bound, name
-        assert bad <= out["single fp16"][0]
+        assert bad <= out["single fp16"][0] and bad <= out["precision 2 (round 5's default here)"][0]
         if name != R.RUN_CFG1_OUTLIER:
             pooled[0] += bad; pooled[1] += tot
         del gen

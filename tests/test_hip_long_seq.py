@@ -73,13 +73,13 @@ def test_pair_gemm_1025_token_sequences(epi, pairs, N, K, nlo):
     st = torch.cuda.current_stream().cuda_stream
     sets, corr = [], 0
     if nlo >= 1:
-        w4 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8); ws = torch.zeros(N, device=DEV, dtype=torch.uint8)
+        w4 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8); ws = torch.zeros(N * K // 128, device=DEV, dtype=torch.uint8)
         _lib.check(lib.mb_w4lo_from_f32(W32.data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), st))
         x4, xs, x4_dec = f4_encode_rows(A[:P].double(), pairs, seq_rows=SQ)
         sets.append((x4, xs, w4, ws))
         corr = x4_dec @ w4_decode(w4, ws, N, K).t()
     if nlo == 2:
-        w4v = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8); wsv = torch.zeros(N, device=DEV, dtype=torch.uint8)
+        w4v = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8); wsv = torch.zeros(N * K // 128, device=DEV, dtype=torch.uint8)
         _lib.check(lib.mb_w4_from_f32(W32.data_ptr(), N, K, w4v.data_ptr(), wsv.data_ptr(), st))
         xl4, xls, xl_dec = f4_encode_rows(xc.double() - A[:P].double(), pairs, seq_rows=SQ)
         sets.append((xl4, xls, w4v, wsv))

@@ -16,7 +16,7 @@ def _weights(N, K, lib, lo: bool):
     from maskbit_amd import _lib
     W32 = torch.randn(N, K, device=DEV) * 0.03 * (0.5 + torch.rand(N, 1, device=DEV) * 2)      # rows of different scale
     w4 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8)
-    wsb = torch.zeros(N, device=DEV, dtype=torch.uint8)
+    wsb = torch.zeros(N * K // 128, device=DEV, dtype=torch.uint8)
     fn = lib.mb_w4lo_from_f32 if lo else lib.mb_w4_from_f32
     _lib.check(fn(W32.data_ptr(), N, K, w4.data_ptr(), wsb.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
@@ -24,7 +24,7 @@ def _weights(N, K, lib, lo: bool):
 
 
 @pytest.mark.parametrize("epi,pairs,N,K,nlo", [(0, 2, 768, 1024, 1), (2, 3, 256, 2048, 1), (1, 2, 512, 1024, 1), (0, 2, 768, 1024, 2), (1, 3, 1024, 1024, 2),
-                                               (2, 2, 1024, 4096, 1)])
+                                               (2, 2, 1024, 4096, 1), (2, 3, 1024, 1024, 2), (2, 2, 1024, 4096, 2)])       # (round 6, precision 4: two sets in the residual GEMMs too)
 def test_pair_gemm_with_mini_tile_passes(epi, pairs, N, K, nlo):
     """Pair tiles: out_c = f(A_c.W^T + sum_sets A4.W4^T + b), out_u = f(the same + A_delta.W^T) -- the corrections reach the unconditional rows through
     the shared conditional accumulator; class-token rows and the difference rows' own 4-bit data take no part."""
@@ -51,7 +51,11 @@ def test_pair_gemm_with_mini_tile_passes(epi, pairs, N, K, nlo):
     res = torch.randn(2 * P, N, device=DEV) if epi == 2 else None
     out32 = res.clone() if epi == 2 else None
     out16 = torch.full((2 * P, N), float("nan"), device=DEV, dtype=torch.float16) if epi != 2 else None
-    gemm_mini(lib, epi, A, W, bias, out32, out32, out16, P, True, N, K, sets)
+    # GELU epilogue with two sets = the engine's FFN-up at precision 4: also the e2m1 copies of the conditional outputs and of their fp16 lo halves
+    f4o = epi == 1 and nlo == 2
+    mk4 = lambda: (torch.zeros(2 * P, 2 * N, device=DEV, dtype=torch.uint8), torch.zeros((N // 64) * pairs * 256 + 256, device=DEV, dtype=torch.uint8))
+    (out4, out4s), (out4l, out4ls) = (mk4(), mk4()) if f4o else ((None, None), (None, None))
+    gemm_mini(lib, epi, A, W, bias, out32, out32, out16, P, True, N, K, sets, out4, out4s, 0, out4l, out4ls)
     torch.cuda.synchronize()
     pc = A[:P].double() @ W.double().t() + corr + bias.double()
     pu = pc + A[P:].double() @ W.double().t()
@@ -65,12 +69,26 @@ def test_pair_gemm_with_mini_tile_passes(epi, pairs, N, K, nlo):
     err = (got - want).abs()
     tol = 6e-5 if epi == 2 else 2e-3 * max(1.0, float(want.abs().max()))
     assert float(err.max()) < tol, (float(err.max()), int(err.argmax()) // N, int(err.argmax()) % N)
+    if f4o:
+        # the two e2m1 copies of the conditional GELU outputs h_c: values, and lo halves h_c - fp16(h_c) (the fp32 accumulation of fp16 products is within
+        # ~1e-6 of the fp64 `want`, far below an fp16 ulp: the kernel's lo halves can be checked against want - fp16 row directly)
+        rows = torch.arange(P)
+        seq, tok = rows // 257, rows % 257
+        keep = tok < 256
+        hc = want[:P][keep.to(DEV)].cpu()
+        for got4, gots, ref, tag in ((out4, out4s, hc, "values"), (out4l, out4ls, hc - out16[:P][keep.to(DEV)].double().cpu(), "lo halves")):
+            sb = torch.stack([gots.cpu()[f4_scale_index(b, pairs, seq[keep], tok[keep])] for b in range(N // 64)], 1).double()
+            dec = (f4_decode(got4[:P][keep.to(DEV)], N).reshape(-1, N // 64, 64) * (2.0 ** (sb - 127)).unsqueeze(-1)).reshape(-1, N)
+            resid = float(((dec - ref) ** 2).sum() / (ref ** 2).sum())
+            print(f"e2m1 copy of the GELU outputs' {tag}: residual energy {resid:.3f}")
+            assert resid < (0.02 if tag == "values" else 0.06), tag
+            assert int(got4[P:].count_nonzero()) == 0              # nothing for the difference rows
     # timing independence: repeat with the caches thrashed in between, bit for bit
     first = (out32 if out32 is not None else out16).clone()
     for _ in range(3):
         junk = torch.empty(96 << 20, device=DEV, dtype=torch.float32).normal_(); del junk
         if out32 is not None: out32.copy_(res)
-        gemm_mini(lib, epi, A, W, bias, out32, out32, out16, P, True, N, K, sets)
+        gemm_mini(lib, epi, A, W, bias, out32, out32, out16, P, True, N, K, sets, out4, out4s, 0, out4l, out4ls)
         torch.cuda.synchronize()
         assert torch.equal(out32 if out32 is not None else out16, first)
     if epi == 2 and nlo == 1:

@@ -52,7 +52,7 @@ def _w4(lib, N, K, lo=True):
     from maskbit_amd import _lib
     W32 = torch.randn(N, K, device=DEV) * 0.03 * (0.5 + torch.rand(N, 1, device=DEV) * 2)
     w4 = torch.zeros(N, 2 * K, device=DEV, dtype=torch.uint8)
-    ws = torch.zeros(N, device=DEV, dtype=torch.uint8)
+    ws = torch.zeros(N * K // 128, device=DEV, dtype=torch.uint8)
     _lib.check((lib.mb_w4lo_from_f32 if lo else lib.mb_w4_from_f32)(W32.data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
     return W32, w4, ws
 

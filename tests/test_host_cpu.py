@@ -209,6 +209,51 @@ def test_host_noise_draws_leave_the_thread_pool_alone_and_keep_the_stream():
     assert torch.equal(conf, want)
 
 
+def test_auto_precision_escalates_on_heavy_tailed_checkpoints(monkeypatch):
+    """The auto mode's load-time rule (LFQBert.weight_statistics / resolved_precision, round 6): Gaussian-like checkpoints resolve to 2 (3 from 7 bits per
+    group on); heavy-tailed Linear weights OR massive-activation LayerNorm channels -- the trained-like family of maskbit_amd/synth.py shows both --
+    escalate to PREC_ALO_ALL (4); an explicit knob wins; shapes the mini-tiles do not serve still degrade; new weights re-evaluate the rule."""
+    import torch
+    from maskbit_amd import LFQBert, synth
+    from maskbit_amd import bert as B
+    monkeypatch.delenv("MASKBIT_AMD_PRECISION", raising=False)
+    cfg = synth.GenCfg(bits=12, splits=2, hidden=768, depth=2, heads=12, mlp=1024)
+    mk = lambda c=cfg: LFQBert(img_size=256, hidden_dim=c.hidden, codebook_size=2 ** c.bits, codebook_splits=2, depth=c.depth, heads=c.heads, mlp_dim=c.mlp)
+    m = mk()
+    st = m.weight_statistics()
+    assert 2.5 < st["kurtosis"] < 3.2 and st["channel_ratio"] < 1.5 and not st["heavy_tailed"] and m.resolved_precision() == B.PREC_WCORR
+    m.load_state_dict(synth.make_generator_weights(cfg, seed=1), strict=True)
+    st = m.weight_statistics()
+    assert 2.8 < st["kurtosis"] < 3.2 and not st["heavy_tailed"] and m.resolved_precision() == B.PREC_WCORR
+    m.load_state_dict(synth.make_generator_weights(cfg, seed=1, style="outlier"), strict=True)          # new weights: the cached statistics are stale
+    st = m.weight_statistics()
+    assert st["kurtosis"] > 8 and st["channel_ratio"] > 8 and st["heavy_tailed"] and m.resolved_precision() == B.PREC_ALO_ALL
+    m.precision = B.PREC_WCORR
+    assert m.resolved_precision() == B.PREC_WCORR                                       # an explicit knob is not escalated
+    m.precision = B.PREC_AUTO
+    # either statistic alone escalates
+    sd = synth.make_generator_weights(cfg, seed=2)
+    for k in sd:
+        if k.endswith("norm.bias"):
+            sd[k][7] = 9.0                                                              # one massive-activation channel, Gaussian weights
+    m.load_state_dict(sd, strict=True)
+    st = m.weight_statistics()
+    assert st["kurtosis"] < 3.2 and st["channel_ratio"] > B.ESCALATE_CHANNEL_RATIO and m.resolved_precision() == B.PREC_ALO_ALL
+    sd = synth.make_generator_weights(cfg, seed=2)
+    gq = torch.Generator().manual_seed(0)
+    for k in sd:
+        if sd[k].dim() == 2 and k.startswith("transformer.layers."):
+            sd[k] = sd[k] * torch.where(torch.rand(sd[k].shape, generator=gq) < 0.03, 3.5, 0.9)     # heavy tails only
+    m.load_state_dict(sd, strict=True)
+    st = m.weight_statistics()
+    assert st["kurtosis"] > B.ESCALATE_KURTOSIS and st["channel_ratio"] < 1.5 and m.resolved_precision() == B.PREC_ALO_ALL
+    # a shape without mini-tiles (heads of 32) cannot run precision >= 2 whatever the statistics say
+    c2 = synth.GenCfg(bits=12, splits=2, hidden=768, depth=2, heads=24, mlp=1024)
+    m2 = mk(c2)
+    m2.load_state_dict(synth.make_generator_weights(c2, seed=1, style="outlier"), strict=True)
+    assert m2.resolved_precision() == B.PREC_DIFF
+
+
 def test_precision_knob_resolution(monkeypatch):
     """LFQBert.precision is the ONE precision knob (mb_gen_cfg.precision: 0 fp16, 1 differential guidance, 2 + weight-correction mini-tiles, 3 +
     activation-lo mini-tiles): the default resolves by codebook and degrades by what the pair / mini tiles serve; the header's enum, the ctypes struct and

@@ -16,7 +16,7 @@ out4 = torch.zeros(2 * P * N, 2 * d, device="cuda", dtype=torch.uint8)
 out4s = torch.zeros(heads * P * 256 + 256, device="cuda", dtype=torch.uint8)
 st = torch.cuda.current_stream().cuda_stream
 plain = lambda: lib.mb_attention_pair(qkv.data_ptr(), out.data_ptr(), P, N, d, heads, st)
-f4 = lambda: lib.mb_attention_pair_f4(qkv.data_ptr(), out.data_ptr(), out4.data_ptr(), out4s.data_ptr(), P, N, d, heads, st)
+f4 = lambda: lib.mb_attention_pair_f4(qkv.data_ptr(), out.data_ptr(), out4.data_ptr(), out4s.data_ptr(), None, None, P, N, d, heads, st)
 
 
 def timed(fn, n=50):

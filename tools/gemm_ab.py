@@ -39,7 +39,7 @@ def main():
             for _ in range(nlo):
                 x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8, generator=torch.Generator(device=dev).manual_seed(1))
                 xsb = torch.full(((K // 64) * 64 * 256 + 256,), 100, device=dev, dtype=torch.uint8)
-                w4 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); ws = torch.zeros(N, device=dev, dtype=torch.uint8)
+                w4 = torch.zeros(N, 2 * K, device=dev, dtype=torch.uint8); ws = torch.zeros(N * K // 128, device=dev, dtype=torch.uint8)
                 assert l.mb_w4_from_f32(W.float().data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), st) == 0
                 ts += [x4, xsb, w4, ws]
             sets[k] = (ts, (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts]))

@@ -25,7 +25,7 @@ sets = []
 for _ in range(nlo):
     x4 = torch.randint(0, 256, (M, 2 * K), device=dev, dtype=torch.uint8)
     xs = torch.full(((K // 64) * 64 * 256 + 256,), 100, device=dev, dtype=torch.uint8)
-    w4 = torch.zeros(N, K // 2, device=dev, dtype=torch.uint8); ws = torch.zeros(N, device=dev, dtype=torch.uint8)
+    w4 = torch.zeros(N, K // 2, device=dev, dtype=torch.uint8); ws = torch.zeros(N * K // 128, device=dev, dtype=torch.uint8)
     _lib.check(lib.mb_w4_from_f32(W.float().data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
     sets += [x4, xs, w4, ws]
 arr = (C.c_void_p * max(1, len(sets)))(*[t.data_ptr() for t in sets])
