@@ -113,6 +113,10 @@ OUTLIER_CONSUMER = 0.0625  # the consumers' columns of those channels (an outlie
 
 # 48 x 0.75, 12 x 1.5, 3 x 2.5, 1 x 4 of 64, normalised to unit second moment: kurtosis 10.9 (a Gaussian's: 3; Student-t_6: 6)
 _HEAVY_TAIL_SCALES = torch.tensor([0.75] * 48 + [1.5] * 12 + [2.5] * 3 + [4.0]) / math.sqrt((48 * 0.75 ** 2 + 12 * 1.5 ** 2 + 3 * 2.5 ** 2 + 16.0) / 64)
+# style "outlier2" (round 6: the held-out trained-like family): HEAVIER tails -- 48 x 0.7, 12 x 1.5, 3 x 3.0, 1 x 5.0 of 64: kurtosis 17.2, one weight in 64 is 7.1x
+# the typical one -- and ten massive-activation channels instead of six
+_HEAVIER_TAIL_SCALES = torch.tensor([0.7] * 48 + [1.5] * 12 + [3.0] * 3 + [5.0]) / math.sqrt((48 * 0.7 ** 2 + 12 * 1.5 ** 2 + 3 * 3.0 ** 2 + 25.0) / 64)
+_STYLES = {"outlier": (_HEAVY_TAIL_SCALES, OUTLIER_CHANNELS), "outlier2": (_HEAVIER_TAIL_SCALES, 10)}
 
 
 def _trained_like(sd: StateDict, cfg: GenCfg, seed: int, style: str) -> None:
@@ -126,8 +130,9 @@ def _trained_like(sd: StateDict, cfg: GenCfg, seed: int, style: str) -> None:
     the Gaussian draw's do (a large gamma instead runs away -- the next LayerNorm divides everything else by the outliers' magnitude -- and from
     +-15 on the random trunk stops passing information) -- and the matching in_proj / net.0 / last_layer.0 columns x OUTLIER_CONSUMER.  Deterministic
     from the seed (a generator of its own, so the Gaussian draw and every existing fixture stay what they were)."""
-    if style != "outlier":
+    if style not in _STYLES:
         raise ValueError(f"unknown weight style '{style}'")
+    tail_scales, n_outlier = _STYLES[style]
     g = torch.Generator().manual_seed(1_000_003 * (seed + 1))
     d = cfg.hidden
     for k in sorted(sd):
@@ -135,9 +140,9 @@ def _trained_like(sd: StateDict, cfg: GenCfg, seed: int, style: str) -> None:
         if v.dim() == 2 and (k.startswith("transformer.layers.") or k.startswith("last_layer.0") or k.startswith("prediction_layer")):
             # a scale mixture of normals from an integer draw and a table of exact constants: one multiply per weight, bit-reproducible on any host
             # (torch's CPU exponential_ and even sqrt are not: both differ between this build container and the GPU boxes' hosts)
-            sd[k] = v * _HEAVY_TAIL_SCALES[torch.randint(0, 64, v.shape, generator=g)]
-    ch = torch.randperm(d, generator=g)[:OUTLIER_CHANNELS]
-    sign = torch.where(torch.rand(OUTLIER_CHANNELS, generator=g) < 0.5, -1.0, 1.0)
+            sd[k] = v * tail_scales[torch.randint(0, 64, v.shape, generator=g)]
+    ch = torch.randperm(d, generator=g)[:n_outlier]
+    sign = torch.where(torch.rand(n_outlier, generator=g) < 0.5, -1.0, 1.0)
     norms = ["first_layer.0"] + [f"transformer.layers.{l}.{s}.norm" for l in range(cfg.depth) for s in (0, 1)]
     for n in norms:
         sd[n + ".weight"][ch] *= OUTLIER_GAMMA
