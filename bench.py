@@ -260,13 +260,16 @@ def variant_configs(dev):
     tok = ConvVQModel(tok_config())
     tok.load_state_dict(synth.make_tokenizer_weights(synth.TokCfg(token_size=12), seed=TOK_SEED), strict=False)
     tok = tok.eval().requires_grad_(False).to(dev)
-    for tag, cls, kw, gcfg, B in (
-            ("variant: use_prenorm=True, 12-bit/64 steps/CFG 7.1", LFQBert, dict(use_prenorm=True), synth.GenCfg(bits=12, splits=2, prenorm=True), 64),
-            ("variant: Bert (embedding tables, tied head), 12-bit/64 steps/CFG 7.1", Bert, dict(), synth.GenCfg(bits=12, splits=2, kind="bert"), 64),
-            ("variant: 1024 + 1 tokens (512 x 512 models), 12-bit/64 steps/CFG 7.1", LFQBert, dict(img_size=512), synth.GenCfg(bits=12, splits=2, seq=1024), 16)):
+    for tag, cls, kw, gcfg, B, style in (
+            ("variant: use_prenorm=True, 12-bit/64 steps/CFG 7.1", LFQBert, dict(use_prenorm=True), synth.GenCfg(bits=12, splits=2, prenorm=True), 64, "gaussian"),
+            ("variant: Bert (embedding tables, tied head), 12-bit/64 steps/CFG 7.1", Bert, dict(), synth.GenCfg(bits=12, splits=2, kind="bert"), 64, "gaussian"),
+            ("variant: 1024 + 1 tokens (512 x 512 models), 12-bit/64 steps/CFG 7.1", LFQBert, dict(img_size=512), synth.GenCfg(bits=12, splits=2, seq=1024), 16, "gaussian"),
+            # the ESCALATED mode (round 6): configs[2]'s workload on a heavy-tailed ("trained-like") checkpoint, which the auto mode escalates from its own
+            # statistics to precision 4 (activation-lo mini-tiles on every trunk GEMM of every layer): what that mode costs against the headline's precision 2
+            ("escalated: trained-like (heavy-tailed) 12-bit checkpoint, auto precision, 64 steps/CFG 7.1", LFQBert, dict(), synth.GenCfg(bits=12, splits=2), 64, "outlier")):
         try:
             gen = cls(**dict(GEN, **kw))
-            gen.load_state_dict(synth.make_generator_weights(gcfg, seed=GEN_SEED + 1, head_gain=HEAD_GAIN), strict=True)
+            gen.load_state_dict(synth.make_generator_weights(gcfg, seed=GEN_SEED + 1, head_gain=HEAD_GAIN, style=style), strict=True)
             gen = gen.eval().requires_grad_(False).to(dev)
             plan = build_plan(NUM_STEPS, 2 * gen.seq_len, SAMPLER["guidance_scale"], SAMPLER["guidance_annealing"], SAMPLER["scale_pow"],
                               SAMPLER["softmax_temperature"], False, SAMPLER["mask_schedule_strategy"])

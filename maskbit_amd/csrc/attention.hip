@@ -621,7 +621,10 @@ int attention_pair(hipStream_t s, const h16* qkv, h16* out, int P, int N, int d,
   if (dh != 64 && dh != 32) return -1;
   if ((out4l || out4ls) && (!out4 || !out4s || !out4l || !out4ls)) return -1;   // the lo copy rides with the value copy
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-  if (N > ATT_NP) {                                           // the 1024 + 1-token models: streaming kernel, both streams of a pair in one workgroup
+  // experiment switch (tools/att_stream_ab.py; never set by the product): the streaming kernel for 257-token sequences too -- 64 queries per workgroup,
+  // 144 VGPRs, K / V in 128-key blocks: more workgroups and waves in flight per CU against a head's K / V re-read by every 64-query chunk
+  static const bool force_stream = getenv("MASKBIT_AMD_ATT_STREAM") && atoi(getenv("MASKBIT_AMD_ATT_STREAM")) != 0;
+  if (N > ATT_NP || (force_stream && (N - 1) % 64 == 0)) {     // the 1024 + 1-token models: streaming kernel, both streams of a pair in one workgroup
     if (out4 && (dh != 64 || (N - 1) % 64)) return -1;
     const int nchunk = ((N + 15) / 16 + 3) / 4;
     dim3 grid(P * heads * nchunk), block(256);

@@ -49,26 +49,35 @@ NOISE_CHUNK_BYTES = 1 << 30       # sample() / generate_uint8() draw and feed th
 OVERLAP_CHUNKS = 8                # ... and in at least this many chunks (+ a one-step head): the host draws chunk k+1 while the device runs chunk k
 
 
-SERIAL_DRAW_ELEMS = 16384      # below ATen's intra-op grain (32 768 elements): a CPU tensor op of this size runs on the calling thread alone
+class _DrawThread:
+    """The host-side draws are a few small CPU tensor ops per step.  With the default intra-op pool of a many-core host (128 OpenMP / MKL threads on the
+    256-CPU MI355X boxes) every such op wakes the pool, whose workers then spin -- and the HIP runtime's own host threads starve: measured on BASELINE
+    configs[1] (16 steps, batch 16) 182-189 ms per run against 118 ms with the draws at one thread (tools/host_draw_ab.py; a `log` over 8 192 values takes
+    2.7 ms there: MKL's vector math threads by itself, so drawing in pieces below ATen's own parallel grain does not help -- round 6 tried).
+    Rounds 3-5 flipped ``torch.set_num_threads`` to 1 around every draw ON THE CALLING THREAD: the caller's own setting changed under it, per draw.  Now the
+    draws run on ONE dedicated worker thread whose OWN intra-op thread count is 1 (OpenMP's and MKL's thread counts are per-thread settings); the caller
+    blocks until its draws are done, so the order in which a run consumes the process-global default CPU generator is the caller's program order.  ATen
+    also remembers the last value ANY thread set as the default for threads created later, so the worker's one-time 1 is followed, once, by the caller
+    re-asserting the count it already has: after that no draw touches any thread setting."""
+    _pool = None
+
+    @classmethod
+    def run(cls, fn):
+        if cls._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            n = torch.get_num_threads()
+            pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="maskbit-draw")
+            # (get first: ATen initialises a thread's count lazily, from the last value set anywhere, on its first intra-op call -- that must not come later)
+            pool.submit(lambda: (torch.get_num_threads(), torch.set_num_threads(1))).result()          # the worker's own setting ...
+            torch.set_num_threads(n)                                # ... and the default new threads inherit is the caller's again (its own count is n already)
+            cls._pool = pool
+        return cls._pool.submit(fn).result()
 
 
-def _draw_conf_serial(gumbel, num_samples: int, n: int, m: int, steps, num_steps: int, randomize_temperature: float) -> torch.Tensor:
-    """The reference's per-step confidence noise (sampling.py:113-117: one ``Gumbel(0, 1).sample([B, n, m])`` from the CPU default generator, scaled by
-    randomize_temperature * (1 - progress)) for `steps`, drawn in row blocks of at most SERIAL_DRAW_ELEMS elements.
-    Why blocks: the draws are a few small CPU tensor ops per step; at batch 64 each is just above ATen's parallel grain, so with the default intra-op pool
-    of a many-core host (128 OpenMP threads on the 256-CPU MI355X boxes) every op wakes the pool, whose workers then spin -- and the HIP runtime's own host
-    threads starve: measured on BASELINE configs[1] (16 steps, batch 16) 345 ms per run against 136 ms of device time.  Rounds 3-5 held the pool at one
-    thread around the draws (``torch.set_num_threads``: visible to every host thread of the process, and inherited by threads created meanwhile); blocks
-    below the grain never enter the pool, so NO thread setting is touched.  Same stream: torch's CPU ``rand`` consumes the generator element by element
-    in order, so consecutive block draws are the one whole draw (tests/test_host_cpu.py compares the bits)."""
-    rows = max(1, SERIAL_DRAW_ELEMS // (n * m))
-    out = torch.empty((len(steps), num_samples, n, m), dtype=torch.float32)
-    for j, i in enumerate(steps):
-        progress = (i + 1) / num_steps
-        for r0 in range(0, num_samples, rows):
-            k = min(rows, num_samples - r0)
-            out[j, r0:r0 + k] = gumbel.sample((k, n, m)) * randomize_temperature * (1 - progress)      # (the reference's order of the two products)
-    return out
+def _draw_conf(gumbel, num_samples: int, n: int, m: int, steps, num_steps: int, randomize_temperature: float) -> torch.Tensor:
+    """The reference's per-step confidence noise (sampling.py:113-117): one ``Gumbel(0, 1).sample([B, n, m])`` from the CPU default generator per step,
+    scaled by randomize_temperature * (1 - progress) (in the reference's order of the two products)."""
+    return torch.stack([gumbel.sample((num_samples, n, m)) * randomize_temperature * (1 - (i + 1) / num_steps) for i in steps])
 
 
 _COPY_STREAMS = {}
@@ -108,7 +117,7 @@ def draw_noise(num_samples: int, n: int, m: int, C_: int, num_steps: int, random
     for i in range(step_end - step_begin):
         exp_noise[i].exponential_(1)
     gumbel = torch.distributions.Gumbel(loc=0.0, scale=1.0)                     # python-float params => CPU draws
-    conf = _draw_conf_serial(gumbel, num_samples, n, m, range(step_begin, step_end), num_steps, randomize_temperature)
+    conf = _DrawThread.run(lambda: _draw_conf(gumbel, num_samples, n, m, range(step_begin, step_end), num_steps, randomize_temperature))
     return exp_noise, _to_device_early(conf, device)
 
 

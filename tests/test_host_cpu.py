@@ -172,27 +172,33 @@ def test_eval_harness_host_pieces():
 
 
 def test_host_noise_draws_leave_the_thread_pool_alone_and_keep_the_stream():
-    """draw_noise draws the confidence noise in row blocks below ATen's intra-op grain (profiles/r03_parity.md section 4: the pool of a many-core host
-    starves the HIP runtime's threads): no thread setting of the process is touched -- not on the calling thread, not transiently, not for threads
-    created meanwhile -- and the CPU stream is the one the reference consumes (one Gumbel draw of [B, n, m] per step from the default generator), at a
-    batch that takes several blocks per step too."""
+    """draw_noise draws the confidence noise on ONE worker thread whose own intra-op thread count is 1 (profiles/r03_parity.md section 4,
+    tools/host_draw_ab.py: the pool of a many-core host starves the HIP runtime's threads): the calling thread's count is never changed, threads that
+    exist or are created while draws run see the process's count, and the CPU stream is the one the reference consumes (one Gumbel draw of [B, n, m] per
+    step from the default generator)."""
     import threading
     import torch
     from maskbit_amd import sampling as S
     from maskbit_amd.sampling import draw_noise
     assert not hasattr(S, "_FewCpuThreads")
     before = torch.get_num_threads()
+    torch.manual_seed(5)
+    _, big = draw_noise(70, 256, 2, 64, 3, 4.5, torch.device("cpu"))          # (the first call also starts the worker)
+    assert S._DrawThread.run(torch.get_num_threads) == 1 and torch.get_num_threads() == before
     seen, stop = [], threading.Event()
 
     def watch():                                                    # another host thread, created and polling while the draws run
         while not stop.is_set():
             seen.append(torch.get_num_threads())
-    torch.manual_seed(5)
     w = threading.Thread(target=watch)
     w.start()
-    _, big = draw_noise(70, 256, 2, 64, 3, 4.5, torch.device("cpu"))          # 70 samples: three row blocks per step
+    for _ in range(3):
+        draw_noise(70, 256, 2, 64, 3, 4.5, torch.device("cpu"))
+    late = []
+    t2 = threading.Thread(target=lambda: late.append(torch.get_num_threads()))
+    t2.start(); t2.join()
     stop.set(); w.join()
-    assert torch.get_num_threads() == before and seen and set(seen) == {before}
+    assert torch.get_num_threads() == before and seen and set(seen) == {before} and late == [before]
     torch.manual_seed(5)
     for i in range(3):
         torch.empty(70 * 512, 64).exponential_(1)
