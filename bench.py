@@ -118,6 +118,8 @@ def measured_traffic(dom: str, mode: str, avg_launch_us=None):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 is not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):
+        return None, "this run is itself being profiled (rocprofv3 environment present): no nested counter passes"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_summary as P
     shape = dom.replace("gemm_", "")

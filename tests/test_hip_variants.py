@@ -62,6 +62,30 @@ def test_variant_full_width_prenorm_bert():
     assert float((out.cpu() - ref).norm() / ref.norm()) < 2e-3
 
 
+def test_variant_full_width_prenorm_guided_precision_modes():
+    """The differential guided forward of the pre-norm generator (LayerNorm pair kernel in front of each sub-layer, raw residual) under the precision knob at
+    full width: 2 = weight-correction mini-tiles, 4 (round 6) = + the activation-lo sets on every trunk GEMM -- each closer to the fp32 oracle in the guided
+    combination; batch invariance of a pair."""
+    cfg = O.GenCfg(bits=12, splits=2, depth=2, prenorm=True)
+    sd = O.make_generator_weights(cfg, seed=79, head_gain=12.0)
+    m = _build(cfg, sd)
+    g = torch.Generator().manual_seed(4)
+    t = torch.randint(0, 65, (3, 256, 2), generator=g); y = torch.tensor([5, 321, 999])
+    drop = torch.cat([torch.zeros(3, dtype=torch.bool), torch.ones(3, dtype=torch.bool)])
+    ref = O.lfq_bert_forward(sd, cfg, torch.cat([t, t]), torch.cat([y, y]), drop)
+    guided = lambda lg: lg[:3] + 6.0 * (lg[:3] - lg[3:])
+    e = {}
+    for prec in (1, 2, 4):
+        m.precision = prec
+        lg = m.forward_cfg(t.to(DEV), y.to(DEV))
+        e[prec] = float((guided(lg.cpu()) - guided(ref)).abs().mean())
+        one = m.forward_cfg(t[2:3].to(DEV), y[2:3].to(DEV))
+        assert torch.equal(one[0], lg[2]) and torch.equal(one[1], lg[5])
+    print(f"pre-norm guided forward, mean |guided logit error| by precision: {e}")
+    assert e[4] < 0.9 * e[2] < 0.9 * e[1]
+    m.precision = -1
+
+
 @pytest.mark.parametrize("name", ["attn_lfq_postnorm", "attn_lfq_prenorm", "attn_bert_postnorm"])
 def test_return_attn_vs_reference_golden(name):
     """return_attn=True: (logits, [head-averaged attention map per layer]) against the maps captured from the reference classes."""

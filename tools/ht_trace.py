@@ -39,10 +39,17 @@ def run(mode):
     st = lambda: torch.cuda.current_stream().cuda_stream
     ptr = lambda t: t.data_ptr() if t is not None else None
     torch.manual_seed(0)
-    P = 64 * 257
-    M = 2 * P
-    for name, epi, N, K in [("qkv", 0, 3072, 1024), ("attn_out", 2, 1024, 1024), ("ffn_up", 1, 4096, 1024), ("ffn_down", 2, 1024, 4096)]:
-        A = torch.randn(M, K, device=dev).half(); A[P:] *= 0.01
+    # HT_PLAIN=n (round 6): PLAIN sequence tiles over n sequences instead of pair tiles over 64 pairs -- with HT_MINI=1 and MASKBIT_AMD_COL_SPLIT=1 / 2 / 4 the
+    # fp32 + residual GEMMs then walk whole / half- / quarter-column tiles (256 x 256 / 128 / 64 outputs per tile): what a K-tile costs by tile WIDTH
+    plain = int(os.environ.get("HT_PLAIN", "0"))
+    P = (plain or 64) * 257
+    M = P if plain else 2 * P
+    shapes = [("qkv", 0, 3072, 1024), ("attn_out", 2, 1024, 1024), ("ffn_up", 1, 4096, 1024), ("ffn_down", 2, 1024, 4096)]
+    if plain:
+        shapes = [s_ for s_ in shapes if s_[1] == 2]
+    for name, epi, N, K in shapes:
+        A = torch.randn(M, K, device=dev).half()
+        if not plain: A[P:] *= 0.01
         W = (torch.randn(N, K, device=dev) * 0.05).half()
         bias = torch.randn(N, device=dev) * 0.1
         res = torch.randn(M, N, device=dev) if epi == 2 else None
@@ -57,7 +64,7 @@ def run(mode):
             _lib.check(lib.mb_w4_from_f32(W.float().data_ptr(), N, K, w4.data_ptr(), ws.data_ptr(), st()))
             sets += [x4, xsb, w4, ws]
         arr = (C.c_void_p * max(1, len(sets)))(*[t.data_ptr() for t in sets])
-        fn = lambda: _lib.check(lib.mb_gemm_mini(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), None, None, P, 1, N, K, nlo, arr, st()))
+        fn = lambda: _lib.check(lib.mb_gemm_mini(epi, A.data_ptr(), W.data_ptr(), bias.data_ptr(), ptr(res), ptr(o32), ptr(o16), None, None, P, 0 if plain else 1, N, K, nlo, arr, st()))
         G = int(os.environ.get("MASKBIT_AMD_HT_GRID", 256))
         trace = torch.zeros(256, 8, 8, dtype=torch.int64, device=dev)
         for _ in range(3): fn()
@@ -66,6 +73,7 @@ def run(mode):
         fn(); torch.cuda.synchronize()
         assert lib.mb_debug_ht_trace(None) == 0
         t = trace.cpu().numpy().astype(np.float64)[:G] * 0.01         # us
+        t = t[t[:, 0, 0] > 0]                                           # (a grid smaller than 256 workgroups leaves the other rows unstamped)
         ntile = int((t[0, :, 0] > 0).sum())
         t0 = t[:, 0, 0].min()
         print(f"== {name}: N={N} K={K}, {ntile} tiles per workgroup; kernel span {t[:, :ntile, 5 if mode == 2 else 4].max() - t0:.1f} us", flush=True)

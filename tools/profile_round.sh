@@ -1,17 +1,17 @@
 #!/bin/bash
-# rocprofv3 evidence (rounds 4-5) of the product default (guided forward with the weight-correction mini-tiles) on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh <tag>
+# rocprofv3 evidence (rounds 4-6) of the product default (guided forward with the weight-correction mini-tiles) on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh <tag>
 #   -> gpurun_out/prof_<tag>/{kt, pmc/<gemm>.<counter>, pmc/dec.<counter>}
 # Kernel-trace statistics of the default bench workload, then separate --pmc passes (never combined with other trace domains) over the
 # trunk GEMM shapes as the guided forward runs them (CFG pair tiles) and over the decoder.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 export PAIR_ONE_MINI=1
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-modes > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-modes --no-traffic > $OUT/bench_under_rocprof.log 2>&1
 for shape in qkv attn_out ffn_up ffn_down; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc/$shape.$ctr -o run -- python $ROOT/tools/pair_one.py $shape 3 > $OUT/pmc_$shape.$ctr.log 2>&1
