@@ -310,6 +310,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();
 #define MB_MMA(AH, BH) MB_MMA_DO(AH, BH) MB_MMA_END
+  // experiment (round 6, -DMB_MERGE_PHASES): FOUR barrier crossings per K-tile instead of eight -- the barrier pairs between phases 0 / 1 and between phases
+  // 2 / 3 left out, so a wave group's slots are [L0] [M0 L1 M1] [L2] [M2 L3 M3]; the partner group stays one barrier behind
+#ifdef MB_MERGE_PHASES
+#define MB_MID_END __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0);
+#define MB_MID_SYNC() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1);
+#else
+#define MB_MID_END MB_MMA_END
+#define MB_MID_SYNC() MB_SYNC_L()
+#endif
   // one mini-tile: 4 m-tiles of accumulator half AH x 4 n-tiles, one scaled MFMA of K = 128 each; op_sel picks the n-tile's / m-tile's scale byte
 #define MB_MINI_ONE(AH, N, I)                                                                       \
   acc[N][(AH) * MH + (I)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                        \
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       if (SEQ && wm == 0 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
       MB_SYNC_L() \
       if (SEQ && wm == 0 && cls_on) { _Pragma("unroll") for (int n = 0; n < (QN ? 1 : 2); ++n) acce[n] = mma_tile(acce[n], wb[0][n], xe); } \
-      MB_MMA(0, 0) \
+      MB_MMA_DO(0, 0) MB_MID_END \
       /* ---- phase 1: (A0, B1) [+ class row x B1 for wave row 1]; refill A1 of the other parity with K-tile t+1 */ \
       if constexpr (!HN) { MB_LOAD_B(1) } \
       if (!HN && SEQ && wm == 1 && cls_on) { xe = frag_set(xe, *(const h16x8*)(par + xo[0]), 0); xe = frag_set(xe, *(const h16x8*)(par + xo[1]), 1); } \
@@ -418,14 +427,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
       const int mini_j = mini_every ? t : (t >> 1); \
       if (MINI && mini_issue) { mini_scale_issue(cur, mini_j); MB_MINI_X_DMA(mini_dma_a(cur, mini_j);) } \
       if (n1) dma_a(cur, t + 1, 1); \
-      MB_SYNC_L() \
+      MB_MID_SYNC() \
       if (!HN && SEQ && wm == 1 && cls_on) { _Pragma("unroll") for (int n = 0; n < 2; ++n) acce[n] = mma_tile(acce[n], wb[1][n], xe); } \
       if constexpr (!HN) { MB_MMA_DO(0, 1) } MB_MMA_END \
       /* ---- phase 2: (A1, B1); refill A0 of this parity with K-tile t+2 */ \
       MB_LOAD_A(1) \
       if (MINI && mini_issue) { MB_MINI_X_DMA(mini_dma_b(cur, mini_j);) } \
       if (n2) dma_a(cur, t + 2, 0); \
-      MB_SYNC_L() if (!HN) { MB_MMA_DO(1, 1) } MB_MMA_END \
+      MB_SYNC_L() if (!HN) { MB_MMA_DO(1, 1) } MB_MID_END \
       /* ---- phase 3: (A1, B0), B0 still in registers: no LDS reads; refill B1, X and B0 of this parity with K-tile t+2; K-tile t+1 must have landed. */ \
       /* In K-tile 0 nothing is waited for: K-tile 1 arrived with the prologue, and the previous tile's output */ \
       /* stores stay in flight until the wait of K-tile 1. */ \
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ht_kernel(GemmArgs a, int tiles_m
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
       } \
-      MB_SYNC_L() MB_MMA_DO(1, 0) MB_MMA_END \
+      MB_MID_SYNC() MB_MMA_DO(1, 0) MB_MMA_END \
       /* ---- phase 4 (MINI): the mini-tile that landed under this (or the previous) K-tile's wait x the accumulators of its 128 token rows */ \
       if constexpr (MINI) { \
         if (MB_MINI_PHASE_ON && (mini_every || (t & 1))) { \

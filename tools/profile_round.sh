@@ -11,7 +11,23 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 export PAIR_ONE_MINI=1
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-modes --no-traffic > $OUT/bench_under_rocprof.log 2>&1
+# (round 6: the bench keeps its own HIP-event kernel timing on under the tracer, so that ONE run carries both figures of the dominant kernel: the line's
+#  roofline.avg_launch_us and the trace's average duration -- boxes sustain different clocks, two runs on two boxes do not compare)
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-modes --no-traffic > $OUT/bench_under_rocprof.log 2>&1
+if [ -n "${PROFILE_ONLY_KT:-}" ]; then
+  cd $ROOT
+  DB=$(find $OUT/kt -name "*.db" | head -1)
+  python tools/rocprof_summary.py $DB $OUT/kernel_trace_stats.md > /dev/null
+  grep '"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
+  python - <<PY
+import json
+d = json.load(open("$OUT/bench_under_rocprof.json"))
+r = d["roofline"]
+print("bench line under the tracer:", round(d["value"], 2), "images/s;", r["kernel"], "avg_launch_us (HIP events, every 8th forward)", round(r["avg_launch_us"], 1), "clock", d["telemetry"].get("effective_clock_mhz"))
+PY
+  head -5 $OUT/kernel_trace_stats.md | cut -c1-160
+  exit 0
+fi
 for shape in qkv attn_out ffn_up ffn_down; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc/$shape.$ctr -o run -- python $ROOT/tools/pair_one.py $shape 3 > $OUT/pmc_$shape.$ctr.log 2>&1
