@@ -49,11 +49,11 @@ typedef struct {
    *   MB_PREC_DIFF  1  classifier-free guidance in DIFFERENTIAL form: the unconditional stream's GEMM operands are fp16(x_u - x_c), so the rounding of
    *                    x_c cancels in (c - u); plain forwards carry the LayerNorm outputs as fp16 hi + lo pairs (~1.0e-3: AT the bound).
    *   MB_PREC_WCORR 2  + MX-fp4 mini-tile correction of the fp16 rounding of all four trunk WEIGHTS (gemm_ht.hip XP = 6), guided and plain (5.5e-4).
-   *   MB_PREC_ALO   3  + the same kind of pass for the rounding of the conditional LayerNorm outputs in FFN-up of the guided forward (what the
-   *                    7-bit-per-group codebooks need: 4.9e-4 over four 14-bit / 256-step runs, every run <= 8.3e-4; without it one run is at 1.05e-3).
-   *   MB_PREC_ALO_ALL 4 + that pass on ALL FOUR trunk GEMMs of EVERY layer of the guided forward -- the lo halves of the LayerNorm outputs (QKV, FFN-up), of
-   *                    the attention outputs (out-proj) and of the FFN hiddens (FFN-down) -- and the zero-scale steps of a guided run through the
-   *                    guided forward as well: what heavy-tailed ("trained-like") weights with massive-activation channels need (round 6).
+   *   MB_PREC_ALO   3  + the same kind of pass for the fp16 rounding of the ACTIVATIONS of the guided forward's conditional stream (e2m1 of their lo halves
+   *                    against e2m1 of the fp16 weight): attention outputs in out-proj and LayerNorm outputs in FFN-up, every layer (what the 7-bit-per-group
+   *                    codebooks need: 3.8e-4 over four 14-bit / 256-step runs, every run <= 5.5e-4; without it one run is at 1.0e-3; rounds 4-5: FFN-up only).
+   *   MB_PREC_ALO_ALL 4 + the FFN hiddens in FFN-down (the QKV set buys nothing in any measured configuration), and the zero-scale steps of a guided run
+   *                    through the guided forward as well: what heavy-tailed ("trained-like") weights with massive-activation channels need (round 6).
    * Modes 1-4 need seq in {256, 1024}, hidden in {768, 1024}, mlp % 256 == 0 (2-4 also hidden / heads = 64); other shapes run mode 0 with hi + lo
    * LayerNorm outputs.  The host's default is 2, 3 from 7 bits per group on, 4 for heavy-tailed checkpoints (LFQBert.resolved_precision). */
   int precision;

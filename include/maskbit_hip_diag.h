@@ -67,6 +67,9 @@ int mb_attention_pair_f4(const void* qkv, void* out_h16, void* out4, void* out4_
  * forward) and on the GEMMs of gemm_mask (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down; default 15; both forwards).  No subset keeps the default's
  * parity margin (profiles/r04_gemm_minitiles.md section 4): the product never calls this. */
 int mb_gen_set_wcorr(mb_gen* g, int from_layer, int gemm_mask);
+/* The same kind of study knob for the ACTIVATION-LO sets of precision >= 3: trunk layers >= from_layer, GEMMs of gemm_mask (same bits).  A handle is created
+ * with the operands of its precision's own coverage (3: FFN-up, layers >= depth / 2; 4: every GEMM of every layer); the knob can only narrow that. */
+int mb_gen_set_alo(mb_gen* g, int from_layer, int gemm_mask);
 /* Persistent kernels launch one workgroup per CU.  On a stream created with a CU mask (hipExtStreamCreateWithCUMask) fewer CUs serve the launch:
  * n = the CUs the following launches should size their grids for, 0 = the device's count (default).  Process-wide, not thread-safe. */
 int mb_set_cu_count(int n);

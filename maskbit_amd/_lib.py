@@ -39,6 +39,7 @@ SIGNATURES = {
     "mb_gen_destroy": (None, [C.c_void_p]),
     "mb_gen_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     "mb_gen_set_wcorr": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mb_gen_set_alo": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mb_gen_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_gen_forward_cfg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_gen_forward_attn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

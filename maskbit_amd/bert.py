@@ -24,8 +24,8 @@ from .base_model import BaseModel, ParamSpec
 #   PREC_FP16  0  single fp16 operands, the guided forward as independent streams (1.4e-3 token mismatch on configs[2]: a baseline, not a product mode)
 #   PREC_DIFF  1  classifier-free guidance in differential form; plain forwards with the LayerNorm outputs as fp16 hi + lo pairs (~1.0e-3: AT the bound)
 #   PREC_WCORR 2  + MX-fp4 weight-correction mini-tiles on every trunk GEMM, guided and plain (5.5e-4 over three reference runs of configs[2]; 5.3e-4 on configs[1])
-#   PREC_ALO   3  + activation-lo mini-tiles for the LayerNorm outputs feeding FFN-up in the guided forward (4.9e-4 over four 14-bit / 256-step runs)
-#   PREC_ALO_ALL 4 + activation-lo mini-tiles on all four trunk GEMMs of every layer (LayerNorm outputs, attention outputs, FFN hiddens): heavy-tailed checkpoints
+#   PREC_ALO   3  + activation-lo mini-tiles in out-proj (attention outputs) and FFN-up (LayerNorm outputs) of every layer of the guided forward (3.8e-4 over four 14-bit / 256-step runs)
+#   PREC_ALO_ALL 4 + activation-lo mini-tiles in FFN-down (FFN hiddens) as well, zero-scale steps through the guided forward: heavy-tailed checkpoints
 # -1 = auto: 2, or 3 from 7 bits per group on, or 4 when the checkpoint's statistics ask for it (weight_statistics()), degraded to what the shape allows
 # (resolved_precision()).
 PREC_AUTO, PREC_FP16, PREC_DIFF, PREC_WCORR, PREC_ALO, PREC_ALO_ALL = -1, 0, 1, 2, 3, 4
@@ -109,6 +109,9 @@ class LFQBert(BaseModel):
         self.wcorr_from = int(os.environ.get("MASKBIT_AMD_WFROM", "0"))
         # ... and which GEMMs of a layer carry them: 1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down (15 = all, the default)
         self.wcorr_mask = int(os.environ.get("MASKBIT_AMD_WMASK", str(DEFAULT_WCORR_MASK)))
+        # ... and (mb_gen_set_alo) which GEMMs / from which layer on carry the activation-lo set of precision >= 3; None = the precision's own coverage
+        self.alo_mask = int(os.environ["MASKBIT_AMD_ALO_MASK"]) if "MASKBIT_AMD_ALO_MASK" in os.environ else None
+        self.alo_from = int(os.environ.get("MASKBIT_AMD_ALO_FROM", "0"))
         self._engine_split = None
         self._wstats = None               # (weight signature, statistics) of the last weight_statistics() call
         if not self.embed_tables:
@@ -128,6 +131,7 @@ class LFQBert(BaseModel):
         h = C.c_void_p()
         _lib.check(_lib.load().mb_gen_create(C.byref(cfg), capacity, C.byref(h)), "mb_gen_create")
         self._engine_wfrom = None
+        self._engine_alo = None
         return h
 
     @torch.no_grad()
@@ -196,6 +200,9 @@ class LFQBert(BaseModel):
         if getattr(self, "_engine_wfrom", None) != wf:
             _lib.check(_lib.load().mb_gen_set_wcorr(h, wf[0], wf[1]), "mb_gen_set_wcorr")
             self._engine_wfrom = wf
+        if self.alo_mask is not None and getattr(self, "_engine_alo", None) != (int(self.alo_from), int(self.alo_mask)):
+            _lib.check(_lib.load().mb_gen_set_alo(h, int(self.alo_from), int(self.alo_mask) & 15), "mb_gen_set_alo")
+            self._engine_alo = (int(self.alo_from), int(self.alo_mask))
         return h
 
     def saturation_count(self, reset: bool = True) -> int:

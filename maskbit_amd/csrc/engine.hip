@@ -137,6 +137,13 @@ struct mb_gen {
   int loop_B = 0, loop_steps = 0, loop_guided = 0, loop_next = -1;
   int wcorr_from = 0;                                   // precision >= 2: first trunk layer that carries the correction passes (mb_gen_set_wcorr)
   int wcorr_mask = 15;                                  // ... and which GEMMs of a layer: 1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down
+  // precision >= 3: which GEMMs (same bits) of which layers (>= alo_from) carry the activation-lo set.  Coverage measured on the reference's own runs in round 6
+  // (profiles/r06_coverage.md: four 14-bit / 256-step runs, four 12-bit runs, three trained-like runs; mismatches / guided-forward time of 64 pairs):
+  //   none 595 / 263 / 271 at 29.9 ms;  FFN-up of layers >= depth / 2 (round 5's precision 3) 506 / 222 / 276 at 30.5;  out-proj + FFN-up 384 / 186 / 219 at 31.6;
+  //   out-proj + FFN-up + FFN-down 241 / 115 / 203 at 33.4;  all four 228 / 116 / 200 at 34.3 -- the QKV set buys nothing (as round 5 found for precision 3).
+  // precision 3 = out-proj + FFN-up of every layer; precision 4 = + FFN-down.  mb_gen_set_alo (study knob) selects within what the handle was created with
+  // (precision 4 builds the QKV operands too, for such studies).
+  int alo_mask = 0, alo_from = 0, alo_mask_built = 0, alo_from_built = 0;
   const int64_t* cfg_labels_ready = nullptr;            // gen_forward_cfg: lab_cfg / drop_cfg already hold [labels | labels] / [0 | 1] for this many pairs
   int cfg_ready_B = 0;
   int64_t *tok_a = nullptr, *tok_b = nullptr, *tok_cfg = nullptr, *lab_cfg = nullptr, *pred = nullptr, *codes = nullptr;
@@ -286,24 +293,21 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   // the cost and next to nothing on the 14-bit one (and per GEMM type no subset is a cheaper "precise": section 5 there) -- a study knob
   // (mb_gen_set_wcorr, include/maskbit_hip_diag.h), not the default
   const int wfrom = g->wcorr_from;
-  // precision 3: + activation-lo mini-tiles of the LayerNorm outputs in FFN-UP of the layers >= depth / 2.  Round 4 ran the set in QKV and FFN-up of every
-  // layer.  Over FOUR 14-bit / 256-step reference runs (1 002 744 positions; profiles/r05_coverage.md, raw/r05/alo_mask.log, alo_layers.log): both GEMMs,
-  // all layers 496 mismatches; FFN-up alone 491-493; QKV alone 555; neither 625 -- the QKV set buys nothing and cost 34 us per layer.  FFN-up set by
-  // layer range: [0, 24) 493, [12, 24) 531, [18, 24) 560, [6, 18) 579, [0, 12) 612, [0, 6) 627 -- the late layers carry the gain: the second half
-  // keeps 70 % of it (5.3e-4 pooled, the worst single run 8.7e-4 against 8.3e-4) for half of the 84 us per layer.
-  // precision 4 (round 6; what heavy-tailed checkpoints need, DESIGN.md "Precision"): the activation-lo set on ALL FOUR trunk GEMMs of EVERY layer -- the
-  // lo halves of the LayerNorm outputs (QKV, FFN-up), of the attention outputs (out-proj) and of the FFN hiddens (FFN-down), each as e2m1 with
-  // per-(row, 64 columns) scales against e2m1 of the fp16 weight.  With exact weights the fp16 rounding of those three operands alone costs 7e-4 of
+  // The activation-lo sets of precision >= 3.  Rounds 4-5 knew the LayerNorm outputs' set only: over FOUR 14-bit / 256-step reference runs (1 002 744
+  // positions; profiles/r05_coverage.md) QKV + FFN-up in all layers 496 mismatches, FFN-up alone 491-493, QKV alone 555, neither 625 -- the QKV set buys
+  // nothing --, and round 5 ran it in FFN-up of the layers >= depth / 2 (531).
+  // Round 6 (DESIGN.md "Precision"): the activation-lo set beyond the LayerNorm outputs -- the lo halves of the attention outputs (out-proj) and of the FFN
+  // hiddens (FFN-down), each as e2m1 with per-(row, 64 columns) scales against e2m1 of the fp16 weight, in every layer: precision 3 = out-proj + FFN-up,
+  // precision 4 (what heavy-tailed checkpoints need) = + FFN-down.  With exact weights the fp16 rounding of those three operands alone costs 7e-4 of
   // token mismatch on the early steps of a trained-like run (a third each); emulated on that run (tests/diag/error_budget.py EB_STUDY=r6): rms error
   // of the sampled logits' top-2 gap 0.0062 -> 0.0031 with the three sets (and the per-(row, 128 columns) weight-error scales).
-  const bool alo_all = wmode && c.precision >= 4;
-  const bool alo = wmode && c.precision == 3;
-  auto alo_layer = [&](int l) { return alo_all || (alo && 2 * l + 1 >= c.depth); };
+  // (which GEMMs of which layers: mb_gen::alo_mask / alo_from -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down)
+  auto alo_on = [&](int gemm, int l) { return wmode && c.precision >= 3 && l >= wfrom && l >= g->alo_from && ((g->alo_mask >> gemm) & 1) && ((g->wcorr_mask >> gemm) & 1); };
   auto f4_for = [&](int consumer_layer, bool feeds_ffn = false) {   // what the producer of layer `consumer_layer`'s LayerNorm operand also writes
     Fp4Rows f;
     if (wmode && consumer_layer >= wfrom && (g->wcorr_mask & 5)) {
       f.x4 = g->x4; f.x4s = g->x4s; f.nseq = B; f.seq_rows = N;
-      if (alo_all || (feeds_ffn && alo_layer(consumer_layer))) { f.xl4 = g->xl4; f.xl4s = g->xl4s; }   // (the lo halves' e2m1 copy: precision 3 only the LayerNorm in front of such an FFN-up)
+      if (alo_on(feeds_ffn ? 2 : 0, consumer_layer)) { f.xl4 = g->xl4; f.xl4s = g->xl4s; }   // (the lo halves' e2m1 copy: only the LayerNorm in front of a GEMM that carries the set)
     }
     return f;
   };
@@ -342,16 +346,16 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
   for (int l = 0; l < c.depth; ++l) {
     const mb_gen::Layer& L = g->layers[l];
     const bool wl = wmode && l >= wfrom;
-    const int xlo_mode = wl ? (alo_layer(l) ? 2 : 1) : 0;
+    const int xlo_mode = wl ? (alo_on(2, l) ? 2 : 1) : 0;
     { ProfScope p("gemm_qkv", s, true);
-      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wl ? (alo_all ? 2 : 1) : 0, g->x4, g->x4s, g->xl4, g->xl4s);
+      GemmArgs ga = pgemm(EPI_H16, g->x_h16, L.wqkv, L.bqkv, g->qkv, nullptr, 3 * d, d, 4 * l, wl ? (alo_on(0, l) ? 2 : 1) : 0, g->x4, g->x4s, g->xl4, g->xl4s);
       rc |= gemm_tn(s, EPI_H16, ga, 257); }
     const bool wo4 = wl && (g->wcorr_mask & 2), wh4 = wl && (g->wcorr_mask & 8);
-    const bool lo_o = wo4 && alo_all, lo_h = wh4 && alo_all;      // precision 4: the producers also write the lo halves' e2m1 copies
+    const bool lo_o = wo4 && alo_on(1, l), lo_h = wh4 && alo_on(3, l);      // the producers also write the lo halves' e2m1 copies for a consumer that carries the set
     { ProfScope p("attention", s, true); rc |= attention_pair(s, g->qkv, g->att, B, N, d, c.heads, wo4 ? g->att4 : nullptr, wo4 ? g->att4s : nullptr,
                                                               lo_o ? g->attl4 : nullptr, lo_o ? g->attl4s : nullptr); }
     { ProfScope p("gemm_attn_out", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? (alo_all ? 2 : 1) : 0, g->att4, g->att4s, g->attl4, g->attl4s);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->att, L.wo, L.bo, nullptr, g->y_f32, d, d, 4 * l + 1, wl ? (alo_on(1, l) ? 2 : 1) : 0, g->att4, g->att4s, g->attl4, g->attl4s);
       if (l > 0 && !c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = g->layers[l - 1].ln2g; ga.ln_b = g->layers[l - 1].ln2b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     // post-norm: LayerNorm 1 follows the attention block; pre-norm: LayerNorm 2 precedes the FFN (same place in the launch order, other parameters;
@@ -364,7 +368,7 @@ int gen_forward_pair_impl(mb_gen* g, const int64_t* tokens, const int64_t* label
       if (lo_h) { ga.out4l = g->hl4; ga.out4l_scale = g->hl4s; }
       rc |= gemm_tn(s, EPI_GELU_H16, ga, 257); }
     { ProfScope p("gemm_ffn_down", s, true);
-      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? (alo_all ? 2 : 1) : 0, g->h4, g->h4s, g->hl4, g->hl4s);
+      GemmArgs ga = pgemm(EPI_RES_F32, g->h, L.w2, L.b2, nullptr, g->y_f32, d, f, 4 * l + 3, wl ? (alo_on(3, l) ? 2 : 1) : 0, g->h4, g->h4s, g->hl4, g->hl4s);
       if (!c.prenorm) { ga.ln_stats = g->ln_stats; ga.ln_g = L.ln1g; ga.ln_b = L.ln1b; }
       rc |= gemm_tn(s, EPI_RES_F32, ga, 257); }
     { ProfScope p("layernorm", s, true);
@@ -634,6 +638,8 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
   g->mini_ok = c.precision >= 2 && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && c.hidden / c.heads == 64;   // (FFN-up's N = mlp: whole 256-column tiles)
   // differential CFG forward: 257-token sequences (pair tiles = 2 x 128 tokens + the class pair), vector LayerNorm widths, plain fp16 operands
   // (round 5: also the 1024 + 1-token models of 512 x 512 images -- a pair tile is 128 tokens of a sequence pair whatever the sequence length)
+  if (c.precision == 3) { g->alo_mask = g->alo_mask_built = 6; }              // out-proj + FFN-up, every layer
+  if (c.precision >= 4) { g->alo_mask = 14; g->alo_mask_built = 15; }         // + FFN-down (the QKV operands exist for coverage studies only)
   g->pair_ok = c.precision >= 1 && (c.seq == 256 || c.seq == 1024) && (c.hidden == 768 || c.hidden == 1024) && c.mlp % 256 == 0 && g->chunk_seqs >= 2 &&
                (c.precision == 1 || g->mini_ok);
   if (g->mini_ok) {
@@ -642,14 +648,14 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
     rc |= galloc(g, &g->x4, M * 2 * d); rc |= galloc(g, &g->x4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->att4, M * 2 * d); rc |= galloc(g, &g->att4s, (d / 64) * ns + 256);
     rc |= galloc(g, &g->h4, M * 2 * f); rc |= galloc(g, &g->h4s, (f / 64) * ns + 256);
-    if (c.precision >= 3) { rc |= galloc(g, &g->xl4, M * 2 * d); rc |= galloc(g, &g->xl4s, (d / 64) * ns + 256); }
-    if (c.precision >= 4) {
+    if (g->alo_mask_built & 5) { rc |= galloc(g, &g->xl4, M * 2 * d); rc |= galloc(g, &g->xl4s, (d / 64) * ns + 256); }
+    if (g->alo_mask_built & 2) {
       rc |= galloc(g, &g->attl4, M * 2 * d); rc |= galloc(g, &g->attl4s, (d / 64) * ns + 256);
+      if (!rc) { (void)hipMemset(g->attl4, 0, M * 2 * d); (void)hipMemset(g->attl4s, 0, (d / 64) * ns + 256); }
+    }
+    if (g->alo_mask_built & 8) {
       rc |= galloc(g, &g->hl4, M * 2 * f); rc |= galloc(g, &g->hl4s, (f / 64) * ns + 256);
-      if (!rc) {
-        (void)hipMemset(g->attl4, 0, M * 2 * d); (void)hipMemset(g->attl4s, 0, (d / 64) * ns + 256);
-        (void)hipMemset(g->hl4, 0, M * 2 * f); (void)hipMemset(g->hl4s, 0, (f / 64) * ns + 256);
-      }
+      if (!rc) { (void)hipMemset(g->hl4, 0, M * 2 * f); (void)hipMemset(g->hl4s, 0, (f / 64) * ns + 256); }
     }
     if (!rc) {
       (void)hipMemset(g->x4, 0, M * 2 * d); (void)hipMemset(g->x4s, 0, (d / 64) * ns + 256);
@@ -665,14 +671,10 @@ int mb_gen_create(const mb_gen_cfg* cfg, int max_seqs, mb_gen** out) {
       rc |= galloc(g, &g->w4lo[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4los[4 * l + 1], d * d / 128);
       rc |= galloc(g, &g->w4lo[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4los[4 * l + 2], f * d / 128);
       rc |= galloc(g, &g->w4lo[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4los[4 * l + 3], d * f / 128);
-      if ((c.precision == 3 && 2 * l + 1 >= c.depth) || c.precision >= 4) {   // (precision 3: the activation-lo set runs in FFN-up of the late layers: gen_forward_pair_impl)
-        rc |= galloc(g, &g->w4[4 * l + 2], f * d / 2); rc |= galloc(g, &g->w4s[4 * l + 2], f * d / 128);
-      }
-      if (c.precision >= 4) {                                     // ... precision 4: on all four GEMMs of every layer
-        rc |= galloc(g, &g->w4[4 * l], 3 * d * d / 2); rc |= galloc(g, &g->w4s[4 * l], 3 * d * d / 128);
-        rc |= galloc(g, &g->w4[4 * l + 1], d * d / 2); rc |= galloc(g, &g->w4s[4 * l + 1], d * d / 128);
-        rc |= galloc(g, &g->w4[4 * l + 3], d * f / 2); rc |= galloc(g, &g->w4s[4 * l + 3], d * f / 128);
-      }
+      // e2m1 of the fp16 weight VALUES for the GEMMs that carry an activation-lo set (precision >= 3)
+      const size_t wn[4] = {3 * d * d, d * d, f * d, d * f};
+      for (int q = 0; q < 4; ++q)
+        if ((g->alo_mask_built >> q) & 1) { rc |= galloc(g, &g->w4[4 * l + q], wn[q] / 2); rc |= galloc(g, &g->w4s[4 * l + q], wn[q] / 128); }
     }
   }
   const size_t P = (size_t)c.seq * c.splits, B = max_seqs;
@@ -774,6 +776,14 @@ int mb_gen_load(mb_gen* g, const char* name, const float* data, const int64_t* s
   }
   else HIP_TRY(hipMemcpyAsync(dst_f, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   g->loaded++;
+  return 0;
+}
+
+int mb_gen_set_alo(mb_gen* g, int from_layer, int gemm_mask) {
+  if (!g || from_layer < 0 || from_layer > g->c.depth || gemm_mask < 0 || gemm_mask > 15) return fail(-1, "mb_gen_set_alo: layer outside [0, depth] or mask outside [0, 15]");
+  if ((gemm_mask & ~g->alo_mask_built) || (gemm_mask && from_layer < g->alo_from_built))
+    return fail(-1, "mb_gen_set_alo: the handle was created (precision %d) with the activation-lo operands of GEMM mask %d from layer %d on only", g->c.precision, g->alo_mask_built, g->alo_from_built);
+  g->alo_mask = gemm_mask; g->alo_from = from_layer;
   return 0;
 }
 

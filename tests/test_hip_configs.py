@@ -117,25 +117,24 @@ def test_baseline_config5_14bit_256steps_vs_reference_runs():
     """BASELINE configs[4]'s generator and sampler as named -- 14-bit (C = 128 per group), 256 steps, CFG 5.8 cosine (configs/generator/
     maskbit_generator_14bit_256steps.yaml:38-44) -- against FOUR 256-step runs of the real reference (B = 2, 2, 4 and 4: 1 002 744 sampled positions).
     MEASURED: the differential form alone misses 1e-3 here (1.4e-3; single fp16: 2.0e-3); with the weight-correction mini-tiles and hi/lo head
-    weights (precision 2) the first run measures 6.6e-4; the product default at 7 bits per group (precision 3: + the activation-lo mini-tiles of the
-    LayerNorm outputs, since round 5 in FFN-up only: the QKV set measured no gain over the four runs) 4.8e-4 / 8.3e-4 / 4.4e-4 / 3.7e-4 = 4.9e-4
-    over all; without the set 6.2e-4 over all and 1.05e-3 on the second run.  Asserted without allowance: <= 1e-3 on each run, <= 6e-4 over all."""
+    weights (precision 2) 5.9e-4 over the four runs with one run AT 1.0e-3; the product default at 7 bits per group (precision 3: + the activation-lo
+    mini-tiles -- since round 6 in out-proj and FFN-up of every layer, chosen on these runs: profiles/r06_coverage.md) 3.8e-4 over all, every run <= 5.5e-4
+    (rounds 4-5, FFN-up only: 5.1e-4 / 8.7e-4).  Asserted without allowance: <= 7e-4 on each run, <= 5e-4 over all."""
     from maskbit_amd import parity_replay as R
     r = _vs_reference_run(R.RUN_CFG5, [("product default", -1), ("weight correction + activation-lo pass", 3),
                                        ("weight correction alone", 2), ("differential operands only", 1), ("single fp16", 0)])
     bad, tot = r["differential operands only"]
     assert tot == 167124 and bad / tot <= 2e-3
     assert r["product default"] == r["weight correction + activation-lo pass"]          # what the default resolves to at 7 bits per group
-    for tag in ("product default", "weight correction alone"):
-        bad, tot = r[tag]
-        assert bad / tot <= 1e-3, tag
+    assert r["weight correction alone"][0] / r["weight correction alone"][1] <= 1e-3
     tb, tt = r["product default"]
+    assert tb / tt <= 7e-4
     for name in (R.RUN_CFG5_S2, R.RUN_CFG5_S3, R.RUN_CFG5_S4):
         bad, tot = _vs_reference_run(name, [("product default", -1)])["product default"]
-        assert bad / tot <= 1e-3, name
+        assert bad / tot <= 7e-4, name
         tb += bad; tt += tot
     print(f"configs[4], four reference runs, product default: {tb}/{tt} = {tb / tt:.2e}")
-    assert tt == 1002744 and tb / tt <= 6e-4
+    assert tt == 1002744 and tb / tt <= 5e-4
 
 
 @pytest.mark.timeout(900)
@@ -363,6 +362,6 @@ def test_held_out_reference_runs_default_precision():
         modes = [("product default", -1)] + ([] if name == R.RUN_CFG5_S5 else [("differential / hi + lo operands alone (precision 1)", 1)])   # (256 steps: the default only; precision 1 measured 6.9e-4)
         r = _vs_reference_run(name, modes)
         bad, tot = r["product default"]
-        assert tot >= 87040 and bad / tot <= (1e-3 if name == R.RUN_CFG5_S5 else 7e-4), (name, bad, tot)      # (configs[4]: the per-run bound of its other runs)
+        assert tot >= 87040 and bad / tot <= 7e-4, (name, bad, tot)
         if len(modes) > 1:
             assert bad < r["differential / hi + lo operands alone (precision 1)"][0]

@@ -73,14 +73,14 @@ def test_guided_forward_full_size_vs_oracle():
     assert torch.equal(m.forward_cfg(t.to(DEV), y.to(DEV)), plain)
     e_plain = float((guided(plain.cpu()) - guided(ref)).abs().mean())
     e_by_mode = {}
-    for pair in (1, 2, 3, 4):                                                       # differential form; + weight-correction mini-tiles; + activation-lo mini-tiles (FFN-up, late layers; 4: every GEMM of every layer)
+    for pair in (1, 2, 3, 4):                                                       # differential form; + weight-correction mini-tiles; + activation-lo mini-tiles (3: out-proj + FFN-up; 4: + FFN-down)
         m.precision = pair
         lg = m.forward_cfg(t.to(DEV), y.to(DEV)).cpu()
         rel = float((lg - ref).norm() / ref.norm())
         e_by_mode[pair] = float((guided(lg) - guided(ref)).abs().mean())
         print(f"precision = {pair}: rel-Frobenius logit error {rel:.2e}; mean |guided logit error| {e_by_mode[pair]:.4f} (plain fp16 forward: {e_plain:.4f})")
         assert rel < 2e-3 and e_by_mode[pair] < 0.6 * e_plain
-    assert e_by_mode[2] < 0.8 * e_by_mode[1] and e_by_mode[3] < e_by_mode[2] and e_by_mode[4] < 0.9 * e_by_mode[3]
+    assert e_by_mode[2] < 0.8 * e_by_mode[1] and e_by_mode[3] < 0.9 * e_by_mode[2] and e_by_mode[4] < e_by_mode[3]
     # precision 4, batch invariance and determinism of the two-set pair GEMMs / the producers' lo copies: pair 1's logits alone, bit for bit
     m.precision = 4
     full4 = m.forward_cfg(t.to(DEV), y.to(DEV))
