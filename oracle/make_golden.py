@@ -144,6 +144,9 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # round 6: a THIRD trained-like 12-bit run, HELD OUT (recorded after precision 4 and its escalation rule were built on the two runs above): another seed
     # and a heavier family (maskbit_amd/synth.py style "outlier2": weight kurtosis 17.2 instead of 10.9, ten massive-activation channels instead of six), batch 8
     "sample_full12_64_outlier2": (12, 197, 14.0, 8, FULL64, False, 4338, 3, "outlier2"),
+    # ... and a second one of that family, recorded after the round's LAST precision decision (which GEMMs carry the activation-lo sets: profiles/r06_coverage.md, a study
+    # the run above took part in) was frozen: other seed, head gain 16, noise, labels
+    "sample_full12_64_outlier2_s2": (12, 198, 16.0, 8, FULL64, False, 4339, 7, "outlier2"),
 }
 # sampler arguments of demo_utils.sample (demo_utils.py:139-157); guidance scale / temperature / steps are the notebook's arguments: sample()'s own defaults, 64 steps
 DEMO64 = dict(num_steps=64, guidance_scale=3.0, guidance_annealing="none", scale_pow=1.0, randomize_temperature=4.5, mask_schedule_strategy="arccos")
