@@ -44,6 +44,7 @@ RUN_C3_PRENORM = "sample_full12_64_prenorm"          # configs[2]'s sampler on t
 RUN_C3_SEQ1024 = "sample_full12_64_seq1024"          # use_prenorm=True, and the 512 x 512 models' 1024 + 1 tokens
 RUN_C3_OUTLIER2 = "sample_full12_64_outlier2"        # round 6: a third trained-like 12-bit run, held out, of a heavier family (synth style "outlier2")
 RUN_C3_OUTLIER2_S2 = "sample_full12_64_outlier2_s2"  # ... and a second one, recorded after the activation-lo coverage (the round's last precision decision) was frozen
+RUN_C3_OUTLIER2_S3 = "sample_full12_64_outlier2_s3"  # (the second one is an easy run -- single fp16 1.5e-4 --: a third, head gain 12)
 RUN_DEMO14 = "sample_full14_demo"                    # round 6: the demo's call site (demo_utils.py:139-157, configs/demo/demo.yaml): 14-bit, guidance 3.0 with annealing "none", 64 steps
 
 

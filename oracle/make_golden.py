@@ -147,6 +147,9 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     # ... and a second one of that family, recorded after the round's LAST precision decision (which GEMMs carry the activation-lo sets: profiles/r06_coverage.md, a study
     # the run above took part in) was frozen: other seed, head gain 16, noise, labels
     "sample_full12_64_outlier2_s2": (12, 198, 16.0, 8, FULL64, False, 4339, 7, "outlier2"),
+    # (that run turned out EASY -- single fp16 measures 1.5e-4 on it: few near-ties with these weights --, so a third one of the family with the head gain of most
+    #  other runs was recorded as well; both are reported)
+    "sample_full12_64_outlier2_s3": (12, 199, 12.0, 8, FULL64, False, 4340, 1, "outlier2"),
 }
 # sampler arguments of demo_utils.sample (demo_utils.py:139-157); guidance scale / temperature / steps are the notebook's arguments: sample()'s own defaults, 64 steps
 DEMO64 = dict(num_steps=64, guidance_scale=3.0, guidance_annealing="none", scale_pow=1.0, randomize_temperature=4.5, mask_schedule_strategy="arccos")

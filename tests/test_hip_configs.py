@@ -184,7 +184,7 @@ def test_held_out_trained_like_run_of_a_heavier_family():
     from maskbit_amd import parity_replay as R
     # (the second run of the family was recorded after the round's last precision decision -- the activation-lo coverage, profiles/r06_coverage.md, a study the
     #  first one took part in -- was frozen)
-    for name in (R.RUN_C3_OUTLIER2, R.RUN_C3_OUTLIER2_S2):
+    for name in (R.RUN_C3_OUTLIER2, R.RUN_C3_OUTLIER2_S2, R.RUN_C3_OUTLIER2_S3):
         g = R.load_run(name)
         gen, _ = R.build_models(DEV, with_tokenizer=False, name=name)
         st = gen.weight_statistics()

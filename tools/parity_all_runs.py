@@ -13,7 +13,7 @@ GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C
           "HELD-OUT run: configs[1]": [R.RUN_CFG1_S4],
           "HELD-OUT run: configs[4]": [R.RUN_CFG5_S5],
           "trained-like weights (heavy tails, massive-activation channels): configs[2]": [R.RUN_C3_OUTLIER, R.RUN_C3_OUTLIER_S2],
-          "HELD-OUT trained-like run of a heavier family (round 6): configs[2]": [R.RUN_C3_OUTLIER2, R.RUN_C3_OUTLIER2_S2],
+          "HELD-OUT trained-like run of a heavier family (round 6): configs[2]": [R.RUN_C3_OUTLIER2, R.RUN_C3_OUTLIER2_S2, R.RUN_C3_OUTLIER2_S3],
           "the demo's call site (round 6): 14-bit, guidance 3.0 with annealing none, 64 steps": [R.RUN_DEMO14],
           "trained-like weights: configs[1]": [R.RUN_CFG1_OUTLIER],
           "use_prenorm=True, configs[2]'s sampler": [R.RUN_C3_PRENORM],
