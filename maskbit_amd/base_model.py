@@ -119,6 +119,11 @@ class BaseModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ engine plumbing
     def _weight_signature(self):
+        """Identity of the current weights (storage, in-place version counter, dtype per entry).  Computed once per engine() call -- the walk over ~300 entries costs
+        ~1 ms of host time and engine() sits on the per-step-chunk path --: a caller may hand the value on (`_sig_hint`) for the duration of ONE call."""
+        hint = getattr(self, "_sig_hint", None)
+        if hint is not None:
+            return hint
         return tuple((k, t.data_ptr(), t._version, t.dtype) for k, t in self.state_dict(keep_vars=True).items())
 
     def _require_cuda(self, what: str) -> torch.device:

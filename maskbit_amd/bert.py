@@ -192,10 +192,15 @@ class LFQBert(BaseModel):
 
     def engine(self, min_seqs: int):
         """Device engine able to hold ``min_seqs`` sequences (CFG needs 2 x batch)."""
-        if self._engine is not None and self._engine_split != self.resolved_precision():
-            self._drop_engine()                                    # precision mode changed (the knob, or new weights under the auto rule): rebuild and repack
-        have = self._engine_key[1] if self._engine_key else 0
-        h = self._ensure_engine(max(min_seqs, have, 16))
+        self._sig_hint = None
+        self._sig_hint = self._weight_signature()                  # one walk over the parameters for the auto rule AND the reload check of this call
+        try:
+            if self._engine is not None and self._engine_split != self.resolved_precision():
+                self._drop_engine()                                # precision mode changed (the knob, or new weights under the auto rule): rebuild and repack
+            have = self._engine_key[1] if self._engine_key else 0
+            h = self._ensure_engine(max(min_seqs, have, 16))
+        finally:
+            self._sig_hint = None
         wf = (max(0, min(int(self.wcorr_from), self.depth)), int(self.wcorr_mask) & 15)
         if getattr(self, "_engine_wfrom", None) != wf:
             _lib.check(_lib.load().mb_gen_set_wcorr(h, wf[0], wf[1]), "mb_gen_set_wcorr")
