@@ -179,3 +179,55 @@ def test_pair_attention_e2m1_copy_of_the_conditional_outputs(pairs, N):
     print(f"attention outputs vs fp64 on the same fp16 q / k / v: fp16 rows {e_hi:.3e}, + decoded e2m1 lo halves {e_lo:.3e}")
     assert e_lo < 0.8 * e_hi
     assert int(out4l[pairs * N:].count_nonzero()) == 0
+
+
+@pytest.mark.timeout(900)
+def test_activation_lo_coverage_knob_and_mode_identities():
+    """The precision modes are nested selections of the same machinery, bit for bit (full-width two-layer generator, guided forward of 3 pairs):
+    precision 4 with its activation-lo sets switched off (mb_gen_set_alo mask 0) IS precision 2; precision 4 narrowed to out-proj + FFN-up (mask 6) IS precision 3;
+    the knob refuses what the handle was not built with; and mb_sample at precision 4 equals the forward + step composition in which EVERY step of a guided run --
+    the zero-scale ones too -- takes the guided forward."""
+    from maskbit_amd import _lib
+    from maskbit_amd.sampling import build_plan, draw_noise, run_loop
+    lib = _lib.load()
+    cfg = O.GenCfg(bits=12, splits=2, depth=2)
+    sd = O.make_generator_weights(cfg, seed=31, head_gain=12.0)
+    from hip_helpers import hip_generator
+    m = hip_generator(cfg, sd)
+    g = torch.Generator().manual_seed(9)
+    t = torch.randint(0, 65, (3, 256, 2), generator=g).to(DEV)
+    y = torch.tensor([5, 321, 999], device=DEV)
+    out = {}
+    for prec in (2, 3, 4):
+        m.precision, m.alo_mask = prec, None
+        out[prec] = m.forward_cfg(t, y)
+    assert not torch.equal(out[2], out[3]) and not torch.equal(out[3], out[4])
+    m.precision, m.alo_mask, m.alo_from = 4, 0, 0
+    assert torch.equal(m.forward_cfg(t, y), out[2])
+    m.alo_mask = 6
+    assert torch.equal(m.forward_cfg(t, y), out[3])
+    m.alo_mask = 14
+    assert torch.equal(m.forward_cfg(t, y), out[4])
+    m.alo_mask = 15                                                  # the QKV set: built at precision 4 for coverage studies, not run by default
+    assert not torch.equal(m.forward_cfg(t, y), out[4])
+    m.precision, m.alo_mask = 3, 14                                  # a precision-3 handle holds the operands of out-proj + FFN-up only
+    with pytest.raises(RuntimeError, match="created"):
+        m.forward_cfg(t, y)
+    # mb_sample at precision 4 == composition with the guided forward at every step (cosine annealing: the scale of steps 0 .. 2 is exactly 0)
+    m.precision, m.alo_mask = 4, None
+    N, B = 8, 3
+    plan = build_plan(N, 512, 7.1, "cosine", 3.0, 1.0, False, "arccos")
+    assert plan[0][0] == 0.0 and plan[0][-1] != 0.0
+    torch.manual_seed(3)
+    q, c = draw_noise(B, 256, 2, 64, N, 8.2, torch.device(DEV))
+    _, _, steps, _ = run_loop(m, None, y, plan, q, c, want_image=False)
+    tok = torch.full((B, 256, 2), 64, dtype=torch.int64, device=DEV)
+    for i in range(N):
+        lg = m.forward_cfg(tok, y)
+        lc, lu = lg[:B].contiguous(), lg[B:].contiguous()
+        tout, pred = torch.empty_like(tok), torch.empty_like(tok)
+        _lib.check(lib.mb_sample_step(lc.data_ptr(), lu.data_ptr(), plan[0][i], plan[1][i], q[i].data_ptr(), c[i].data_ptr(), plan[2][i], tok.data_ptr(),
+                                      tout.data_ptr(), pred.data_ptr(), B, 256, 2, 64, torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(pred, steps[i]), f"step {i}"
+        tok = tout
+    m.precision = -1
