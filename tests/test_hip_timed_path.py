@@ -21,15 +21,16 @@ DEV = "cuda"
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("bits,pair", [(12, 2), (14, 3)])
-def test_guided_forward_batch_invariance_full_size(bits, pair):
+@pytest.mark.parametrize("bits,pair,style", [(12, 2, "gaussian"), (14, 3, "gaussian"), (12, 4, "outlier")])
+def test_guided_forward_batch_invariance_full_size(bits, pair, style):
     """forward_cfg (mb_gen_forward_cfg) at BASELINE's full width: pair i's conditional and label-dropped logits are bit-identical at
-    B = 1, 4, 31, 32 and 64 pairs -- 32 to 2 048 pair tiles per GEMM, 1 to 8 persistent rounds, ragged last rounds at 31."""
+    B = 1, 4, 31, 32 and 64 pairs -- 32 to 2 048 pair tiles per GEMM, 1 to 8 persistent rounds, ragged last rounds at 31.  The three product defaults:
+    precision 2 (12-bit), 3 (14-bit) and -- a trained-like checkpoint escalated by its statistics -- 4."""
     cfg = O.GenCfg(bits=bits, splits=2)
-    sd = O.make_generator_weights(cfg, seed=100, head_gain=12.0)
+    sd = O.make_generator_weights(cfg, seed=100, head_gain=12.0, style=style)
     m = hip_generator(cfg, sd)
     m.precision = -1
-    assert m.resolved_precision() == pair                          # the product default of this codebook
+    assert m.resolved_precision() == pair                          # the product default of this codebook / checkpoint
     g = torch.Generator().manual_seed(bits)
     C_ = cfg.group_codes
     tok = torch.randint(0, C_ + 1, (64, 256, 2), generator=g)
@@ -58,7 +59,7 @@ def _w4(lib, N, K, lo=True):
 
 
 @pytest.mark.parametrize("epi,pairs,N,K,nlo", [(0, 5, 1024, 1024, 1), (0, 5, 768, 1024, 2), (1, 5, 1024, 1024, 1), (1, 4, 1024, 1024, 2), (2, 5, 1024, 1024, 1),
-                                               (2, 5, 1024, 4096, 1)])
+                                               (2, 5, 1024, 4096, 1), (2, 5, 1024, 1024, 2), (2, 4, 1024, 4096, 2)])   # (the last two, round 6: out-proj / FFN-down with an activation-lo set: precision 3 / 4)
 def test_pair_mini_tile_kernels_walked_by_fewer_workgroups_give_the_same_bits(epi, pairs, N, K, nlo):
     """Pair tiles with correction mini-tiles (the kernels of the timed guided forward: QKV / FFN-up / the two residual GEMMs; FFN-down's K = 4096 with
     32 mini-tiles per tile): 256 workgroups (one tile each), 24 and 8 workgroups (up to 5 tiles each -- the mini-tile buffer, the scale dwords and the
@@ -88,9 +89,11 @@ def test_pair_mini_tile_kernels_walked_by_fewer_workgroups_give_the_same_bits(ep
             out16 = torch.full((2 * P, N), float("nan"), device=DEV, dtype=torch.float16) if epi != 2 else None
             out4 = torch.zeros(2 * P, 2 * N, device=DEV, dtype=torch.uint8) if epi == 1 else None
             out4s = torch.zeros((N // 64) * pairs * 256 + 256, device=DEV, dtype=torch.uint8) if epi == 1 else None
-            gemm_mini(lib, epi, A, W, bias, out32, out32, out16, P, True, N, K, sets, out4, out4s)
+            out4l = torch.zeros_like(out4) if (epi == 1 and nlo == 2) else None         # (FFN-up at precision 4 also writes the lo halves' copy for FFN-down's set)
+            out4ls = torch.zeros_like(out4s) if (epi == 1 and nlo == 2) else None
+            gemm_mini(lib, epi, A, W, bias, out32, out32, out16, P, True, N, K, sets, out4, out4s, 0, out4l, out4ls)
             torch.cuda.synchronize()
-            outs.append((out32 if out32 is not None else out16, out4, out4s))
+            outs.append((out32 if out32 is not None else out16, out4, out4s, out4l, out4ls))
     finally:
         lib.mb_set_cu_count(0)
     assert torch.isfinite(outs[0][0].float()).all()
@@ -99,6 +102,8 @@ def test_pair_mini_tile_kernels_walked_by_fewer_workgroups_give_the_same_bits(ep
         if epi == 1:
             keep = (torch.arange(P, device=DEV) % 257) < 256            # (class-token rows take no part in the e2m1 copy)
             assert torch.equal(o[1][:P][keep][:, : N // 2], outs[0][1][:P][keep][:, : N // 2]) and torch.equal(o[2], outs[0][2])
+            if nlo == 2:
+                assert torch.equal(o[3][:P][keep][:, : N // 2], outs[0][3][:P][keep][:, : N // 2]) and torch.equal(o[4], outs[0][4])
 
 
 @pytest.mark.parametrize("epi,nseq,N,K", [(0, 9, 768, 1024), (1, 9, 1024, 1024), (2, 3, 1024, 1024), (2, 3, 1024, 4096)])
