@@ -119,3 +119,21 @@ def test_return_attn_full_width():
     assert float((logits.cpu() - ref_logits).norm() / ref_logits.norm()) < 2e-3
     for l in range(2):
         assert float((attn[l].cpu() - ref_attn[l]).abs().max()) < 1e-3
+
+
+def test_embed_tables_engine_rejects_lfqbert_only_checkpoint_entries():
+    """An embedding-table (`Bert`) engine has neither a bit projection nor an untied prediction layer (bert.py:222-262): `prediction_layer.*` / `input_proj.*` of an
+    LFQBert checkpoint are unknown entries there (code -2) -- round 5's advisor found that `prediction_layer.weight` reached the hi / lo split with a null lo plane."""
+    import ctypes as C
+    from maskbit_amd import _lib
+    cfg = O.GenCfg(bits=12, splits=2, hidden=128, depth=1, heads=2, mlp=256, nclass=10, kind="bert")
+    m = _build(cfg, O.make_generator_weights(cfg, seed=5))
+    h = m.engine(4)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for name, shape in (("prediction_layer.weight", (128, 128)), ("prediction_layer.bias", (128,)), ("input_proj.weight", (128, 12)), ("input_proj.bias", (128,))):
+        w = torch.zeros(shape, device=DEV)
+        rc = lib.mb_gen_load(h, name.encode(), w.data_ptr(), (C.c_int64 * len(shape))(*shape), len(shape), st)
+        assert rc == -2 and b"unknown checkpoint entry" in lib.mb_last_error(), (name, rc)
+    t = torch.randint(0, 65, (2, 256, 2), device=DEV)
+    assert torch.isfinite(m(t, torch.tensor([1, 2], device=DEV), torch.zeros(2, dtype=torch.bool, device=DEV))).all()      # the handle is intact
