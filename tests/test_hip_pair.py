@@ -231,3 +231,40 @@ def test_activation_lo_coverage_knob_and_mode_identities():
         assert torch.equal(pred, steps[i]), f"step {i}"
         tok = tout
     m.precision = -1
+
+
+@pytest.mark.timeout(900)
+def test_guided_and_plain_forward_at_hidden_768():
+    """The other trunk width the pair / mini tiles serve (hidden 768 = the reference constructor's default width, 12 heads of 64, mlp 3072; K = 768 = six
+    mini-tiles per operand set, N = 768 / 2 304 / 3 072: three / nine / twelve 256-column tiles): guided forward at every precision against the fp32 oracle --
+    each step closer in the guided combination --, pair batch invariance, the plain forward with and without the weight correction."""
+    from hip_helpers import hip_generator
+    cfg = O.GenCfg(bits=12, splits=2, hidden=768, depth=2, heads=12, mlp=3072)
+    sd = O.make_generator_weights(cfg, seed=41, head_gain=12.0)
+    m = hip_generator(cfg, sd)
+    assert m.resolved_precision() == 2
+    g = torch.Generator().manual_seed(11)
+    t = torch.randint(0, 65, (3, 256, 2), generator=g)
+    y = torch.tensor([5, 321, 999])
+    drop = torch.cat([torch.zeros(3, dtype=torch.bool), torch.ones(3, dtype=torch.bool)])
+    ref = O.lfq_bert_forward(sd, cfg, torch.cat([t, t]), torch.cat([y, y]), drop)
+    guided = lambda lg: lg[:3] + 6.0 * (lg[:3] - lg[3:])
+    m.precision = 0
+    plain0 = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV))
+    assert torch.equal(m.forward_cfg(t.to(DEV), y.to(DEV)), plain0)
+    e = {0: float((guided(plain0.cpu()) - guided(ref)).abs().mean())}
+    for prec in (1, 2, 3, 4):
+        m.precision = prec
+        lg = m.forward_cfg(t.to(DEV), y.to(DEV))
+        assert float((lg.cpu() - ref).norm() / ref.norm()) < 2e-3
+        e[prec] = float((guided(lg.cpu()) - guided(ref)).abs().mean())
+        one = m.forward_cfg(t[1:2].to(DEV), y[1:2].to(DEV))
+        assert torch.equal(one[0], lg[1]) and torch.equal(one[1], lg[4])
+    print(f"hidden 768: mean |guided logit error| by precision {e}")
+    assert e[1] < 0.6 * e[0] and e[2] < 0.85 * e[1] and e[3] < e[2] and e[4] < e[3]
+    m.precision = 2
+    w = m(torch.cat([t, t]).to(DEV), torch.cat([y, y]).to(DEV), drop.to(DEV)).cpu()
+    e_w, e_0 = float((w - ref).abs().mean()), float((plain0.cpu() - ref).abs().mean())
+    print(f"hidden 768, plain forward: mean |logit error| single fp16 {e_0:.4f}, default {e_w:.4f}")
+    assert e_w < 0.75 * e_0 and m.saturation_count() == 0
+    m.precision = -1
