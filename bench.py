@@ -267,7 +267,7 @@ def variant_configs(dev):
             ("variant: Bert (embedding tables, tied head), 12-bit/64 steps/CFG 7.1", Bert, dict(), synth.GenCfg(bits=12, splits=2, kind="bert"), 64, "gaussian"),
             ("variant: 1024 + 1 tokens (512 x 512 models), 12-bit/64 steps/CFG 7.1", LFQBert, dict(img_size=512), synth.GenCfg(bits=12, splits=2, seq=1024), 16, "gaussian"),
             # the ESCALATED mode (round 6): configs[2]'s workload on a heavy-tailed ("trained-like") checkpoint, which the auto mode escalates from its own
-            # statistics to precision 4 (activation-lo mini-tiles on every trunk GEMM of every layer): what that mode costs against the headline's precision 2
+            # statistics to precision 4 (activation-lo mini-tiles in out-proj, FFN-up and FFN-down of every layer): what that mode costs against the headline's precision 2
             ("escalated: trained-like (heavy-tailed) 12-bit checkpoint, auto precision, 64 steps/CFG 7.1", LFQBert, dict(), synth.GenCfg(bits=12, splits=2), 64, "outlier")):
         try:
             gen = cls(**dict(GEN, **kw))
