@@ -45,6 +45,8 @@ RUN_C3_SEQ1024 = "sample_full12_64_seq1024"          # use_prenorm=True, and the
 RUN_C3_OUTLIER2 = "sample_full12_64_outlier2"        # round 6: a third trained-like 12-bit run, held out, of a heavier family (synth style "outlier2")
 RUN_C3_OUTLIER2_S2 = "sample_full12_64_outlier2_s2"  # ... and a second one, recorded after the activation-lo coverage (the round's last precision decision) was frozen
 RUN_C3_OUTLIER2_S3 = "sample_full12_64_outlier2_s3"  # (the second one is an easy run -- single fp16 1.5e-4 --: a third, head gain 12)
+RUN_16BIT = "sample_full16_64"                       # round 6: the other shipped codebooks (README.md:74-75), each with its own yaml's sampler: 16-bit (C = 256 per group) ...
+RUN_18BIT = "sample_full18_64"                       # ... and 18-bit (C = 512)
 RUN_DEMO14 = "sample_full14_demo"                    # round 6: the demo's call site (demo_utils.py:139-157, configs/demo/demo.yaml): 14-bit, guidance 3.0 with annealing "none", 64 steps
 
 

@@ -151,6 +151,12 @@ RUNS = {   # fixture name -> (bits, generator seed, head gain, B, sampler kwargs
     #  other runs was recorded as well; both are reported)
     "sample_full12_64_outlier2_s3": (12, 199, 12.0, 8, FULL64, False, 4340, 1, "outlier2"),
 }
+# round 6, end: the other two shipped generator codebooks (README.md:74-75; BASELINE.json names 10 / 12 / 14 bits only): 16-bit (C = 256 per group) and 18-bit (C = 512), each with
+# the sampler block of its own yaml (configs/generator/maskbit_generator_16bit.yaml / _18bit.yaml:38-48), 64 steps
+CFG16_64 = dict(num_steps=64, guidance_scale=6.5, guidance_annealing="cosine", scale_pow=2.5, randomize_temperature=7.5, mask_schedule_strategy="arccos")
+CFG18_64 = dict(num_steps=64, guidance_scale=5.7, guidance_annealing="cosine", scale_pow=2.5, randomize_temperature=8.5, mask_schedule_strategy="arccos")
+RUNS["sample_full16_64"] = (16, 201, 12.0, 4, CFG16_64, False, 4341, 2)
+RUNS["sample_full18_64"] = (18, 202, 12.0, 2, CFG18_64, False, 4342, 9)
 # sampler arguments of demo_utils.sample (demo_utils.py:139-157); guidance scale / temperature / steps are the notebook's arguments: sample()'s own defaults, 64 steps
 DEMO64 = dict(num_steps=64, guidance_scale=3.0, guidance_annealing="none", scale_pow=1.0, randomize_temperature=4.5, mask_schedule_strategy="arccos")
 RUNS["sample_full14_demo"] = RUNS["sample_full14_demo"][:4] + (DEMO64,) + RUNS["sample_full14_demo"][5:]

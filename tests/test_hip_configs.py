@@ -244,6 +244,18 @@ def test_demo_call_site_14bit_vs_reference_run():
     assert tot == 84284 and bad / tot <= 1e-3 and bad < r["single fp16"][0]
 
 
+@pytest.mark.timeout(900)
+def test_other_shipped_codebooks_16_and_18_bit_vs_reference_runs():
+    """The two shipped generator codebooks BASELINE.json does not name (README.md:74-75): 16-bit (C = 256 per group) and 18-bit (C = 512), each with the sampler
+    block of its own yaml (guidance 6.5 / 5.7 cosine, scale_pow 2.5, 64 steps), full-size runs of the REAL reference (oracle/make_golden.py RUNS sample_full16_64: batch 4,
+    84 284 positions; sample_full18_64: batch 2, 42 142), teacher-forced in the product default (precision 3 at 8 / 9 bits per group)."""
+    from maskbit_amd import parity_replay as R
+    for name, tot_want in ((R.RUN_16BIT, 84284), (R.RUN_18BIT, 42142)):
+        r = _vs_reference_run(name, [("product default", -1), ("single fp16", 0)])
+        bad, tot = r["product default"]
+        assert tot == tot_want and bad / tot <= 1e-3 and bad < r["single fp16"][0], (name, bad, tot)
+
+
 def _full_length_run(bits, num_steps, B, kw, seed):
     """A complete free-running mb_sample of a BASELINE configuration at full size and full length, checked through the size-independent
     properties of the loop (sampling.py:81-131): the run is deterministic; it equals, bit for bit, the step-by-step composition

@@ -16,6 +16,7 @@ GROUPS = {"configs[2] 12-bit / 64 steps / CFG 7.1": ["sample_full12_64", R.RUN_C
           "HELD-OUT trained-like run of a heavier family (round 6): configs[2]": [R.RUN_C3_OUTLIER2, R.RUN_C3_OUTLIER2_S2, R.RUN_C3_OUTLIER2_S3],
           "the demo's call site (round 6): 14-bit, guidance 3.0 with annealing none, 64 steps": [R.RUN_DEMO14],
           "trained-like weights: configs[1]": [R.RUN_CFG1_OUTLIER],
+          "the other shipped codebooks (round 6): 16-bit / 18-bit, 64 steps, their own yaml's sampler": [R.RUN_16BIT, R.RUN_18BIT],
           "use_prenorm=True, configs[2]'s sampler": [R.RUN_C3_PRENORM],
           "1024 + 1 tokens (512 x 512 models), configs[2]'s sampler": [R.RUN_C3_SEQ1024]}
 MODES = (("default", -1), ("differential only (precision 1)", 1))
